@@ -1,0 +1,224 @@
+/*
+ * wft.h — C ABI of libwft.so, the MI355X (gfx950) kernel library behind the
+ * whisper_finetune training hot path.
+ *
+ * The reference (i4Ds/whisper-finetune) has no FFI of its own: its hot path is
+ * Python calling PyTorch / openai-whisper / torchaudio ops.  Each entry point
+ * below names the reference call site (path relative to the reference root,
+ * file:line) whose arithmetic it replaces.  The Python host side
+ * (whisper-finetune_amd/whisper_finetune/engine/lib.py) binds these with ctypes;
+ * INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is a DEVICE pointer unless
+ *    the name ends in _host; the caller (PyTorch's allocator) owns every buffer
+ *    including workspaces;
+ *  - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*):
+ *    no host sync, no allocation, no default-stream use, no device state kept
+ *    in the library — re-entrant across streams and threads;
+ *  - return value: WFT_OK (0) or a negative wft_status; wft_last_error() gives
+ *    a thread-local message for the last failure on the calling thread;
+ *  - matrices are row-major; `ld*` are leading dimensions in ELEMENTS;
+ *  - "bf16" buffers hold IEEE bfloat16 (uint16_t storage), "f32" IEEE float;
+ *  - RNG-dependent ops take ALREADY-DRAWN parameters so the host keeps the
+ *    reference's CPU-generator draw order (SURVEY.md §7 "RNG parity").
+ */
+#ifndef WFT_H
+#define WFT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  WFT_OK = 0,
+  WFT_ERR_ARG = -1,     /* bad shape / alignment / null pointer            */
+  WFT_ERR_LAUNCH = -2,  /* hipLaunchKernel failed (message has the reason) */
+  WFT_ERR_UNSUPPORTED = -3
+} wft_status;
+
+typedef uint16_t wft_bf16;
+
+const char* wft_last_error(void);
+/* library version + compiled arch string, e.g. "wft 0.1 gfx950" */
+const char* wft_version(void);
+
+/* ------------------------------------------------------------------ casts */
+/* fp32 master weight -> bf16 shadow (what `W.to(x.dtype)` does on every
+ * whisper.model.Linear.forward under autocast).        */
+int wft_cast_f32_bf16(const float* src, wft_bf16* dst, int64_t n, void* stream);
+int wft_cast_bf16_f32(const wft_bf16* src, float* dst, int64_t n, void* stream);
+/* src f32 [rows, cols] -> dst bf16 [rows_pad, cols_pad] (zero padded) and, if
+ * dst_t != NULL, dst_t bf16 [cols_pad, rows_pad] (the transposed shadow the
+ * backward-data GEMM consumes).  rows_pad>=rows, cols_pad>=cols.            */
+int wft_cast_pad_transpose_f32_bf16(const float* src, int64_t rows, int64_t cols,
+                                    wft_bf16* dst, wft_bf16* dst_t,
+                                    int64_t rows_pad, int64_t cols_pad, void* stream);
+/* y[i] = a[i] + b[i] (bf16) — gradient accumulation on the residual stream. */
+int wft_add_bf16(const wft_bf16* a, const wft_bf16* b, wft_bf16* y, int64_t n, void* stream);
+/* out[c] (+)= sum_r x[r, c] — bias gradients.  x bf16 [rows, ld], out f32[cols] */
+int wft_colsum_bf16(const wft_bf16* x, int64_t rows, int64_t cols, int64_t ld,
+                    float* out, int accumulate, void* stream);
+
+/* -------------------------------------------------------------- LayerNorm */
+/* whisper.model.LayerNorm.forward = F.layer_norm(x.float()).type(x.dtype)
+ * (call sites model/model_utils.py:287,324 and every
+ * ResidualAttentionBlock).  x,y bf16 [rows, cols]; gamma,beta f32[cols];
+ * mean,rstd f32[rows] are saved for the backward.  cols % 8 == 0, <= 2048.
+ * Optional deep-SpecAugment masks (model/model_utils.py:409-417): if
+ * rows_per_batch > 0, rows t in [t0,t1) of every batch item and columns in
+ * [c0,c1) are zero-filled in y (time mask then "frequency"=channel mask).   */
+int wft_layernorm_fwd(const wft_bf16* x, const float* gamma, const float* beta,
+                      wft_bf16* y, float* mean, float* rstd,
+                      int64_t rows, int cols, float eps,
+                      int rows_per_batch, int t0, int t1, int c0, int c1,
+                      void* stream);
+/* dx = LN'(dy) (+ dres if dres != NULL); dgamma/dbeta are ACCUMULATED (+=).
+ * partial: f32 workspace of wft_layernorm_bwd_workspace(rows, cols) bytes.
+ * The same mask arguments zero the masked positions of dy first.            */
+int64_t wft_layernorm_bwd_workspace(int64_t rows, int cols);
+int wft_layernorm_bwd(const wft_bf16* dy, const wft_bf16* x, const float* gamma,
+                      const float* mean, const float* rstd, const wft_bf16* dres,
+                      wft_bf16* dx, float* dgamma, float* dbeta, void* partial,
+                      int64_t rows, int cols,
+                      int rows_per_batch, int t0, int t1, int c0, int c1,
+                      void* stream);
+
+/* ------------------------------------------------------------------- GEMM */
+/* Epilogue selector for wft_gemm_nt_bf16. */
+enum {
+  WFT_EPI_NONE = 0,
+  WFT_EPI_GELU = 1,   /* C = gelu_erf(acc + bias); if aux != NULL also store pre-activation there */
+  WFT_EPI_DGELU = 2   /* C = acc * gelu'(aux)  (backward through GELU; aux = saved pre-activation) */
+};
+/* C[b][m, n] = alpha * sum_k A[b][m, k] * B[b][n, k]  (+ bias[n]) (epilogue)
+ *              (+ residual[b][m, n]);  bf16 inputs, fp32 MFMA accumulation.
+ * Replaces whisper.model.Linear / Conv1d / the tied logits matmul
+ * (model/model_utils.py:276-277,325).
+ *  A: bf16, row m at A + b*strideA + m*lda, K contiguous (lda may be < K:
+ *     overlapping rows = im2col-free conv1d windows);
+ *  B: bf16 [N, K] K contiguous (a Linear weight as stored, or a transposed
+ *     shadow for backward-data);  C: bf16 or f32 (c_is_f32), ldc;
+ *  accumulate: C += result (only with c_is_f32);
+ *  valid_rows_period/valid_rows: if period > 0, rows with (m % period) >=
+ *     valid_rows are written as zero (keeps conv pad rows zero);
+ *  K % 64 == 0, N % 128 == 0, M >= 1; all base pointers 16-byte aligned,
+ *  lda/ldb % 8 == 0.                                                         */
+typedef struct {
+  const wft_bf16* A; int64_t lda; int64_t strideA;
+  const wft_bf16* B; int64_t ldb; int64_t strideB;
+  void* C; int64_t ldc; int64_t strideC; int c_is_f32; int accumulate;
+  const float* bias;                    /* f32 [N] or NULL                    */
+  const wft_bf16* residual; int64_t ldr; int64_t strideR;  /* or NULL         */
+  wft_bf16* aux; int64_t ldaux; int64_t strideAux;         /* see epilogues    */
+  int epilogue; float alpha;
+  int64_t M; int64_t N; int64_t K; int batch;
+  int valid_rows_period; int valid_rows;
+} wft_gemm_args;
+int wft_gemm_nt_bf16(const wft_gemm_args* args, void* stream);
+/* C[p, q] (+)= alpha * sum_r A[r, p] * B[r, q]   (weight gradients dW = dY^T X:
+ * what autograd's mm-backward computes for whisper.model.Linear).
+ *  A bf16 [R, P] (row r at A + r*lda, P contiguous), B bf16 [R, Q];
+ *  C f32 or bf16 [P, Q].  P % 128 == 0, Q % 128 == 0, any R >= 1.
+ *  Uses the same wft_gemm_args: M:=P, N:=Q, K:=R; bias/residual/aux ignored.
+ *  batch > 1 sums over the batch as extra reduction (conv weight grads).     */
+int wft_gemm_tn_bf16(const wft_gemm_args* args, void* stream);
+
+/* -------------------------------------------------------------- Attention */
+/* whisper.model.MultiHeadAttention.qkv_attention:
+ * softmax(q k^T / sqrt(64) [+ causal mask]) v, head_dim fixed to 64.
+ * q: bf16, element (b, t, h, d) at q + b*q_bs + t*ldq + h*64 + d (so a fused
+ * [B*T, 3*d_model] QKV buffer is consumed in place); same for k, v, o, do,
+ * dq, dk, dv.  lse f32 [B, H, Tq] = log-sum-exp of the scaled scores (saved
+ * for backward).  causal != 0: key j visible to query i iff j <= i.          */
+typedef struct {
+  const wft_bf16* q; int64_t ldq; int64_t q_bs;
+  const wft_bf16* k; int64_t ldk; int64_t k_bs;
+  const wft_bf16* v; int64_t ldv; int64_t v_bs;
+  wft_bf16* o; int64_t ldo; int64_t o_bs;
+  float* lse;
+  int B; int H; int Tq; int Tk; int causal; float scale;
+  /* backward only */
+  const wft_bf16* d_o; int64_t lddo; int64_t do_bs;
+  float* delta;                 /* f32 workspace [B, H, Tq]                  */
+  wft_bf16* dq; int64_t lddq; int64_t dq_bs;
+  wft_bf16* dk; int64_t lddk; int64_t dk_bs;
+  wft_bf16* dv; int64_t lddv; int64_t dv_bs;
+} wft_attn_args;
+int wft_attn_fwd_bf16(const wft_attn_args* args, void* stream);
+int wft_attn_bwd_bf16(const wft_attn_args* args, void* stream);
+
+/* -------------------------------------------------------------- Embedding */
+/* TextDecoder: x = token_embedding(tokens) + positional_embedding[:S]
+ * (model/model_utils.py:317-318).  tokens i64 [B*S]; emb f32 [V, d];
+ * pos f32 [n_ctx, d]; out bf16 [B*S, d].                                     */
+int wft_embed_fwd(const int64_t* tokens, const float* emb, const float* pos,
+                  wft_bf16* out, int64_t B, int64_t S, int d, int64_t V, void* stream);
+/* demb[tokens[i], :] += dout[i, :] (f32 atomics), dpos[s, :] += sum_b dout.   */
+int wft_embed_bwd(const int64_t* tokens, const wft_bf16* dout, float* demb, float* dpos,
+                  int64_t B, int64_t S, int d, int64_t V, void* stream);
+
+/* ---------------------------------------------------------- Cross entropy */
+/* F.cross_entropy(logits.transpose(1,2), y_out, label_smoothing=eps),
+ * ignore_index = -100, mean over non-ignored targets
+ * (model/model_utils.py:66).  logits bf16 [rows, ld] (only the first V
+ * columns are read); targets i64 [rows].
+ * fwd: row_loss f32[rows] (0 for ignored rows), row_lse f32[rows],
+ *      stats f32[2] = {sum of row losses, number of valid rows} (zeroed by
+ *      the call, then accumulated) — loss = stats[0] / stats[1].
+ * bwd: dlogits (bf16, may alias logits) = (softmax - ((1-eps) onehot + eps/V))
+ *      * valid * gscale[0] / stats[1]; columns [V, ld) are written as 0.
+ *      gscale: device f32[1] (the upstream grad of the mean loss).
+ * argmax (optional, may be NULL): i64 [rows] = argmax over the V columns,
+ *      lowest index on ties (eval/evaluator.py:70-73 teacher-forced argmax).  */
+int wft_ce_fwd(const wft_bf16* logits, int64_t ld, const int64_t* targets,
+               int64_t rows, int64_t V, float label_smoothing,
+               float* row_loss, float* row_lse, float* stats, int64_t* argmax,
+               void* stream);
+int wft_ce_bwd(const wft_bf16* logits, int64_t ld, const int64_t* targets,
+               int64_t rows, int64_t V, float label_smoothing,
+               const float* row_lse, const float* stats, const float* gscale,
+               wft_bf16* dlogits, void* stream);
+
+/* ------------------------------------------------- Log-mel + SpecAugment */
+/* whisper.audio.log_mel_spectrogram (data/data_loader.py:278; SURVEY.md App.
+ * A.2): reflect-pad 200, Hann-400 STFT hop 160, |.|^2, mel filterbank,
+ * log10(clamp 1e-10), floor at clip max - 8, (x+4)/4.
+ * audio f32 [B, n_samples] (n_samples = 160 * n_frames); filters f32
+ * [n_mels, 201]; out f32 [B, n_mels, n_frames]; clipmax f32 [B] workspace.   */
+int wft_logmel(const float* audio, const float* filters, float* out, float* clipmax,
+               int B, int n_samples, int n_mels, int n_frames, void* stream);
+/* SpecAugment on a batch of log-mels, all parameters already drawn on the
+ * host in the reference's order (data/data_loader.py:284-290,
+ * data/utils.py:41-143,146-190): per clip 8 ints
+ *   {apply_warp, warp_p, warp_d, t0, t1, f0, f1, unused} and 2 ints
+ *   {extreme_low_len, extreme_high_len}.
+ * in/out f32 [B, n_mels, T]; must not alias.                                  */
+int wft_specaug(const float* in, float* out, const int32_t* params, const int32_t* extremes,
+                int B, int n_mels, int T, void* stream);
+/* mel f32 [B, n_mels, T] -> time-major, channel-padded, row-padded bf16
+ * [B, T+2, c_pad] with zero rows 0 and T+1 (the conv1d k=3 p=1 halo) — the
+ * layout the conv-as-GEMM stem consumes (model/model_utils.py:276).          */
+int wft_mel_to_tmajor_bf16(const float* mel, wft_bf16* out, int B, int n_mels, int T,
+                           int c_pad, void* stream);
+/* d(mel) is never needed (inputs carry no grad). */
+
+/* ---------------------------------------------------------------- AdamW */
+/* torch.optim.AdamW single-tensor step over a flat f32 range
+ * (model/optimizer.py:240-262 → optimizer.step() in model_utils.py:122).
+ * g is multiplied by gscale[0] (device scalar: the clip_grad_norm_ coefficient,
+ * model_utils.py:107) before use.  If p_bf16 != NULL the bf16 shadow is
+ * refreshed in the same pass.                                                */
+int wft_adamw_step(float* p, const float* g, float* m, float* v, wft_bf16* p_bf16,
+                   int64_t n, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, float bias_corr1, float bias_corr2,
+                   const float* gscale, void* stream);
+/* out[0] += sum(g^2) over n elements (for the global grad norm).             */
+int wft_sumsq_f32(const float* g, int64_t n, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WFT_H */

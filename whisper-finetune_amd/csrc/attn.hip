@@ -1,0 +1,487 @@
+// attn.hip — fused attention for head_dim 64 (every Whisper size): forward with online
+// softmax, and a two-kernel recompute backward (dQ sweep over keys; dK/dV sweep over
+// queries) — no atomics, bitwise reproducible.
+//
+// MFMA plan (v_mfma_f32_32x32x16_bf16, one wave = 32 queries (fwd, dq) or 32 keys (dkdv)):
+//   fwd : S^T = K·Q^T (key rows from LDS, Q in registers; the query sits on the LANE, so
+//         the row max / row sum of softmax are in-lane reductions + one xor-32 shuffle),
+//         O^T += V^T·P^T with P^T taken straight from the S^T accumulators
+//         (cdna_hip_programming.md §3 "An accumulator tile as the next MFMA's operand")
+//         and V^T fragments read with ds_read_b64_tr_b16.
+//   dq  : same orientation; dP^T = V·dO^T, dS^T = P^T ⊙ (dP^T − δ), dQ^T += K^T·dS^T.
+//   dkdv: key on the lane: S = Q·K^T, dP = dO·V^T (K, V rows in registers, Q/dO tiles in
+//         LDS), dV^T += dO^T·P, dK^T += Q^T·dS.
+// LDS tiles are [64 rows][64 bf16] (128-byte rows) filled by global_load_lds_dwordx4 with
+// ONE source-side swizzle (chunk ^= F(row)) that is conflict-free for both the 32-row
+// ds_read_b128 operand reads and the 4-row transposed reads.
+#include "common.h"
+
+#define ATT_NEG (-1.0e30f)
+#define LOG2E 1.4426950408889634f
+
+struct AttnP {
+  const unsigned short* q; long ldq, q_bs;
+  const unsigned short* k; long ldk, k_bs;
+  const unsigned short* v; long ldv, v_bs;
+  unsigned short* o; long ldo, o_bs;
+  float* lse;
+  int B, H, Tq, Tk, causal;
+  float scale;
+  const unsigned short* d_o; long lddo, do_bs;
+  float* delta;
+  unsigned short* dq; long lddq, dq_bs;
+  unsigned short* dk; long lddk, dk_bs;
+  unsigned short* dv; long lddv, dv_bs;
+};
+
+__device__ __forceinline__ int att_F(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+
+// Stage one [64][64] bf16 tile (rows row0.. of a [nrows, ld] matrix, 64 columns at `base`).
+// 8 wave-instructions of 8 rows x 128 B; wave w issues instructions 2w, 2w+1.
+__device__ __forceinline__ void att_stage(const unsigned short* base, long ld, int row0, int nrows,
+                                          char* tile, int wave, int lane) {
+  const int rr = lane >> 3, cp = lane & 7;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int i = wave * 2 + j;
+    const int row = 8 * i + rr;
+    int gr = row0 + row;
+    gr = gr < nrows ? gr : nrows - 1;
+    const int c = cp ^ att_F(row);
+    glds16(base + (long)gr * ld + c * 8, tile + i * 1024);
+  }
+}
+
+// 32x32x16 A-operand row read: lane (r = lane&31, h = lane>>5) gets tile[blk*32 + r][16s + 8h .. +8]
+__device__ __forceinline__ bf16x8 att_row_frag(const char* tile, int blk, int s, int lane) {
+  const int row = blk * 32 + (lane & 31);
+  const int chunk = 2 * s + (lane >> 5);
+  return *(const bf16x8*)(tile + row * 128 + ((chunk ^ att_F(row)) << 4));
+}
+
+// 32x32x16 A-operand TRANSPOSED read for the "accumulator as B operand" k-order:
+// element j of lane (r, h) = tile[R0 + 8*(j>>2) + 4h + (j&3)][32*db + r], R0 = 16*ks.
+__device__ __forceinline__ bf16x8 att_tr_frag(const char* tile, int ks, int db, int lane) {
+  const int g = lane >> 4, i = lane & 15, h = g >> 1;
+  const int col = 32 * db + 16 * (g & 1) + 4 * (i & 3);
+  const int chunk = col >> 3;
+  const int inner = (col & 7) << 1;
+  s16x8 out;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int row = 16 * ks + 8 * t + 4 * h + (i >> 2);
+    const s16x4 x = lds_read_tr16(tile + row * 128 + ((chunk ^ att_F(row)) << 4) + inner);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) out[4 * t + e] = x[e];
+  }
+  return __builtin_bit_cast(bf16x8, out);
+}
+
+__device__ __forceinline__ bf16x8 att_pack8(const f32x16& a, int s) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (__bf16)a[8 * s + j];
+  return r;
+}
+
+__device__ __forceinline__ bf16x8 att_load_reg_frag(const unsigned short* rowptr, int s, int h) {
+  return *(const bf16x8*)(rowptr + 16 * s + 8 * h);
+}
+
+// ------------------------------------------------------------------------------ forward
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
+  __shared__ __attribute__((aligned(16))) char smem[32768];  // [buf 2][K 8K | V 8K]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int q0 = blockIdx.x * 128, hd = blockIdx.y, b = blockIdx.z;
+  const int qw0 = q0 + wave * 32;
+  const int qi = qw0 + r;
+  const int qc = qi < p.Tq ? qi : p.Tq - 1;
+  const unsigned short* qrow = p.q + (long)b * p.q_bs + (long)qc * p.ldq + hd * 64;
+  const unsigned short* kb = p.k + (long)b * p.k_bs + hd * 64;
+  const unsigned short* vb = p.v + (long)b * p.v_bs + hd * 64;
+  bf16x8 qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) qf[s] = att_load_reg_frag(qrow, s, h);
+
+  int nkt = (p.Tk + 63) >> 6;
+  if (p.causal) {
+    const int last = (q0 + 127) / 64 + 1;
+    nkt = nkt < last ? nkt : last;
+  }
+  const float c = p.scale * LOG2E;
+  f32x16 oacc[2];
+  oacc[0] = f32x16{0};
+  oacc[1] = f32x16{0};
+  float m = ATT_NEG, l = 0.f;
+
+  att_stage(kb, p.ldk, 0, p.Tk, smem, wave, lane);
+  att_stage(vb, p.ldv, 0, p.Tk, smem + 8192, wave, lane);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    const int key0 = kt * 64;
+    if (kt + 1 < nkt) {
+      att_stage(kb, p.ldk, key0 + 64, p.Tk, smem + (cur ^ 1) * 16384, wave, lane);
+      att_stage(vb, p.ldv, key0 + 64, p.Tk, smem + (cur ^ 1) * 16384 + 8192, wave, lane);
+    }
+    const char* kt_l = smem + cur * 16384;
+    const char* vt_l = kt_l + 8192;
+    const bool active = !(p.causal && key0 > qw0 + 31);
+    if (active) {
+      f32x16 sacc[2];
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; ++kb2) {
+        sacc[kb2] = f32x16{0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          sacc[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_row_frag(kt_l, kb2, s, lane), qf[s],
+                                                              sacc[kb2], 0, 0, 0);
+      }
+      // mask + tile max
+      float tmax = ATT_NEG;
+      const bool need_mask = (key0 + 64 > p.Tk) || (p.causal && key0 + 63 > qw0);
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          if (need_mask) {
+            const int key = key0 + 32 * kb2 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (key >= p.Tk || (p.causal && key > qi)) sacc[kb2][e] = ATT_NEG;
+          }
+          tmax = fmaxf(tmax, sacc[kb2][e]);
+        }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float mnew = fmaxf(m, tmax);
+      const float alpha = exp2f((m - mnew) * c);
+      const float mc = mnew * c;
+      float ls = 0.f;
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float pv = exp2f(sacc[kb2][e] * c - mc);
+          sacc[kb2][e] = pv;
+          ls += pv;
+        }
+      ls += __shfl_xor(ls, 32, 64);
+      l = l * alpha + ls;
+      m = mnew;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[db][e] *= alpha;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 pf = att_pack8(sacc[ks >> 1], ks & 1);
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_tr_frag(vt_l, ks, db, lane), pf, oacc[db],
+                                                             0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  if (qi < p.Tq) {
+    const float inv = 1.0f / l;
+    unsigned short* orow = p.o + (long)b * p.o_bs + (long)qi * p.ldo + hd * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int d = 32 * db + 8 * a + 4 * h;
+        u32x2 pk = {pack2bf(oacc[db][4 * a] * inv, oacc[db][4 * a + 1] * inv),
+                    pack2bf(oacc[db][4 * a + 2] * inv, oacc[db][4 * a + 3] * inv)};
+        *(u32x2*)(orow + d) = pk;
+      }
+    if (h == 0 && p.lse) p.lse[((long)b * p.H + hd) * p.Tq + qi] = m * p.scale + __logf(l);
+  }
+}
+
+// ------------------------------------------------------------------------------ delta
+// delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d]
+__global__ __launch_bounds__(256) void attn_delta_kernel(AttnP p) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)p.B * p.Tq * p.H;
+  if (idx >= total) return;
+  const int hd = (int)(idx % p.H);
+  const long bq = idx / p.H;
+  const int qi = (int)(bq % p.Tq);
+  const int b = (int)(bq / p.Tq);
+  const unsigned short* orow = p.o + (long)b * p.o_bs + (long)qi * p.ldo + hd * 64;
+  const unsigned short* drow = p.d_o + (long)b * p.do_bs + (long)qi * p.lddo + hd * 64;
+  float s = 0.f;
+#pragma unroll
+  for (int cidx = 0; cidx < 8; ++cidx) {
+    const u32x4 a = *(const u32x4*)(orow + cidx * 8);
+    const u32x4 d = *(const u32x4*)(drow + cidx * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      s += bf2f((unsigned short)(a[e] & 0xffff)) * bf2f((unsigned short)(d[e] & 0xffff));
+      s += bf2f((unsigned short)(a[e] >> 16)) * bf2f((unsigned short)(d[e] >> 16));
+    }
+  }
+  p.delta[((long)b * p.H + hd) * p.Tq + qi] = s;
+}
+
+// ------------------------------------------------------------------------------ dQ
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
+  __shared__ __attribute__((aligned(16))) char smem[32768];  // [buf 2][K 8K | V 8K]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int q0 = blockIdx.x * 128, hd = blockIdx.y, b = blockIdx.z;
+  const int qw0 = q0 + wave * 32;
+  const int qi = qw0 + r;
+  const int qc = qi < p.Tq ? qi : p.Tq - 1;
+  const unsigned short* qrow = p.q + (long)b * p.q_bs + (long)qc * p.ldq + hd * 64;
+  const unsigned short* dorow = p.d_o + (long)b * p.do_bs + (long)qc * p.lddo + hd * 64;
+  const unsigned short* kb = p.k + (long)b * p.k_bs + hd * 64;
+  const unsigned short* vb = p.v + (long)b * p.v_bs + hd * 64;
+  bf16x8 qf[4], dof[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    qf[s] = att_load_reg_frag(qrow, s, h);
+    dof[s] = att_load_reg_frag(dorow, s, h);
+  }
+  const long sidx = ((long)b * p.H + hd) * p.Tq + qc;
+  const float lse2 = p.lse[sidx] * LOG2E;
+  const float dlt = p.delta[sidx];
+
+  int nkt = (p.Tk + 63) >> 6;
+  if (p.causal) {
+    const int last = (q0 + 127) / 64 + 1;
+    nkt = nkt < last ? nkt : last;
+  }
+  const float c = p.scale * LOG2E;
+  f32x16 dqacc[2];
+  dqacc[0] = f32x16{0};
+  dqacc[1] = f32x16{0};
+
+  att_stage(kb, p.ldk, 0, p.Tk, smem, wave, lane);
+  att_stage(vb, p.ldv, 0, p.Tk, smem + 8192, wave, lane);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    const int key0 = kt * 64;
+    if (kt + 1 < nkt) {
+      att_stage(kb, p.ldk, key0 + 64, p.Tk, smem + (cur ^ 1) * 16384, wave, lane);
+      att_stage(vb, p.ldv, key0 + 64, p.Tk, smem + (cur ^ 1) * 16384 + 8192, wave, lane);
+    }
+    const char* kt_l = smem + cur * 16384;
+    const char* vt_l = kt_l + 8192;
+    const bool active = !(p.causal && key0 > qw0 + 31);
+    if (active) {
+      f32x16 sacc[2], pacc[2];
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; ++kb2) {
+        sacc[kb2] = f32x16{0};
+        pacc[kb2] = f32x16{0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          sacc[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_row_frag(kt_l, kb2, s, lane), qf[s],
+                                                              sacc[kb2], 0, 0, 0);
+          pacc[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_row_frag(vt_l, kb2, s, lane), dof[s],
+                                                              pacc[kb2], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = key0 + 32 * kb2 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const bool ok = key < p.Tk && !(p.causal && key > qi);
+          const float pv = ok ? exp2f(sacc[kb2][e] * c - lse2) : 0.f;
+          sacc[kb2][e] = pv * (pacc[kb2][e] - dlt);  // dS^T (unscaled)
+        }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 dsf = att_pack8(sacc[ks >> 1], ks & 1);
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+          dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_tr_frag(kt_l, ks, db, lane), dsf,
+                                                              dqacc[db], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  if (qi < p.Tq) {
+    unsigned short* drow = p.dq + (long)b * p.dq_bs + (long)qi * p.lddq + hd * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int d = 32 * db + 8 * a + 4 * h;
+        u32x2 pk = {pack2bf(dqacc[db][4 * a] * p.scale, dqacc[db][4 * a + 1] * p.scale),
+                    pack2bf(dqacc[db][4 * a + 2] * p.scale, dqacc[db][4 * a + 3] * p.scale)};
+        *(u32x2*)(drow + d) = pk;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------ dK, dV
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
+  // [buf 2][Q 8K | dO 8K | lse 256 B | delta 256 B]
+  __shared__ __attribute__((aligned(16))) char smem[2 * (16384 + 512)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int k0 = blockIdx.x * 128, hd = blockIdx.y, b = blockIdx.z;
+  const int kw0 = k0 + wave * 32;
+  const int ki = kw0 + r;
+  const int kc = ki < p.Tk ? ki : p.Tk - 1;
+  const unsigned short* krow = p.k + (long)b * p.k_bs + (long)kc * p.ldk + hd * 64;
+  const unsigned short* vrow = p.v + (long)b * p.v_bs + (long)kc * p.ldv + hd * 64;
+  const unsigned short* qb = p.q + (long)b * p.q_bs + hd * 64;
+  const unsigned short* dob = p.d_o + (long)b * p.do_bs + hd * 64;
+  const float* lse_b = p.lse + ((long)b * p.H + hd) * p.Tq;
+  const float* dlt_b = p.delta + ((long)b * p.H + hd) * p.Tq;
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    kf[s] = att_load_reg_frag(krow, s, h);
+    vf[s] = att_load_reg_frag(vrow, s, h);
+  }
+  const float c = p.scale * LOG2E;
+  const int nqt = (p.Tq + 63) >> 6;
+  const int qt0 = p.causal ? (k0 >> 6) : 0;  // first query tile that can see key k0
+  f32x16 dkacc[2], dvacc[2];
+  dkacc[0] = f32x16{0}; dkacc[1] = f32x16{0};
+  dvacc[0] = f32x16{0}; dvacc[1] = f32x16{0};
+
+  auto stage_q = [&](int buf, int qt) {
+    char* base = smem + buf * (16384 + 512);
+    att_stage(qb, p.ldq, qt * 64, p.Tq, base, wave, lane);
+    att_stage(dob, p.lddo, qt * 64, p.Tq, base + 8192, wave, lane);
+    if (tid < 64) {
+      const int qq = qt * 64 + tid;
+      ((float*)(base + 16384))[tid] = qq < p.Tq ? lse_b[qq] * LOG2E : 0.f;
+    } else if (tid < 128) {
+      const int qq = qt * 64 + tid - 64;
+      ((float*)(base + 16384 + 256))[tid - 64] = qq < p.Tq ? dlt_b[qq] : 0.f;
+    }
+  };
+
+  if (qt0 < nqt) {
+    stage_q(0, qt0);
+    __syncthreads();
+  }
+  for (int qt = qt0; qt < nqt; ++qt) {
+    const int cur = (qt - qt0) & 1;
+    const int qq0 = qt * 64;
+    if (qt + 1 < nqt) stage_q(cur ^ 1, qt + 1);
+    const char* q_l = smem + cur * (16384 + 512);
+    const char* do_l = q_l + 8192;
+    const float* lse_l = (const float*)(q_l + 16384);
+    const float* dlt_l = lse_l + 64;
+    const bool active = !(p.causal && kw0 > qq0 + 63);
+    if (active) {
+#pragma unroll
+      for (int qb2 = 0; qb2 < 2; ++qb2) {
+        f32x16 sacc = f32x16{0}, pacc = f32x16{0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_row_frag(q_l, qb2, s, lane), kf[s], sacc, 0, 0, 0);
+          pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_row_frag(do_l, qb2, s, lane), vf[s], pacc, 0, 0, 0);
+        }
+        f32x16 dsacc;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int qoff = 32 * qb2 + 8 * a + 4 * h;
+          const f32x4 l4 = *(const f32x4*)(lse_l + qoff);
+          const f32x4 d4 = *(const f32x4*)(dlt_l + qoff);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int qg = qq0 + qoff + e;
+            const bool ok = qg < p.Tq && ki < p.Tk && !(p.causal && ki > qg);
+            const float pv = ok ? exp2f(sacc[4 * a + e] * c - l4[e]) : 0.f;
+            sacc[4 * a + e] = pv;
+            dsacc[4 * a + e] = pv * (pacc[4 * a + e] - d4[e]);
+          }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const bf16x8 pf = att_pack8(sacc, ks);
+          const bf16x8 dsf = att_pack8(dsacc, ks);
+#pragma unroll
+          for (int db = 0; db < 2; ++db) {
+            dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_tr_frag(do_l, 2 * qb2 + ks, db, lane), pf,
+                                                                dvacc[db], 0, 0, 0);
+            dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_tr_frag(q_l, 2 * qb2 + ks, db, lane), dsf,
+                                                                dkacc[db], 0, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (ki < p.Tk) {
+    unsigned short* dkrow = p.dk + (long)b * p.dk_bs + (long)ki * p.lddk + hd * 64;
+    unsigned short* dvrow = p.dv + (long)b * p.dv_bs + (long)ki * p.lddv + hd * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int d = 32 * db + 8 * a + 4 * h;
+        u32x2 pk = {pack2bf(dkacc[db][4 * a] * p.scale, dkacc[db][4 * a + 1] * p.scale),
+                    pack2bf(dkacc[db][4 * a + 2] * p.scale, dkacc[db][4 * a + 3] * p.scale)};
+        *(u32x2*)(dkrow + d) = pk;
+        u32x2 pv = {pack2bf(dvacc[db][4 * a], dvacc[db][4 * a + 1]),
+                    pack2bf(dvacc[db][4 * a + 2], dvacc[db][4 * a + 3])};
+        *(u32x2*)(dvrow + d) = pv;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------ host
+static int attn_fill(const wft_attn_args* a, AttnP& p) {
+  p.q = a->q; p.ldq = a->ldq; p.q_bs = a->q_bs;
+  p.k = a->k; p.ldk = a->ldk; p.k_bs = a->k_bs;
+  p.v = a->v; p.ldv = a->ldv; p.v_bs = a->v_bs;
+  p.o = a->o; p.ldo = a->ldo; p.o_bs = a->o_bs;
+  p.lse = a->lse;
+  p.B = a->B; p.H = a->H; p.Tq = a->Tq; p.Tk = a->Tk; p.causal = a->causal;
+  p.scale = a->scale;
+  p.d_o = a->d_o; p.lddo = a->lddo; p.do_bs = a->do_bs;
+  p.delta = a->delta;
+  p.dq = a->dq; p.lddq = a->lddq; p.dq_bs = a->dq_bs;
+  p.dk = a->dk; p.lddk = a->lddk; p.dk_bs = a->dk_bs;
+  p.dv = a->dv; p.lddv = a->lddv; p.dv_bs = a->dv_bs;
+  return 0;
+}
+
+#define ATT_ALIGNED(ptr, ld, bs) ((((uintptr_t)(ptr)) & 15) == 0 && ((ld) % 8) == 0 && ((bs) % 8) == 0)
+
+extern "C" int wft_attn_fwd_bf16(const wft_attn_args* a, void* stream) {
+  WFT_CHECK_ARG(a && a->q && a->k && a->v && a->o && a->lse, "null pointer");
+  WFT_CHECK_ARG(a->B >= 1 && a->H >= 1 && a->Tq >= 1 && a->Tk >= 1, "bad shape");
+  WFT_CHECK_ARG(ATT_ALIGNED(a->q, a->ldq, a->q_bs) && ATT_ALIGNED(a->k, a->ldk, a->k_bs) &&
+                    ATT_ALIGNED(a->v, a->ldv, a->v_bs) && ATT_ALIGNED(a->o, a->ldo, a->o_bs),
+                "q/k/v/o need 16-byte aligned bases and strides that are multiples of 8");
+  WFT_CHECK_ARG(!a->causal || a->Tq == a->Tk, "causal attention needs Tq == Tk");
+  AttnP p;
+  attn_fill(a, p);
+  dim3 grid((a->Tq + 127) / 128, a->H, a->B), block(256);
+  hipLaunchKernelGGL(attn_fwd_kernel, grid, block, 0, (hipStream_t)stream, p);
+  WFT_CHECK_LAUNCH();
+  return WFT_OK;
+}
+
+extern "C" int wft_attn_bwd_bf16(const wft_attn_args* a, void* stream) {
+  WFT_CHECK_ARG(a && a->q && a->k && a->v && a->o && a->lse && a->d_o && a->delta && a->dq && a->dk && a->dv,
+                "null pointer");
+  WFT_CHECK_ARG(a->B >= 1 && a->H >= 1 && a->Tq >= 1 && a->Tk >= 1, "bad shape");
+  WFT_CHECK_ARG(ATT_ALIGNED(a->q, a->ldq, a->q_bs) && ATT_ALIGNED(a->k, a->ldk, a->k_bs) &&
+                    ATT_ALIGNED(a->v, a->ldv, a->v_bs) && ATT_ALIGNED(a->o, a->ldo, a->o_bs) &&
+                    ATT_ALIGNED(a->d_o, a->lddo, a->do_bs) && ATT_ALIGNED(a->dq, a->lddq, a->dq_bs) &&
+                    ATT_ALIGNED(a->dk, a->lddk, a->dk_bs) && ATT_ALIGNED(a->dv, a->lddv, a->dv_bs),
+                "tensors need 16-byte aligned bases and strides that are multiples of 8");
+  WFT_CHECK_ARG(!a->causal || a->Tq == a->Tk, "causal attention needs Tq == Tk");
+  AttnP p;
+  attn_fill(a, p);
+  hipStream_t s = (hipStream_t)stream;
+  const long total = (long)a->B * a->Tq * a->H;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((a->Tq + 127) / 128, a->H, a->B), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3((a->Tk + 127) / 128, a->H, a->B), dim3(256), 0, s, p);
+  WFT_CHECK_LAUNCH();
+  return WFT_OK;
+}

@@ -1,0 +1,354 @@
+// gemm.hip — bf16 MFMA GEMMs for the Linear / Conv1d-as-GEMM / logits paths.
+//
+//   wft_gemm_nt_bf16 : C[M,N] = A[M,K] · B[N,K]^T   (forward, backward-data with a
+//                      transposed weight shadow)
+//   wft_gemm_tn_bf16 : C[P,Q] = A[R,P]^T · B[R,Q]   (weight gradients)
+//
+// Both: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave,
+// 4x4 tiles of v_mfma_f32_16x16x32_bf16), K-step 64, double-buffered LDS filled by
+// global_load_lds_dwordx4 (LDS image is lane-linear, so the bank swizzle is applied to
+// the per-lane SOURCE address and again on the read — cdna_hip_programming.md rule 21),
+// XCD-aware bijective tile remap so that tiles sharing an A row-panel sit on one L2.
+// MFMA operands are swapped (D^T = B·A^T) so that each lane ends up with 4 consecutive
+// output columns of one row: 8-byte bf16 / 16-byte f32 stores.
+#include "common.h"
+
+struct GemmP {
+  const unsigned short* A; long lda; long sA;
+  const unsigned short* B; long ldb; long sB;
+  void* C; long ldc; long sC;
+  const float* bias;
+  const unsigned short* res; long ldr; long sR;
+  unsigned short* aux; long ldaux; long sAux;
+  float alpha;
+  int M, N, K, batch;
+  int accumulate;
+  int period, valid;
+};
+
+__device__ __forceinline__ int xcd_remap(int bid, int ntile) {
+  const int q = ntile >> 3, r = ntile & 7, xcd = bid & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// ---------------------------------------------------------------------------------- NT
+template <int EPI, bool C_F32>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
+  __shared__ __attribute__((aligned(16))) char smem[65536];  // [buf 2][A 16K | B 16K]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = p.N >> 7;
+  const int tiles_m = (p.M + 127) >> 7;
+  const int sid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int tm = sid / tiles_n, tn = sid - tm * tiles_n;
+  const int m0 = tm << 7, n0 = tn << 7;
+  const int bz = blockIdx.z;
+  const unsigned short* Ab = p.A + (long)bz * p.sA;
+  const unsigned short* Bb = p.B + (long)bz * p.sB;
+
+  // per-lane source pointers for the 4+4 staging instructions this wave issues per K-tile
+  const int lr = lane >> 3, lc = lane & 7;
+  const unsigned short* asrc[4];
+  const unsigned short* bsrc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (wave * 4 + j) * 8 + lr;
+    int gm = m0 + row;
+    gm = gm < p.M ? gm : p.M - 1;
+    asrc[j] = Ab + (long)gm * p.lda + ((lc ^ lr) << 3);
+    bsrc[j] = Bb + (long)(n0 + row) * p.ldb + ((lc ^ lr) << 3);
+  }
+  auto stage = [&](int buf, int kt) {
+    char* sa = smem + buf * 32768 + wave * 4096;
+    char* sb = sa + 16384;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      glds16(asrc[j] + kt * 64, sa + j * 1024);
+      glds16(bsrc[j] + kt * 64, sb + j * 1024);
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K >> 6;
+  stage(0, 0);
+  __syncthreads();
+  const int frow = lane & 15, fg = lane >> 4, sw = lane & 7;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const char* sa = smem + cur * 32768 + (wm * 64 + frow) * 128;
+    const char* sb = smem + cur * 32768 + 16384 + (wn * 64 + frow) * 128;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int coff = ((s * 4 + fg) ^ sw) << 4;
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(sa + i * 2048 + coff);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(sb + j * 2048 + coff);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds C[m][n..n+3] per (i,j)
+  const long cb = (long)bz * p.sC;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + frow;
+    if (m >= p.M) continue;
+    const bool zero_row = p.period > 0 && (m % p.period) >= p.valid;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + fg * 4;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * p.alpha;
+      if (p.bias) {
+        const f32x4 b4 = *(const f32x4*)(p.bias + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += b4[e];
+      }
+      if (EPI == WFT_EPI_GELU) {
+        if (p.aux) {
+          u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+          *(u32x2*)(p.aux + (long)bz * p.sAux + (long)m * p.ldaux + n) = pk;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+      } else if (EPI == WFT_EPI_DGELU) {
+        const u32x2 a2 = *(const u32x2*)(p.aux + (long)bz * p.sAux + (long)m * p.ldaux + n);
+        v[0] *= dgelu_f(bf2f((unsigned short)(a2[0] & 0xffff)));
+        v[1] *= dgelu_f(bf2f((unsigned short)(a2[0] >> 16)));
+        v[2] *= dgelu_f(bf2f((unsigned short)(a2[1] & 0xffff)));
+        v[3] *= dgelu_f(bf2f((unsigned short)(a2[1] >> 16)));
+      }
+      if (p.res) {
+        const u32x2 r2 = *(const u32x2*)(p.res + (long)bz * p.sR + (long)m * p.ldr + n);
+        v[0] += bf2f((unsigned short)(r2[0] & 0xffff));
+        v[1] += bf2f((unsigned short)(r2[0] >> 16));
+        v[2] += bf2f((unsigned short)(r2[1] & 0xffff));
+        v[3] += bf2f((unsigned short)(r2[1] >> 16));
+      }
+      if (zero_row) { v[0] = v[1] = v[2] = v[3] = 0.f; }
+      if (C_F32) {
+        float* cp = (float*)p.C + cb + (long)m * p.ldc + n;
+        f32x4 o = {v[0], v[1], v[2], v[3]};
+        if (p.accumulate) {
+          const f32x4 old = *(const f32x4*)cp;
+          o += old;
+        }
+        *(f32x4*)cp = o;
+      } else {
+        unsigned short* cp = (unsigned short*)p.C + cb + (long)m * p.ldc + n;
+        u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+        *(u32x2*)cp = pk;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------- TN
+// C[p][q] = sum_r A[r][p] * B[r][q].  LDS tiles are [64 r][128 cols] (256-byte rows);
+// MFMA operands are column reads of those tiles -> ds_read_b64_tr_b16.
+__device__ __forceinline__ int tn_f(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
+
+template <bool C_F32>
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmP p) {
+  __shared__ __attribute__((aligned(16))) char smem[65536];  // [buf 2][A 16K | B 16K]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wq = wave >> 1, wp = wave & 1;
+  const int P = p.M, Q = p.N, R = p.K;
+  const int tiles_q = Q >> 7;
+  const int tiles_p = P >> 7;
+  const int sid = xcd_remap(blockIdx.x, tiles_p * tiles_q);
+  const int tp = sid / tiles_q, tq = sid - tp * tiles_q;
+  const int p0 = tp << 7, q0 = tq << 7;
+
+  const int tpb = (R + 63) >> 6;  // reduction tiles per batch item
+  const int nsteps = tpb * p.batch;
+
+  // staging: instruction i (0..15) covers r rows 4i..4i+3; lane -> (rr = lane>>4, c' = lane&15)
+  const int rr = lane >> 4, cp = lane & 15;
+  auto stage = [&](int buf, int step) {
+    const int b = step / tpb, t = step - b * tpb;
+    const unsigned short* Ab = p.A + (long)b * p.sA;
+    const unsigned short* Bb = p.B + (long)b * p.sB;
+    char* sa = smem + buf * 32768 + wave * 4096;
+    char* sb = sa + 16384;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = wave * 4 + j;
+      const int r = i * 4 + rr;
+      int gr = t * 64 + r;
+      gr = gr < R ? gr : R - 1;
+      const int c = cp ^ (tn_f(r) << 1);
+      glds16(Ab + (long)gr * p.lda + p0 + (c << 3), sa + j * 1024);
+      glds16(Bb + (long)gr * p.ldb + q0 + (c << 3), sb + j * 1024);
+    }
+  };
+  auto zero_tail = [&](int buf, int step) {
+    const int t = step % tpb;
+    const int rem = R - t * 64;  // valid rows in this tile
+    if (rem >= 64) return false;
+    // rows [rem, 64) of both tiles -> 0 ; 16 chunks of 16 B per row per operand
+    char* base = smem + buf * 32768;
+    const int nchunk = (64 - rem) * 16;
+    for (int c = tid; c < nchunk; c += 256) {
+      const int off = (rem * 16 + c) * 16;
+      *(u32x4*)(base + off) = u32x4{0, 0, 0, 0};
+      *(u32x4*)(base + 16384 + off) = u32x4{0, 0, 0, 0};
+    }
+    return true;
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  stage(0, 0);
+  __syncthreads();
+  if (zero_tail(0, 0)) __syncthreads();
+
+  const int g = lane >> 4, li = lane & 15;
+  const int r_in = (li >> 2);               // row within the 4-row block
+  const int fsw = (r_in | ((g & 1) << 2)) << 1;  // tn_f(r) << 1 for r = 32s + 8g + 4t + r_in
+  const int colq = wq * 64 + 4 * (li & 3);  // + iq*16
+  const int colp = wp * 64 + 4 * (li & 3);  // + jp*16
+  for (int step = 0; step < nsteps; ++step) {
+    const int cur = step & 1;
+    if (step + 1 < nsteps) stage(cur ^ 1, step + 1);
+    const char* sa = smem + cur * 32768;
+    const char* sb = sa + 16384;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      s16x8 qf[4], pf[4];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int r = 32 * s + 8 * g + 4 * t + r_in;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int cq = colq + i * 16;
+          const int aq = r * 256 + (((cq >> 3) ^ fsw) << 4) + ((cq & 7) << 1);
+          const s16x4 x = lds_read_tr16(sb + aq);
+          const int cpp = colp + i * 16;
+          const int ap = r * 256 + (((cpp >> 3) ^ fsw) << 4) + ((cpp & 7) << 1);
+          const s16x4 y = lds_read_tr16(sa + ap);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            qf[i][4 * t + e] = x[e];
+            pf[i][4 * t + e] = y[e];
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              __builtin_bit_cast(bf16x8, qf[i]), __builtin_bit_cast(bf16x8, pf[j]), acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    if (step + 1 < nsteps) {
+      if (zero_tail(cur ^ 1, step + 1)) __syncthreads();
+    }
+  }
+
+  // epilogue: D[q][p]: col (lane&15) = p index, rows 4*(lane>>4)+e = q index
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int pp = p0 + wp * 64 + j * 16 + li;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int qq = q0 + wq * 64 + i * 16 + g * 4;
+      f32x4 o = acc[i][j] * p.alpha;
+      if (C_F32) {
+        float* cptr = (float*)p.C + (long)pp * p.ldc + qq;
+        if (p.accumulate) o += *(const f32x4*)cptr;
+        *(f32x4*)cptr = o;
+      } else {
+        unsigned short* cptr = (unsigned short*)p.C + (long)pp * p.ldc + qq;
+        u32x2 pk = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+        *(u32x2*)cptr = pk;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------- host
+static int fill_params(const wft_gemm_args* a, GemmP& p) {
+  p.A = a->A; p.lda = a->lda; p.sA = a->strideA;
+  p.B = a->B; p.ldb = a->ldb; p.sB = a->strideB;
+  p.C = a->C; p.ldc = a->ldc; p.sC = a->strideC;
+  p.bias = a->bias;
+  p.res = a->residual; p.ldr = a->ldr; p.sR = a->strideR;
+  p.aux = a->aux; p.ldaux = a->ldaux; p.sAux = a->strideAux;
+  p.alpha = a->alpha;
+  p.M = (int)a->M; p.N = (int)a->N; p.K = (int)a->K; p.batch = a->batch;
+  p.accumulate = a->accumulate;
+  p.period = a->valid_rows_period; p.valid = a->valid_rows;
+  return 0;
+}
+
+extern "C" int wft_gemm_nt_bf16(const wft_gemm_args* a, void* stream) {
+  WFT_CHECK_ARG(a && a->A && a->B && a->C, "null pointer");
+  WFT_CHECK_ARG(a->M >= 1 && a->N >= 128 && a->K >= 64 && a->batch >= 1, "bad shape");
+  WFT_CHECK_ARG(a->N % 128 == 0, "N must be a multiple of 128");
+  WFT_CHECK_ARG(a->K % 64 == 0, "K must be a multiple of 64");
+  WFT_CHECK_ARG(a->lda % 8 == 0 && a->ldb % 8 == 0 && a->ldc % 4 == 0, "ld alignment");
+  WFT_CHECK_ARG(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->B & 15) == 0 && ((uintptr_t)a->C & 15) == 0,
+                "base pointers must be 16-byte aligned");
+  WFT_CHECK_ARG(!(a->accumulate && !a->c_is_f32), "accumulate needs an f32 C");
+  WFT_CHECK_ARG(a->epilogue != WFT_EPI_DGELU || a->aux, "DGELU epilogue needs aux");
+  WFT_CHECK_ARG(a->M < (1ll << 31) && a->N < (1ll << 31) && a->K < (1ll << 31), "dims exceed int32");
+  GemmP p;
+  fill_params(a, p);
+  const long tiles = ((a->M + 127) / 128) * (a->N / 128);
+  dim3 grid((unsigned)tiles, 1, (unsigned)a->batch), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH_NT(E)                                                               \
+  do {                                                                             \
+    if (a->c_is_f32) hipLaunchKernelGGL((gemm_nt_kernel<E, true>), grid, block, 0, s, p);  \
+    else hipLaunchKernelGGL((gemm_nt_kernel<E, false>), grid, block, 0, s, p);     \
+  } while (0)
+  switch (a->epilogue) {
+    case WFT_EPI_NONE: LAUNCH_NT(WFT_EPI_NONE); break;
+    case WFT_EPI_GELU: LAUNCH_NT(WFT_EPI_GELU); break;
+    case WFT_EPI_DGELU: LAUNCH_NT(WFT_EPI_DGELU); break;
+    default: wft_set_error("wft_gemm_nt_bf16: unknown epilogue %d", a->epilogue); return WFT_ERR_ARG;
+  }
+#undef LAUNCH_NT
+  WFT_CHECK_LAUNCH();
+  return WFT_OK;
+}
+
+extern "C" int wft_gemm_tn_bf16(const wft_gemm_args* a, void* stream) {
+  WFT_CHECK_ARG(a && a->A && a->B && a->C, "null pointer");
+  WFT_CHECK_ARG(a->M >= 128 && a->N >= 128 && a->K >= 1 && a->batch >= 1, "bad shape");
+  WFT_CHECK_ARG(a->M % 128 == 0 && a->N % 128 == 0, "P and Q must be multiples of 128");
+  WFT_CHECK_ARG(a->lda % 8 == 0 && a->ldb % 8 == 0 && a->ldc % 4 == 0, "ld alignment");
+  WFT_CHECK_ARG(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->B & 15) == 0 && ((uintptr_t)a->C & 15) == 0,
+                "base pointers must be 16-byte aligned");
+  WFT_CHECK_ARG(!(a->accumulate && !a->c_is_f32), "accumulate needs an f32 C");
+  WFT_CHECK_ARG(a->M < (1ll << 31) && a->N < (1ll << 31) && a->K < (1ll << 31), "dims exceed int32");
+  GemmP p;
+  fill_params(a, p);
+  const long tiles = (a->M / 128) * (a->N / 128);
+  dim3 grid((unsigned)tiles), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (a->c_is_f32) hipLaunchKernelGGL((gemm_tn_kernel<true>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((gemm_tn_kernel<false>), grid, block, 0, s, p);
+  WFT_CHECK_LAUNCH();
+  return WFT_OK;
+}

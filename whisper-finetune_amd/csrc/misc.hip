@@ -1,0 +1,457 @@
+// misc.hip — HBM-bound side kernels of the training step: casts / padded transposed weight
+// shadows, residual-gradient add, bias-gradient column sums, token embedding fwd/bwd,
+// label-smoothed cross entropy fwd/bwd (+ teacher-forced argmax), AdamW, sum of squares.
+// All use 16-byte per-lane accesses where the layout allows (cdna_hip_programming.md G13).
+#include "common.h"
+#include <stdarg.h>
+
+static thread_local char g_err[512] = "";
+void wft_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* wft_last_error(void) { return g_err; }
+extern "C" const char* wft_version(void) { return "wft 0.1 gfx950"; }
+
+static inline int ew_grid(int64_t nvec) {
+  int64_t g = (nvec + 255) / 256;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ----------------------------------------------------------------------------- casts
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* src, unsigned short* dst, long n) {
+  const long nv = n >> 3;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+    const f32x4 a = *(const f32x4*)(src + i * 8), b = *(const f32x4*)(src + i * 8 + 4);
+    u32x4 o = {pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3])};
+    *(u32x4*)(dst + i * 8) = o;
+  }
+  if (blockIdx.x == 0) {
+    const long t = (nv << 3) + threadIdx.x;
+    if (t < n) dst[t] = f2bf(src[t]);
+  }
+}
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const unsigned short* src, float* dst, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = bf2f(src[i]);
+}
+
+extern "C" int wft_cast_f32_bf16(const float* src, wft_bf16* dst, int64_t n, void* stream) {
+  WFT_CHECK_ARG(src && dst && n >= 0, "bad args");
+  WFT_CHECK_ARG((((uintptr_t)src) & 15) == 0 && (((uintptr_t)dst) & 15) == 0, "16-byte alignment");
+  if (n == 0) return WFT_OK;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(ew_grid(n / 8 + 1)), dim3(256), 0, (hipStream_t)stream, src, dst, (long)n);
+  WFT_CHECK_LAUNCH();
+  return WFT_OK;
+}
+extern "C" int wft_cast_bf16_f32(const wft_bf16* src, float* dst, int64_t n, void* stream) {
+  WFT_CHECK_ARG(src && dst && n >= 0, "bad args");
+  if (n == 0) return WFT_OK;
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, src, dst, (long)n);
+  WFT_CHECK_LAUNCH();
+  return WFT_OK;
+}
+
+// src f32 [rows, cols] -> dst bf16 [rows_pad, cols_pad], dst_t bf16 [cols_pad, rows_pad]; 64x64 tiles via LDS
+__global__ __launch_bounds__(256) void cast_pad_t_kernel(const float* src, long rows, long cols, unsigned short* dst,
+                                                          unsigned short* dst_t, long rows_pad, long cols_pad) {
+  __shared__ unsigned short tile[64][66];
+  const long r0 = (long)blockIdx.y * 64, c0 = (long)blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int rr = ty; rr < 64; rr += 4) {
+    const long r = r0 + rr, c = c0 + tx;
+    unsigned short v = 0;
+    if (r < rows && c < cols) v = f2bf(src[r * cols + c]);
+    tile[rr][tx] = v;
+    if (r < rows_pad && c < cols_pad) dst[r * cols_pad + c] = v;
+  }
+  if (dst_t) {
+    __syncthreads();
+    for (int cc = ty; cc < 64; cc += 4) {
+      const long c = c0 + cc, r = r0 + tx;
+      if (c < cols_pad && r < rows_pad) dst_t[c * rows_pad + r] = tile[tx][cc];
+    }
+  }
+}
+extern "C" int wft_cast_pad_transpose_f32_bf16(const float* src, int64_t rows, int64_t cols, wft_bf16* dst,
+                                               wft_bf16* dst_t, int64_t rows_pad, int64_t cols_pad, void* stream) {
+  WFT_CHECK_ARG(src && dst, "null pointer");
+  WFT_CHECK_ARG(rows >= 1 && cols >= 1 && rows_pad >= rows && cols_pad >= cols, "bad shape");
+  dim3 grid((unsigned)((cols_pad + 63) / 64), (unsigned)((rows_pad + 63) / 64));
+  hipLaunchKernelGGL(cast_pad_t_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, (long)rows, (long)cols, dst, dst_t,
+                     (long)rows_pad, (long)cols_pad);
+  WFT_CHECK_LAUNCH();
+  return WFT_OK;
+}
+
+__global__ __launch_bounds__(256) void add_bf16_kernel(const unsigned short* a, const unsigned short* b,
+                                                        unsigned short* y, long n) {
+  const long nv = n >> 3;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+    const u32x4 x = *(const u32x4*)(a + i * 8), z = *(const u32x4*)(b + i * 8);
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      o[e] = pack2bf(bf2f((unsigned short)(x[e] & 0xffff)) + bf2f((unsigned short)(z[e] & 0xffff)),
+                     bf2f((unsigned short)(x[e] >> 16)) + bf2f((unsigned short)(z[e] >> 16)));
+    *(u32x4*)(y + i * 8) = o;
+  }
+  if (blockIdx.x == 0) {
+    const long t = (nv << 3) + threadIdx.x;
+    if (t < n) y[t] = f2bf(bf2f(a[t]) + bf2f(b[t]));
+  }
+}
+extern "C" int wft_add_bf16(const wft_bf16* a, const wft_bf16* b, wft_bf16* y, int64_t n, void* stream) {
+  WFT_CHECK_ARG(a && b && y && n >= 0, "bad args");
+  WFT_CHECK_ARG((((uintptr_t)a) & 15) == 0 && (((uintptr_t)b) & 15) == 0 && (((uintptr_t)y) & 15) == 0, "16-byte alignment");
+  if (n == 0) return WFT_OK;
+  hipLaunchKernelGGL(add_bf16_kernel, dim3(ew_grid(n / 8 + 1)), dim3(256), 0, (hipStream_t)stream, a, b, y, (long)n);
+  WFT_CHECK_LAUNCH();
+  return WFT_OK;
+}
+
+// ----------------------------------------------------------------------------- column sums
+// grid (cols/8 chunks per 16-thread group ...): block = 16 column-threads (8 cols each = 128 cols) x 16 row-lanes
+__global__ __launch_bounds__(256) void colsum_kernel(const unsigned short* x, long rows, long cols, long ld, float* out,
+                                                      int rows_per_split) {
+  __shared__ float red[16][128];
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const long c0 = (long)blockIdx.x * 128 + cx * 8;
+  const long rbeg = (long)blockIdx.y * rows_per_split;
+  long rend = rbeg + rows_per_split;
+  if (rend > rows) rend = rows;
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c0 < cols) {
+    for (long r = rbeg + ry; r < rend; r += 16) {
+      const u32x4 v = *(const u32x4*)(x + r * ld + c0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s[2 * e] += bf2f((unsigned short)(v[e] & 0xffff));
+        s[2 * e + 1] += bf2f((unsigned short)(v[e] >> 16));
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[ry][cx * 8 + e] = s[e];
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
+    const long c = (long)blockIdx.x * 128 + threadIdx.x;
+    if (c < cols) atomicAdd(out + c, t);
+  }
+}
+extern "C" int wft_colsum_bf16(const wft_bf16* x, int64_t rows, int64_t cols, int64_t ld, float* out, int accumulate,
+                               void* stream) {
+  WFT_CHECK_ARG(x && out, "null pointer");
+  WFT_CHECK_ARG(rows >= 1 && cols >= 8 && cols % 8 == 0 && ld % 8 == 0, "cols/ld must be multiples of 8");
+  WFT_CHECK_ARG((((uintptr_t)x) & 15) == 0, "16-byte alignment");
+  hipStream_t s = (hipStream_t)stream;
+  if (!accumulate) (void)hipMemsetAsync(out, 0, cols * sizeof(float), s);
+  int nsplit = (int)((rows + 511) / 512);
+  if (nsplit > 64) nsplit = 64;
+  const int rps = (int)((rows + nsplit - 1) / nsplit);
+  dim3 grid((unsigned)((cols + 127) / 128), (unsigned)nsplit);
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, x, (long)rows, (long)cols, (long)ld, out, rps);
+  WFT_CHECK_LAUNCH();
+  return WFT_OK;
+}
+
+// ----------------------------------------------------------------------------- embedding
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const long* tokens, const float* emb, const float* pos,
+                                                         unsigned short* out, long n_tok, long S, int d, long V) {
+  const int dv = d >> 3;
+  const long total = n_tok * dv;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long t = i / dv;
+    const int c = (int)(i - t * dv) * 8;
+    long tok = tokens[t];
+    tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
+    const float* e = emb + tok * d + c;
+    const float* pp = pos + (t % S) * d + c;
+    const f32x4 a0 = *(const f32x4*)e, a1 = *(const f32x4*)(e + 4);
+    const f32x4 b0 = *(const f32x4*)pp, b1 = *(const f32x4*)(pp + 4);
+    u32x4 o = {pack2bf(a0[0] + b0[0], a0[1] + b0[1]), pack2bf(a0[2] + b0[2], a0[3] + b0[3]),
+               pack2bf(a1[0] + b1[0], a1[1] + b1[1]), pack2bf(a1[2] + b1[2], a1[3] + b1[3])};
+    *(u32x4*)(out + t * d + c) = o;
+  }
+}
+extern "C" int wft_embed_fwd(const int64_t* tokens, const float* emb, const float* pos, wft_bf16* out, int64_t B,
+                             int64_t S, int d, int64_t V, void* stream) {
+  WFT_CHECK_ARG(tokens && emb && pos && out, "null pointer");
+  WFT_CHECK_ARG(B >= 1 && S >= 1 && d >= 8 && d % 8 == 0 && V >= 1, "bad shape");
+  const long total = B * S * (d / 8);
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const long*)tokens, emb,
+                     pos, out, (long)(B * S), (long)S, d, (long)V);
+  WFT_CHECK_LAUNCH();
+  return WFT_OK;
+}
+
+__global__ __launch_bounds__(256) void embed_bwd_tok_kernel(const long* tokens, const unsigned short* dout, float* demb,
+                                                             long n_tok, int d, long V) {
+  const long total = n_tok * d;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long t = i / d;
+    const int c = (int)(i - t * d);
+    const long tok = tokens[t];
+    if (tok >= 0 && tok < V) atomicAdd(demb + tok * d + c, bf2f(dout[i]));
+  }
+}
+__global__ __launch_bounds__(256) void embed_bwd_pos_kernel(const unsigned short* dout, float* dpos, long B, long S, int d) {
+  const long total = S * d;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    float s = 0.f;
+    for (long b = 0; b < B; ++b) s += bf2f(dout[b * S * d + i]);
+    dpos[i] += s;
+  }
+}
+extern "C" int wft_embed_bwd(const int64_t* tokens, const wft_bf16* dout, float* demb, float* dpos, int64_t B, int64_t S,
+                             int d, int64_t V, void* stream) {
+  WFT_CHECK_ARG(tokens && dout && demb && dpos, "null pointer");
+  WFT_CHECK_ARG(B >= 1 && S >= 1 && d >= 1 && V >= 1, "bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(embed_bwd_tok_kernel, dim3(ew_grid(B * S * d)), dim3(256), 0, s, (const long*)tokens, dout, demb,
+                     (long)(B * S), d, (long)V);
+  hipLaunchKernelGGL(embed_bwd_pos_kernel, dim3(ew_grid(S * d)), dim3(256), 0, s, dout, dpos, (long)B, (long)S, d);
+  WFT_CHECK_LAUNCH();
+  return WFT_OK;
+}
+
+// ----------------------------------------------------------------------------- cross entropy
+// one 256-thread block per row; online (max, sum-exp), sum of logits, target logit, argmax.
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const unsigned short* logits, long ld, const long* targets, long V,
+                                                      float eps, float* row_loss, float* row_lse, long* argmax) {
+  __shared__ float sm[4], ss[4], sx[4], sbv[4];
+  __shared__ int sbi[4];
+  const long row = blockIdx.x;
+  const unsigned short* x = logits + row * ld;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  float m = -3.0e38f, s = 0.f, sumx = 0.f, bv = -3.0e38f;
+  int bi = 0x7fffffff;
+  const long nv = V >> 3;
+  for (long i = tid; i < nv; i += 256) {
+    const u32x4 r = *(const u32x4*)(x + i * 8);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[2 * e] = bf2f((unsigned short)(r[e] & 0xffff));
+      v[2 * e + 1] = bf2f((unsigned short)(r[e] >> 16));
+    }
+    float cm = v[0];
+#pragma unroll
+    for (int e = 1; e < 8; ++e) cm = fmaxf(cm, v[e]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (v[e] > bv) { bv = v[e]; bi = (int)(i * 8 + e); }
+      sumx += v[e];
+    }
+    if (cm > m) { s *= __expf(m - cm); m = cm; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += __expf(v[e] - m);
+  }
+  for (long c = (nv << 3) + tid; c < V; c += 256) {
+    const float v = bf2f(x[c]);
+    if (v > bv) { bv = v; bi = (int)c; }
+    sumx += v;
+    if (v > m) { s *= __expf(m - v); m = v; }
+    s += __expf(v - m);
+  }
+  // wave reduce
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float om = __shfl_xor(m, o, 64), os = __shfl_xor(s, o, 64);
+    const float nm = fmaxf(m, om);
+    s = s * __expf(m - nm) + os * __expf(om - nm);
+    m = nm;
+    sumx += __shfl_xor(sumx, o, 64);
+    const float obv = __shfl_xor(bv, o, 64);
+    const int obi = __shfl_xor(bi, o, 64);
+    if (obv > bv || (obv == bv && obi < bi)) { bv = obv; bi = obi; }
+  }
+  if (lane == 0) { sm[wv] = m; ss[wv] = s; sx[wv] = sumx; sbv[wv] = bv; sbi[wv] = bi; }
+  __syncthreads();
+  if (tid == 0) {
+    float M = sm[0], S = ss[0], X = sx[0], BV = sbv[0];
+    int BI = sbi[0];
+    for (int w = 1; w < 4; ++w) {
+      const float nm = fmaxf(M, sm[w]);
+      S = S * __expf(M - nm) + ss[w] * __expf(sm[w] - nm);
+      M = nm;
+      X += sx[w];
+      if (sbv[w] > BV || (sbv[w] == BV && sbi[w] < BI)) { BV = sbv[w]; BI = sbi[w]; }
+    }
+    const float lse = M + __logf(S);
+    const long t = targets[row];
+    float loss = 0.f;
+    if (t >= 0 && t < V) {
+      const float xt = bf2f(x[t]);
+      loss = (1.f - eps) * (lse - xt) + eps * (lse - X / (float)V);
+    }
+    row_loss[row] = loss;
+    row_lse[row] = lse;
+    if (argmax) argmax[row] = BI;
+  }
+}
+// deterministic reduction of the row losses (single block)
+__global__ __launch_bounds__(256) void ce_reduce_kernel(const float* row_loss, const long* targets, long rows, long V,
+                                                         float* stats) {
+  __shared__ float sl[256], sc[256];
+  float l = 0.f, c = 0.f;
+  for (long r = threadIdx.x; r < rows; r += 256) {
+    const long t = targets[r];
+    if (t >= 0 && t < V) { l += row_loss[r]; c += 1.f; }
+  }
+  sl[threadIdx.x] = l;
+  sc[threadIdx.x] = c;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) { sl[threadIdx.x] += sl[threadIdx.x + o]; sc[threadIdx.x] += sc[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { stats[0] = sl[0]; stats[1] = sc[0]; }
+}
+extern "C" int wft_ce_fwd(const wft_bf16* logits, int64_t ld, const int64_t* targets, int64_t rows, int64_t V,
+                          float label_smoothing, float* row_loss, float* row_lse, float* stats, int64_t* argmax,
+                          void* stream) {
+  WFT_CHECK_ARG(logits && targets && row_loss && row_lse && stats, "null pointer");
+  WFT_CHECK_ARG(rows >= 1 && V >= 1 && ld >= V && ld % 8 == 0, "bad shape (ld must be a multiple of 8, >= V)");
+  WFT_CHECK_ARG((((uintptr_t)logits) & 15) == 0, "16-byte alignment");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3((unsigned)rows), dim3(256), 0, s, logits, (long)ld, (const long*)targets, (long)V,
+                     label_smoothing, row_loss, row_lse, (long*)argmax);
+  hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(256), 0, s, row_loss, (const long*)targets, (long)rows, (long)V, stats);
+  WFT_CHECK_LAUNCH();
+  return WFT_OK;
+}
+
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const unsigned short* logits, long ld, const long* targets, long V,
+                                                      float eps, const float* row_lse, const float* stats,
+                                                      const float* gscale, unsigned short* dlogits) {
+  const long row = blockIdx.x;
+  const unsigned short* x = logits + row * ld;
+  unsigned short* dx = dlogits + row * ld;
+  const long t = targets[row];
+  const bool valid = t >= 0 && t < V;
+  const float coef = valid ? gscale[0] / fmaxf(stats[1], 1.f) : 0.f;
+  const float lse = row_lse[row];
+  const float sm = eps / (float)V;
+  const long nv = ld >> 3;
+  for (long i = threadIdx.x; i < nv; i += 256) {
+    const u32x4 r = *(const u32x4*)(x + i * 8);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[2 * e] = bf2f((unsigned short)(r[e] & 0xffff));
+      v[2 * e + 1] = bf2f((unsigned short)(r[e] >> 16));
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const long c = i * 8 + e;
+      float g = 0.f;
+      if (c < V) {
+        g = __expf(v[e] - lse) - sm;
+        if (c == t) g -= (1.f - eps);
+        g *= coef;
+      }
+      v[e] = g;
+    }
+    u32x4 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+    *(u32x4*)(dx + i * 8) = o;
+  }
+}
+extern "C" int wft_ce_bwd(const wft_bf16* logits, int64_t ld, const int64_t* targets, int64_t rows, int64_t V,
+                          float label_smoothing, const float* row_lse, const float* stats, const float* gscale,
+                          wft_bf16* dlogits, void* stream) {
+  WFT_CHECK_ARG(logits && targets && row_lse && stats && gscale && dlogits, "null pointer");
+  WFT_CHECK_ARG(rows >= 1 && V >= 1 && ld >= V && ld % 8 == 0, "bad shape (ld must be a multiple of 8, >= V)");
+  WFT_CHECK_ARG((((uintptr_t)logits) & 15) == 0 && (((uintptr_t)dlogits) & 15) == 0, "16-byte alignment");
+  hipLaunchKernelGGL(ce_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, (long)ld,
+                     (const long*)targets, (long)V, label_smoothing, row_lse, stats, gscale, dlogits);
+  WFT_CHECK_LAUNCH();
+  return WFT_OK;
+}
+
+// ----------------------------------------------------------------------------- AdamW
+__global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, unsigned short* pb,
+                                                     long n, float lr, float b1, float b2, float eps, float wd, float bc1,
+                                                     float bc2, const float* gscale) {
+  const float gs = gscale ? gscale[0] : 1.f;
+  const float step = lr / bc1;
+  const float rbc2 = rsqrtf(bc2);
+  const long nv = n >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+    f32x4 pp = *(f32x4*)(p + i * 4);
+    const f32x4 gg = *(const f32x4*)(g + i * 4) * gs;
+    f32x4 mm = *(f32x4*)(m + i * 4), vv = *(f32x4*)(v + i * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      pp[e] *= (1.f - lr * wd);
+      mm[e] = b1 * mm[e] + (1.f - b1) * gg[e];
+      vv[e] = b2 * vv[e] + (1.f - b2) * gg[e] * gg[e];
+      const float denom = sqrtf(vv[e]) * rbc2 + eps;
+      pp[e] -= step * mm[e] / denom;
+    }
+    *(f32x4*)(p + i * 4) = pp;
+    *(f32x4*)(m + i * 4) = mm;
+    *(f32x4*)(v + i * 4) = vv;
+    if (pb) {
+      u32x2 o = {pack2bf(pp[0], pp[1]), pack2bf(pp[2], pp[3])};
+      *(u32x2*)(pb + i * 4) = o;
+    }
+  }
+  if (blockIdx.x == 0) {
+    const long t = (nv << 2) + threadIdx.x;
+    if (t < n) {
+      float pp = p[t] * (1.f - lr * wd);
+      const float gg = g[t] * gs;
+      const float mm = b1 * m[t] + (1.f - b1) * gg;
+      const float vv = b2 * v[t] + (1.f - b2) * gg * gg;
+      pp -= step * mm / (sqrtf(vv) * rbc2 + eps);
+      p[t] = pp; m[t] = mm; v[t] = vv;
+      if (pb) pb[t] = f2bf(pp);
+    }
+  }
+}
+extern "C" int wft_adamw_step(float* p, const float* g, float* m, float* v, wft_bf16* p_bf16, int64_t n, float lr,
+                              float beta1, float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2,
+                              const float* gscale, void* stream) {
+  WFT_CHECK_ARG(p && g && m && v && n >= 1, "bad args");
+  WFT_CHECK_ARG((((uintptr_t)p) & 15) == 0 && (((uintptr_t)g) & 15) == 0 && (((uintptr_t)m) & 15) == 0 &&
+                    (((uintptr_t)v) & 15) == 0 && (!p_bf16 || (((uintptr_t)p_bf16) & 7) == 0),
+                "16-byte alignment");
+  hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, p_bf16, (long)n,
+                     lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, gscale);
+  WFT_CHECK_LAUNCH();
+  return WFT_OK;
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* g, long n, float* out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  const long nv = n >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+    const f32x4 x = *(const f32x4*)(g + i * 4);
+    s += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+  }
+  if (blockIdx.x == 0) {
+    const long t = (nv << 2) + threadIdx.x;
+    if (t < n) s += g[t] * g[t];
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+extern "C" int wft_sumsq_f32(const float* g, int64_t n, float* out, void* stream) {
+  WFT_CHECK_ARG(g && out && n >= 1, "bad args");
+  WFT_CHECK_ARG((((uintptr_t)g) & 15) == 0, "16-byte alignment");
+  int grid = ew_grid(n / 4 + 1);
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, (long)n, out);
+  WFT_CHECK_LAUNCH();
+  return WFT_OK;
+}

@@ -1,0 +1,353 @@
+"""Tensor-level wrappers over the C ABI (no autograd here; see ops.py).
+
+Every function takes torch CUDA tensors, checks dtype/contiguity, and enqueues the HIP
+kernel on the current stream.  Shapes follow include/wft.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import lib as L
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _p(t: Optional[torch.Tensor]):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _chk(t: torch.Tensor, dtype, name: str):
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_cuda:
+        raise L.WftError(f"{name}: libwft kernels need CUDA/HIP tensors (got {t.device}); there is no CPU path")
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+# --------------------------------------------------------------------------- casts
+def cast_bf16(src: torch.Tensor) -> torch.Tensor:
+    _chk(src, F32, "src")
+    src = src.contiguous()
+    dst = torch.empty(src.shape, dtype=BF16, device=src.device)
+    L.check(L.load().wft_cast_f32_bf16(_p(src), _p(dst), src.numel(), L.stream_ptr()), "wft_cast_f32_bf16")
+    return dst
+
+
+def cast_f32(src: torch.Tensor) -> torch.Tensor:
+    _chk(src, BF16, "src")
+    src = src.contiguous()
+    dst = torch.empty(src.shape, dtype=F32, device=src.device)
+    L.check(L.load().wft_cast_bf16_f32(_p(src), _p(dst), src.numel(), L.stream_ptr()), "wft_cast_bf16_f32")
+    return dst
+
+
+def weight_shadow(w: torch.Tensor, rows_pad: int, cols_pad: int, want_t: bool, out=None, out_t=None):
+    """f32 [rows, cols] -> bf16 [rows_pad, cols_pad] (+ transposed [cols_pad, rows_pad])."""
+    _chk(w, F32, "w")
+    w2 = w.reshape(w.shape[0], -1).contiguous()
+    rows, cols = w2.shape
+    dst = out if out is not None else torch.empty((rows_pad, cols_pad), dtype=BF16, device=w.device)
+    dst_t = None
+    if want_t:
+        dst_t = out_t if out_t is not None else torch.empty((cols_pad, rows_pad), dtype=BF16, device=w.device)
+    L.check(
+        L.load().wft_cast_pad_transpose_f32_bf16(_p(w2), rows, cols, _p(dst), _p(dst_t), rows_pad, cols_pad, L.stream_ptr()),
+        "wft_cast_pad_transpose_f32_bf16",
+    )
+    return dst, dst_t
+
+
+def add_bf16(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    _chk(a, BF16, "a"); _chk(b, BF16, "b")
+    a = a.contiguous(); b = b.contiguous()
+    y = torch.empty_like(a)
+    L.check(L.load().wft_add_bf16(_p(a), _p(b), _p(y), a.numel(), L.stream_ptr()), "wft_add_bf16")
+    return y
+
+
+def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """x bf16 [rows, cols] (row stride may exceed cols) -> f32 [cols]."""
+    _chk(x, BF16, "x")
+    assert x.dim() == 2 and x.stride(1) == 1
+    rows, cols = x.shape
+    if out is None:
+        out = torch.empty(cols, dtype=F32, device=x.device)
+        accumulate = False
+    L.check(L.load().wft_colsum_bf16(_p(x), rows, cols, x.stride(0), _p(out), int(accumulate), L.stream_ptr()), "wft_colsum_bf16")
+    return out
+
+
+# --------------------------------------------------------------------------- layernorm
+def layernorm_fwd(x, gamma, beta, eps=1e-5, mask=None):
+    """x bf16 [..., cols]; mask = (rows_per_batch, t0, t1, c0, c1) or None."""
+    _chk(x, BF16, "x"); _chk(gamma, F32, "gamma"); _chk(beta, F32, "beta")
+    x = x.contiguous()
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=F32, device=x.device)
+    rstd = torch.empty(rows, dtype=F32, device=x.device)
+    rpb, t0, t1, c0, c1 = mask if mask is not None else (0, 0, 0, 0, 0)
+    L.check(
+        L.load().wft_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, cols, eps,
+                                   rpb, t0, t1, c0, c1, L.stream_ptr()),
+        "wft_layernorm_fwd",
+    )
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, mask=None):
+    """returns dx bf16, dgamma f32, dbeta f32 (fresh, zero-initialised accumulators)."""
+    _chk(dy, BF16, "dy"); _chk(x, BF16, "x")
+    dy = dy.contiguous(); x = x.contiguous()
+    if dres is not None:
+        _chk(dres, BF16, "dres")
+        dres = dres.contiguous()
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    lib = L.load()
+    ws = torch.empty(lib.wft_layernorm_bwd_workspace(rows, cols), dtype=torch.uint8, device=x.device)
+    dx = torch.empty_like(x)
+    dgamma = torch.zeros(cols, dtype=F32, device=x.device)
+    dbeta = torch.zeros(cols, dtype=F32, device=x.device)
+    rpb, t0, t1, c0, c1 = mask if mask is not None else (0, 0, 0, 0, 0)
+    L.check(
+        lib.wft_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), _p(dgamma), _p(dbeta),
+                              _p(ws), rows, cols, rpb, t0, t1, c0, c1, L.stream_ptr()),
+        "wft_layernorm_bwd",
+    )
+    return dx, dgamma, dbeta
+
+
+# --------------------------------------------------------------------------- GEMM
+def gemm_nt(a, b, *, M=None, N=None, K=None, lda=None, ldb=None, out=None, out_f32=False, accumulate=False,
+            bias=None, residual=None, aux=None, epilogue=L.EPI_NONE, alpha=1.0, batch=1,
+            strideA=0, strideB=0, strideC=0, strideR=0, strideAux=0, ldc=None,
+            valid_rows_period=0, valid_rows=0):
+    """C[M,N] = alpha * A[M,K] @ B[N,K]^T (+bias) (epilogue) (+residual).
+
+    a: bf16, row m at a.data_ptr() + m*lda; b: bf16 [N, K] (ldb).  Defaults take the shapes
+    from 2-D contiguous tensors.  `aux`: GELU pre-activation out (EPI_GELU) / in (EPI_DGELU).
+    """
+    _chk(a, BF16, "A"); _chk(b, BF16, "B")
+    if M is None:
+        M = a.shape[0]
+    if K is None:
+        K = a.shape[-1]
+    if N is None:
+        N = b.shape[0]
+    if lda is None:
+        lda = a.stride(-2) if a.dim() >= 2 else K
+    if ldb is None:
+        ldb = b.stride(-2)
+    if out is None:
+        out = torch.empty((batch * M, N) if batch > 1 else (M, N), dtype=F32 if out_f32 else BF16, device=a.device)
+        if batch > 1 and strideC == 0:
+            strideC = M * N
+    if ldc is None:
+        ldc = out.stride(-2)
+    out_f32 = out.dtype == F32
+    args = L.GemmArgs()
+    args.A, args.lda, args.strideA = a.data_ptr(), lda, strideA
+    args.B, args.ldb, args.strideB = b.data_ptr(), ldb, strideB
+    args.C, args.ldc, args.strideC = out.data_ptr(), ldc, strideC
+    args.c_is_f32, args.accumulate = int(out_f32), int(accumulate)
+    args.bias = 0 if bias is None else bias.data_ptr()
+    if residual is not None:
+        _chk(residual, BF16, "residual")
+        args.residual, args.ldr, args.strideR = residual.data_ptr(), residual.stride(-2), strideR
+    if aux is not None:
+        _chk(aux, BF16, "aux")
+        args.aux, args.ldaux, args.strideAux = aux.data_ptr(), aux.stride(-2), strideAux
+    args.epilogue, args.alpha = epilogue, alpha
+    args.M, args.N, args.K, args.batch = M, N, K, batch
+    args.valid_rows_period, args.valid_rows = valid_rows_period, valid_rows
+    L.check(L.load().wft_gemm_nt_bf16(C.byref(args), L.stream_ptr()), "wft_gemm_nt_bf16")
+    return out
+
+
+def gemm_tn(a, b, *, P=None, Q=None, R=None, lda=None, ldb=None, out=None, out_f32=True, accumulate=False,
+            alpha=1.0, batch=1, strideA=0, strideB=0):
+    """C[P,Q] (+)= alpha * A[R,P]^T @ B[R,Q]  (weight gradients)."""
+    _chk(a, BF16, "A"); _chk(b, BF16, "B")
+    if R is None:
+        R = a.shape[0]
+    if P is None:
+        P = a.shape[1]
+    if Q is None:
+        Q = b.shape[1]
+    if lda is None:
+        lda = a.stride(0)
+    if ldb is None:
+        ldb = b.stride(0)
+    if out is None:
+        out = torch.empty((P, Q), dtype=F32 if out_f32 else BF16, device=a.device)
+        accumulate = False
+    args = L.GemmArgs()
+    args.A, args.lda, args.strideA = a.data_ptr(), lda, strideA
+    args.B, args.ldb, args.strideB = b.data_ptr(), ldb, strideB
+    args.C, args.ldc, args.strideC = out.data_ptr(), out.stride(0), 0
+    args.c_is_f32, args.accumulate = int(out.dtype == F32), int(accumulate)
+    args.epilogue, args.alpha = L.EPI_NONE, alpha
+    args.M, args.N, args.K, args.batch = P, Q, R, batch
+    L.check(L.load().wft_gemm_tn_bf16(C.byref(args), L.stream_ptr()), "wft_gemm_tn_bf16")
+    return out
+
+
+# --------------------------------------------------------------------------- attention
+def _attn_view(t: torch.Tensor):
+    """t: [B, T, H*64-ish view] with last-dim stride 1 -> (ptr, ld, batch_stride)."""
+    assert t.dim() == 3 and t.stride(2) == 1
+    return t.data_ptr(), t.stride(1), t.stride(0)
+
+
+def attn_fwd(q, k, v, n_head: int, causal: bool, scale: float):
+    """q [B,Tq,H*64], k/v [B,Tk,H*64] bf16 views (any row stride) -> o [B,Tq,H*64], lse [B,H,Tq]."""
+    for n, t in (("q", q), ("k", k), ("v", v)):
+        _chk(t, BF16, n)
+    B, Tq, D = q.shape
+    Tk = k.shape[1]
+    assert D == n_head * 64, "head_dim must be 64"
+    o = torch.empty((B, Tq, D), dtype=BF16, device=q.device)
+    lse = torch.empty((B, n_head, Tq), dtype=F32, device=q.device)
+    a = L.AttnArgs()
+    a.q, a.ldq, a.q_bs = _attn_view(q)
+    a.k, a.ldk, a.k_bs = _attn_view(k)
+    a.v, a.ldv, a.v_bs = _attn_view(v)
+    a.o, a.ldo, a.o_bs = _attn_view(o)
+    a.lse = lse.data_ptr()
+    a.B, a.H, a.Tq, a.Tk, a.causal, a.scale = B, n_head, Tq, Tk, int(causal), scale
+    L.check(L.load().wft_attn_fwd_bf16(C.byref(a), L.stream_ptr()), "wft_attn_fwd_bf16")
+    return o, lse
+
+
+def attn_bwd(q, k, v, o, lse, do, n_head: int, causal: bool, scale: float, dq=None, dk=None, dv=None):
+    B, Tq, D = q.shape
+    Tk = k.shape[1]
+    _chk(do, BF16, "do")
+    if do.stride(2) != 1:
+        do = do.contiguous()
+    dq = torch.empty((B, Tq, D), dtype=BF16, device=q.device) if dq is None else dq
+    dk = torch.empty((B, Tk, D), dtype=BF16, device=q.device) if dk is None else dk
+    dv = torch.empty((B, Tk, D), dtype=BF16, device=q.device) if dv is None else dv
+    delta = torch.empty((B, n_head, Tq), dtype=F32, device=q.device)
+    a = L.AttnArgs()
+    a.q, a.ldq, a.q_bs = _attn_view(q)
+    a.k, a.ldk, a.k_bs = _attn_view(k)
+    a.v, a.ldv, a.v_bs = _attn_view(v)
+    a.o, a.ldo, a.o_bs = _attn_view(o)
+    a.lse = lse.data_ptr()
+    a.B, a.H, a.Tq, a.Tk, a.causal, a.scale = B, n_head, Tq, Tk, int(causal), scale
+    a.d_o, a.lddo, a.do_bs = _attn_view(do)
+    a.delta = delta.data_ptr()
+    a.dq, a.lddq, a.dq_bs = _attn_view(dq)
+    a.dk, a.lddk, a.dk_bs = _attn_view(dk)
+    a.dv, a.lddv, a.dv_bs = _attn_view(dv)
+    L.check(L.load().wft_attn_bwd_bf16(C.byref(a), L.stream_ptr()), "wft_attn_bwd_bf16")
+    return dq, dk, dv
+
+
+# --------------------------------------------------------------------------- embedding / CE
+def embed_fwd(tokens, emb, pos):
+    _chk(tokens, torch.int64, "tokens"); _chk(emb, F32, "emb"); _chk(pos, F32, "pos")
+    tokens = tokens.contiguous()
+    B, S = tokens.shape
+    V, d = emb.shape
+    out = torch.empty((B, S, d), dtype=BF16, device=emb.device)
+    L.check(L.load().wft_embed_fwd(_p(tokens), _p(emb), _p(pos), _p(out), B, S, d, V, L.stream_ptr()), "wft_embed_fwd")
+    return out
+
+
+def embed_bwd(tokens, dout, demb, dpos):
+    """accumulates into demb f32 [V,d] and dpos f32 [n_ctx,d]."""
+    _chk(dout, BF16, "dout")
+    tokens = tokens.contiguous(); dout = dout.contiguous()
+    B, S = tokens.shape
+    V, d = demb.shape
+    L.check(L.load().wft_embed_bwd(_p(tokens), _p(dout), _p(demb), _p(dpos), B, S, d, V, L.stream_ptr()), "wft_embed_bwd")
+
+
+def ce_fwd(logits, targets, V: int, label_smoothing: float, want_argmax: bool = False):
+    """logits bf16 [rows, ld>=V]; targets i64 [rows] -> (row_loss, row_lse, stats[2], argmax|None)."""
+    _chk(logits, BF16, "logits"); _chk(targets, torch.int64, "targets")
+    assert logits.dim() == 2 and logits.stride(1) == 1
+    rows, ld = logits.shape[0], logits.stride(0)
+    targets = targets.contiguous()
+    dev = logits.device
+    row_loss = torch.empty(rows, dtype=F32, device=dev)
+    row_lse = torch.empty(rows, dtype=F32, device=dev)
+    stats = torch.empty(2, dtype=F32, device=dev)
+    am = torch.empty(rows, dtype=torch.int64, device=dev) if want_argmax else None
+    L.check(
+        L.load().wft_ce_fwd(_p(logits), ld, _p(targets), rows, V, label_smoothing, _p(row_loss), _p(row_lse), _p(stats),
+                            _p(am), L.stream_ptr()),
+        "wft_ce_fwd",
+    )
+    return row_loss, row_lse, stats, am
+
+
+def ce_bwd(logits, targets, V: int, label_smoothing: float, row_lse, stats, gscale, inplace=True):
+    rows, ld = logits.shape[0], logits.stride(0)
+    dl = logits if inplace else torch.empty_like(logits)
+    gscale = gscale.reshape(1).to(F32)
+    L.check(
+        L.load().wft_ce_bwd(_p(logits), ld, _p(targets.contiguous()), rows, V, label_smoothing, _p(row_lse), _p(stats),
+                            _p(gscale), _p(dl), L.stream_ptr()),
+        "wft_ce_bwd",
+    )
+    return dl
+
+
+# --------------------------------------------------------------------------- audio
+def logmel(audio, filters, n_frames: int = 3000):
+    """audio f32 [B, 160*n_frames], filters f32 [n_mels, 201] -> f32 [B, n_mels, n_frames]."""
+    _chk(audio, F32, "audio"); _chk(filters, F32, "filters")
+    audio = audio.contiguous(); filters = filters.contiguous()
+    B, n = audio.shape
+    n_mels = filters.shape[0]
+    out = torch.empty((B, n_mels, n_frames), dtype=F32, device=audio.device)
+    clipmax = torch.empty(B, dtype=F32, device=audio.device)
+    L.check(L.load().wft_logmel(_p(audio), _p(filters), _p(out), _p(clipmax), B, n, n_mels, n_frames, L.stream_ptr()), "wft_logmel")
+    return out
+
+
+def specaug(mel, params, extremes=None):
+    """mel f32 [B, n_mels, T]; params i32 [B, 8]; extremes i32 [B, 2] or None."""
+    _chk(mel, F32, "mel"); _chk(params, torch.int32, "params")
+    mel = mel.contiguous(); params = params.contiguous()
+    B, n_mels, T = mel.shape
+    out = torch.empty_like(mel)
+    if extremes is not None:
+        _chk(extremes, torch.int32, "extremes")
+        extremes = extremes.contiguous()
+    L.check(L.load().wft_specaug(_p(mel), _p(out), _p(params), _p(extremes), B, n_mels, T, L.stream_ptr()), "wft_specaug")
+    return out
+
+
+def mel_to_tmajor(mel, c_pad: int):
+    _chk(mel, F32, "mel")
+    mel = mel.contiguous()
+    B, n_mels, T = mel.shape
+    out = torch.empty((B, T + 2, c_pad), dtype=BF16, device=mel.device)
+    L.check(L.load().wft_mel_to_tmajor_bf16(_p(mel), _p(out), B, n_mels, T, c_pad, L.stream_ptr()), "wft_mel_to_tmajor_bf16")
+    return out
+
+
+# --------------------------------------------------------------------------- optimizer
+def adamw_step(p, g, m, v, p_bf16, lr, beta1, beta2, eps, wd, bc1, bc2, gscale=None):
+    L.check(
+        L.load().wft_adamw_step(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), p.numel(), lr, beta1, beta2, eps, wd, bc1, bc2,
+                                _p(gscale), L.stream_ptr()),
+        "wft_adamw_step",
+    )
+
+
+def sumsq(g, out):
+    L.check(L.load().wft_sumsq_f32(_p(g), g.numel(), _p(out), L.stream_ptr()), "wft_sumsq_f32")

@@ -1,0 +1,127 @@
+"""ctypes binding of libwft.so (the C ABI declared in include/wft.h).
+
+Only plain pointers and sizes cross this boundary: tensors are passed as
+``tensor.data_ptr()`` and the stream as ``torch.cuda.current_stream().cuda_stream``.
+There is NO fallback: if the shared library is missing or a call fails, an exception
+is raised (the product path never routes through the CPU oracle).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_PKG_ROOT = Path(__file__).resolve().parents[2]  # whisper-finetune_amd/
+LIB_PATH = Path(os.environ.get("WFT_LIB", _PKG_ROOT / "libwft.so"))
+
+c_i64 = C.c_int64
+c_vp = C.c_void_p
+
+
+class GemmArgs(C.Structure):
+    """Mirror of wft_gemm_args (include/wft.h)."""
+
+    _fields_ = [
+        ("A", c_vp), ("lda", c_i64), ("strideA", c_i64),
+        ("B", c_vp), ("ldb", c_i64), ("strideB", c_i64),
+        ("C", c_vp), ("ldc", c_i64), ("strideC", c_i64), ("c_is_f32", C.c_int), ("accumulate", C.c_int),
+        ("bias", c_vp),
+        ("residual", c_vp), ("ldr", c_i64), ("strideR", c_i64),
+        ("aux", c_vp), ("ldaux", c_i64), ("strideAux", c_i64),
+        ("epilogue", C.c_int), ("alpha", C.c_float),
+        ("M", c_i64), ("N", c_i64), ("K", c_i64), ("batch", C.c_int),
+        ("valid_rows_period", C.c_int), ("valid_rows", C.c_int),
+    ]
+
+
+class AttnArgs(C.Structure):
+    """Mirror of wft_attn_args (include/wft.h)."""
+
+    _fields_ = [
+        ("q", c_vp), ("ldq", c_i64), ("q_bs", c_i64),
+        ("k", c_vp), ("ldk", c_i64), ("k_bs", c_i64),
+        ("v", c_vp), ("ldv", c_i64), ("v_bs", c_i64),
+        ("o", c_vp), ("ldo", c_i64), ("o_bs", c_i64),
+        ("lse", c_vp),
+        ("B", C.c_int), ("H", C.c_int), ("Tq", C.c_int), ("Tk", C.c_int), ("causal", C.c_int), ("scale", C.c_float),
+        ("d_o", c_vp), ("lddo", c_i64), ("do_bs", c_i64),
+        ("delta", c_vp),
+        ("dq", c_vp), ("lddq", c_i64), ("dq_bs", c_i64),
+        ("dk", c_vp), ("lddk", c_i64), ("dk_bs", c_i64),
+        ("dv", c_vp), ("lddv", c_i64), ("dv_bs", c_i64),
+    ]
+
+
+EPI_NONE, EPI_GELU, EPI_DGELU = 0, 1, 2
+
+# name -> argtypes (restype is int unless listed in _RESTYPES); this table is also what
+# tests/test_abi.py checks against the declarations in include/wft.h.
+SIGNATURES = {
+    "wft_cast_f32_bf16": [c_vp, c_vp, c_i64, c_vp],
+    "wft_cast_bf16_f32": [c_vp, c_vp, c_i64, c_vp],
+    "wft_cast_pad_transpose_f32_bf16": [c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_i64, c_vp],
+    "wft_add_bf16": [c_vp, c_vp, c_vp, c_i64, c_vp],
+    "wft_colsum_bf16": [c_vp, c_i64, c_i64, c_i64, c_vp, C.c_int, c_vp],
+    "wft_layernorm_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_float,
+                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp],
+    "wft_layernorm_bwd_workspace": [c_i64, C.c_int],
+    "wft_layernorm_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int,
+                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp],
+    "wft_gemm_nt_bf16": [C.POINTER(GemmArgs), c_vp],
+    "wft_gemm_tn_bf16": [C.POINTER(GemmArgs), c_vp],
+    "wft_attn_fwd_bf16": [C.POINTER(AttnArgs), c_vp],
+    "wft_attn_bwd_bf16": [C.POINTER(AttnArgs), c_vp],
+    "wft_embed_fwd": [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, C.c_int, c_i64, c_vp],
+    "wft_embed_bwd": [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, C.c_int, c_i64, c_vp],
+    "wft_ce_fwd": [c_vp, c_i64, c_vp, c_i64, c_i64, C.c_float, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "wft_ce_bwd": [c_vp, c_i64, c_vp, c_i64, c_i64, C.c_float, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "wft_logmel": [c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, c_vp],
+    "wft_specaug": [c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp],
+    "wft_mel_to_tmajor_bf16": [c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, c_vp],
+    "wft_adamw_step": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_float, C.c_float, C.c_float, C.c_float,
+                       C.c_float, C.c_float, C.c_float, c_vp, c_vp],
+    "wft_sumsq_f32": [c_vp, c_i64, c_vp, c_vp],
+    "wft_last_error": [],
+    "wft_version": [],
+}
+_RESTYPES = {"wft_last_error": C.c_char_p, "wft_version": C.c_char_p, "wft_layernorm_bwd_workspace": c_i64}
+
+_lib = None
+
+
+class WftError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libwft.so (once). Raises WftError if it is missing — never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise WftError(
+            f"HIP extension {LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(make -C whisper-finetune_amd/csrc). There is no CPU fallback for the product path."
+        )
+    lib = C.CDLL(str(LIB_PATH))
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().wft_last_error().decode()
+
+
+def check(status: int, what: str):
+    if status != 0:
+        raise WftError(f"{what} failed with status {status}: {last_error()}")
+
+
+def stream_ptr():
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
