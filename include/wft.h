@@ -50,14 +50,19 @@ const char* wft_version(void);
  * whisper.model.Linear.forward under autocast).        */
 int wft_cast_f32_bf16(const float* src, wft_bf16* dst, int64_t n, void* stream);
 int wft_cast_bf16_f32(const wft_bf16* src, float* dst, int64_t n, void* stream);
-/* src f32 [rows, cols] -> dst bf16 [rows_pad, cols_pad] (zero padded) and, if
- * dst_t != NULL, dst_t bf16 [cols_pad, rows_pad] (the transposed shadow the
- * backward-data GEMM consumes).  rows_pad>=rows, cols_pad>=cols.            */
+/* src f32 [rows, cols] -> dst bf16 [rows_pad, cols_pad] (zero padded, row
+ * stride ld_dst) and, if dst_t != NULL, dst_t bf16 [cols_pad, rows_pad] (row
+ * stride ld_dst_t: the transposed shadow the backward-data GEMM consumes).
+ * The strides let several weights (q/k/v) share one concatenated shadow.     */
 int wft_cast_pad_transpose_f32_bf16(const float* src, int64_t rows, int64_t cols,
                                     wft_bf16* dst, wft_bf16* dst_t,
-                                    int64_t rows_pad, int64_t cols_pad, void* stream);
+                                    int64_t rows_pad, int64_t cols_pad,
+                                    int64_t ld_dst, int64_t ld_dst_t, void* stream);
 /* y[i] = a[i] + b[i] (bf16) — gradient accumulation on the residual stream. */
 int wft_add_bf16(const wft_bf16* a, const wft_bf16* b, wft_bf16* y, int64_t n, void* stream);
+/* out[i] = dy[i] * gelu'(pre[i]) (exact-erf GELU) — backward through F.gelu in the
+ * conv stem (model/model_utils.py:276-277).                                  */
+int wft_dgelu_mul_bf16(const wft_bf16* dy, const wft_bf16* pre, wft_bf16* out, int64_t n, void* stream);
 /* out[c] (+)= sum_r x[r, c] — bias gradients.  x bf16 [rows, ld], out f32[cols] */
 int wft_colsum_bf16(const wft_bf16* x, int64_t rows, int64_t cols, int64_t ld,
                     float* out, int accumulate, void* stream);
@@ -116,6 +121,7 @@ typedef struct {
   int epilogue; float alpha;
   int64_t M; int64_t N; int64_t K; int batch;
   int valid_rows_period; int valid_rows;
+  int residual_first;  /* != 0: add the residual BEFORE the epilogue op (gelu / dgelu) instead of after */
 } wft_gemm_args;
 int wft_gemm_nt_bf16(const wft_gemm_args* args, void* stream);
 /* C[p, q] (+)= alpha * sum_r A[r, p] * B[r, q]   (weight gradients dW = dY^T X:

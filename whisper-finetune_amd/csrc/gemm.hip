@@ -24,6 +24,7 @@ struct GemmP {
   int M, N, K, batch;
   int accumulate;
   int period, valid;
+  int res_first;
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int ntile) {
@@ -118,6 +119,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += b4[e];
       }
+      if (p.res && p.res_first) {
+        const u32x2 r2 = *(const u32x2*)(p.res + (long)bz * p.sR + (long)m * p.ldr + n);
+        v[0] += bf2f((unsigned short)(r2[0] & 0xffff));
+        v[1] += bf2f((unsigned short)(r2[0] >> 16));
+        v[2] += bf2f((unsigned short)(r2[1] & 0xffff));
+        v[3] += bf2f((unsigned short)(r2[1] >> 16));
+      }
       if (EPI == WFT_EPI_GELU) {
         if (p.aux) {
           u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
@@ -132,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
         v[2] *= dgelu_f(bf2f((unsigned short)(a2[1] & 0xffff)));
         v[3] *= dgelu_f(bf2f((unsigned short)(a2[1] >> 16)));
       }
-      if (p.res) {
+      if (p.res && !p.res_first) {
         const u32x2 r2 = *(const u32x2*)(p.res + (long)bz * p.sR + (long)m * p.ldr + n);
         v[0] += bf2f((unsigned short)(r2[0] & 0xffff));
         v[1] += bf2f((unsigned short)(r2[0] >> 16));
@@ -298,6 +306,7 @@ static int fill_params(const wft_gemm_args* a, GemmP& p) {
   p.M = (int)a->M; p.N = (int)a->N; p.K = (int)a->K; p.batch = a->batch;
   p.accumulate = a->accumulate;
   p.period = a->valid_rows_period; p.valid = a->valid_rows;
+  p.res_first = a->residual_first;
   return 0;
 }
 

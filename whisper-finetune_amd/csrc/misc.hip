@@ -57,7 +57,8 @@ extern "C" int wft_cast_bf16_f32(const wft_bf16* src, float* dst, int64_t n, voi
 
 // src f32 [rows, cols] -> dst bf16 [rows_pad, cols_pad], dst_t bf16 [cols_pad, rows_pad]; 64x64 tiles via LDS
 __global__ __launch_bounds__(256) void cast_pad_t_kernel(const float* src, long rows, long cols, unsigned short* dst,
-                                                          unsigned short* dst_t, long rows_pad, long cols_pad) {
+                                                          unsigned short* dst_t, long rows_pad, long cols_pad,
+                                                          long ld_dst, long ld_dst_t) {
   __shared__ unsigned short tile[64][66];
   const long r0 = (long)blockIdx.y * 64, c0 = (long)blockIdx.x * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -66,23 +67,25 @@ __global__ __launch_bounds__(256) void cast_pad_t_kernel(const float* src, long 
     unsigned short v = 0;
     if (r < rows && c < cols) v = f2bf(src[r * cols + c]);
     tile[rr][tx] = v;
-    if (r < rows_pad && c < cols_pad) dst[r * cols_pad + c] = v;
+    if (r < rows_pad && c < cols_pad) dst[r * ld_dst + c] = v;
   }
   if (dst_t) {
     __syncthreads();
     for (int cc = ty; cc < 64; cc += 4) {
       const long c = c0 + cc, r = r0 + tx;
-      if (c < cols_pad && r < rows_pad) dst_t[c * rows_pad + r] = tile[tx][cc];
+      if (c < cols_pad && r < rows_pad) dst_t[c * ld_dst_t + r] = tile[tx][cc];
     }
   }
 }
 extern "C" int wft_cast_pad_transpose_f32_bf16(const float* src, int64_t rows, int64_t cols, wft_bf16* dst,
-                                               wft_bf16* dst_t, int64_t rows_pad, int64_t cols_pad, void* stream) {
+                                               wft_bf16* dst_t, int64_t rows_pad, int64_t cols_pad, int64_t ld_dst,
+                                               int64_t ld_dst_t, void* stream) {
   WFT_CHECK_ARG(src && dst, "null pointer");
   WFT_CHECK_ARG(rows >= 1 && cols >= 1 && rows_pad >= rows && cols_pad >= cols, "bad shape");
+  WFT_CHECK_ARG(ld_dst >= cols_pad && (!dst_t || ld_dst_t >= rows_pad), "leading dimensions too small");
   dim3 grid((unsigned)((cols_pad + 63) / 64), (unsigned)((rows_pad + 63) / 64));
   hipLaunchKernelGGL(cast_pad_t_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, (long)rows, (long)cols, dst, dst_t,
-                     (long)rows_pad, (long)cols_pad);
+                     (long)rows_pad, (long)cols_pad, (long)ld_dst, (long)ld_dst_t);
   WFT_CHECK_LAUNCH();
   return WFT_OK;
 }
@@ -109,6 +112,35 @@ extern "C" int wft_add_bf16(const wft_bf16* a, const wft_bf16* b, wft_bf16* y, i
   WFT_CHECK_ARG((((uintptr_t)a) & 15) == 0 && (((uintptr_t)b) & 15) == 0 && (((uintptr_t)y) & 15) == 0, "16-byte alignment");
   if (n == 0) return WFT_OK;
   hipLaunchKernelGGL(add_bf16_kernel, dim3(ew_grid(n / 8 + 1)), dim3(256), 0, (hipStream_t)stream, a, b, y, (long)n);
+  WFT_CHECK_LAUNCH();
+  return WFT_OK;
+}
+
+
+// ----------------------------------------------------------------------------- dGELU
+// out = dy * gelu'(pre)   (conv stem backward; the Linear path fuses this in the GEMM epilogue)
+__global__ __launch_bounds__(256) void dgelu_mul_kernel(const unsigned short* dy, const unsigned short* pre,
+                                                         unsigned short* out, long n) {
+  const long nv = n >> 3;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+    const u32x4 a = *(const u32x4*)(dy + i * 8), b = *(const u32x4*)(pre + i * 8);
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      o[e] = pack2bf(bf2f((unsigned short)(a[e] & 0xffff)) * dgelu_f(bf2f((unsigned short)(b[e] & 0xffff))),
+                     bf2f((unsigned short)(a[e] >> 16)) * dgelu_f(bf2f((unsigned short)(b[e] >> 16))));
+    *(u32x4*)(out + i * 8) = o;
+  }
+  if (blockIdx.x == 0) {
+    const long t = (nv << 3) + threadIdx.x;
+    if (t < n) out[t] = f2bf(bf2f(dy[t]) * dgelu_f(bf2f(pre[t])));
+  }
+}
+extern "C" int wft_dgelu_mul_bf16(const wft_bf16* dy, const wft_bf16* pre, wft_bf16* out, int64_t n, void* stream) {
+  WFT_CHECK_ARG(dy && pre && out && n >= 0, "bad args");
+  WFT_CHECK_ARG((((uintptr_t)dy) & 15) == 0 && (((uintptr_t)pre) & 15) == 0 && (((uintptr_t)out) & 15) == 0, "16-byte alignment");
+  if (n == 0) return WFT_OK;
+  hipLaunchKernelGGL(dgelu_mul_kernel, dim3(ew_grid(n / 8 + 1)), dim3(256), 0, (hipStream_t)stream, dy, pre, out, (long)n);
   WFT_CHECK_LAUNCH();
   return WFT_OK;
 }

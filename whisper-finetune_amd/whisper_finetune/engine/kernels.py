@@ -57,8 +57,10 @@ def weight_shadow(w: torch.Tensor, rows_pad: int, cols_pad: int, want_t: bool, o
     dst_t = None
     if want_t:
         dst_t = out_t if out_t is not None else torch.empty((cols_pad, rows_pad), dtype=BF16, device=w.device)
+    assert dst.stride(1) == 1 and (dst_t is None or dst_t.stride(1) == 1)
     L.check(
-        L.load().wft_cast_pad_transpose_f32_bf16(_p(w2), rows, cols, _p(dst), _p(dst_t), rows_pad, cols_pad, L.stream_ptr()),
+        L.load().wft_cast_pad_transpose_f32_bf16(_p(w2), rows, cols, _p(dst), _p(dst_t), rows_pad, cols_pad,
+                                                 dst.stride(0), 0 if dst_t is None else dst_t.stride(0), L.stream_ptr()),
         "wft_cast_pad_transpose_f32_bf16",
     )
     return dst, dst_t
@@ -70,6 +72,14 @@ def add_bf16(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     y = torch.empty_like(a)
     L.check(L.load().wft_add_bf16(_p(a), _p(b), _p(y), a.numel(), L.stream_ptr()), "wft_add_bf16")
     return y
+
+
+def dgelu_mul(dy: torch.Tensor, pre: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(dy, BF16, "dy"); _chk(pre, BF16, "pre")
+    assert dy.is_contiguous() and pre.is_contiguous()
+    out = torch.empty_like(dy) if out is None else out
+    L.check(L.load().wft_dgelu_mul_bf16(_p(dy), _p(pre), _p(out), dy.numel(), L.stream_ptr()), "wft_dgelu_mul_bf16")
+    return out
 
 
 def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
@@ -130,7 +140,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, mask=None):
 def gemm_nt(a, b, *, M=None, N=None, K=None, lda=None, ldb=None, out=None, out_f32=False, accumulate=False,
             bias=None, residual=None, aux=None, epilogue=L.EPI_NONE, alpha=1.0, batch=1,
             strideA=0, strideB=0, strideC=0, strideR=0, strideAux=0, ldc=None,
-            valid_rows_period=0, valid_rows=0):
+            valid_rows_period=0, valid_rows=0, residual_first=False, ldaux=None, ldr=None):
     """C[M,N] = alpha * A[M,K] @ B[N,K]^T (+bias) (epilogue) (+residual).
 
     a: bf16, row m at a.data_ptr() + m*lda; b: bf16 [N, K] (ldb).  Defaults take the shapes
@@ -162,13 +172,14 @@ def gemm_nt(a, b, *, M=None, N=None, K=None, lda=None, ldb=None, out=None, out_f
     args.bias = 0 if bias is None else bias.data_ptr()
     if residual is not None:
         _chk(residual, BF16, "residual")
-        args.residual, args.ldr, args.strideR = residual.data_ptr(), residual.stride(-2), strideR
+        args.residual, args.ldr, args.strideR = residual.data_ptr(), (residual.stride(-2) if ldr is None else ldr), strideR
     if aux is not None:
         _chk(aux, BF16, "aux")
-        args.aux, args.ldaux, args.strideAux = aux.data_ptr(), aux.stride(-2), strideAux
+        args.aux, args.ldaux, args.strideAux = aux.data_ptr(), (aux.stride(-2) if ldaux is None else ldaux), strideAux
     args.epilogue, args.alpha = epilogue, alpha
     args.M, args.N, args.K, args.batch = M, N, K, batch
     args.valid_rows_period, args.valid_rows = valid_rows_period, valid_rows
+    args.residual_first = int(residual_first)
     L.check(L.load().wft_gemm_nt_bf16(C.byref(args), L.stream_ptr()), "wft_gemm_nt_bf16")
     return out
 

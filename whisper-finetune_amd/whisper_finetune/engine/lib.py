@@ -31,6 +31,7 @@ class GemmArgs(C.Structure):
         ("epilogue", C.c_int), ("alpha", C.c_float),
         ("M", c_i64), ("N", c_i64), ("K", c_i64), ("batch", C.c_int),
         ("valid_rows_period", C.c_int), ("valid_rows", C.c_int),
+        ("residual_first", C.c_int),
     ]
 
 
@@ -59,8 +60,9 @@ EPI_NONE, EPI_GELU, EPI_DGELU = 0, 1, 2
 SIGNATURES = {
     "wft_cast_f32_bf16": [c_vp, c_vp, c_i64, c_vp],
     "wft_cast_bf16_f32": [c_vp, c_vp, c_i64, c_vp],
-    "wft_cast_pad_transpose_f32_bf16": [c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_i64, c_vp],
+    "wft_cast_pad_transpose_f32_bf16": [c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp],
     "wft_add_bf16": [c_vp, c_vp, c_vp, c_i64, c_vp],
+    "wft_dgelu_mul_bf16": [c_vp, c_vp, c_vp, c_i64, c_vp],
     "wft_colsum_bf16": [c_vp, c_i64, c_i64, c_i64, c_vp, C.c_int, c_vp],
     "wft_layernorm_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_float,
                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp],

@@ -1,0 +1,517 @@
+"""torch.autograd.Function wrappers: every forward/backward below is a sequence of libwft
+kernel launches (kernels.py) — PyTorch only provides memory, streams and the autograd graph.
+
+Layout conventions: activations are bf16, contiguous, 2-D [rows, features] (rows = B*T);
+parameters stay fp32 (master weights, as the reference's AMP keeps them — SURVEY.md §7
+"Numerics contract") and are shadowed in bf16 by `LinearGroup`.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import kernels as K
+from . import lib as L
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+# bumped by optimizers that update parameters through raw pointers (torch's in-place ops bump
+# tensor._version themselves); part of every shadow-cache key.
+_SHADOW_EPOCH = [0]
+
+
+def bump_shadow_epoch():
+    _SHADOW_EPOCH[0] += 1
+
+
+def _ver(t: Optional[torch.Tensor]):
+    return None if t is None else (t.data_ptr(), t._version)
+
+
+class LoraSpec:
+    """Low-rank adapter of one Linear (minLoRA semantics):
+    W_eff = W + scaling * B @ (A * mask);  A [r, in], B [out, r], mask [1, in] (already drawn)."""
+
+    __slots__ = ("A", "B", "scaling", "mask")
+
+    def __init__(self, A, B, scaling: float, mask: Optional[torch.Tensor]):
+        self.A, self.B, self.scaling, self.mask = A, B, float(scaling), mask
+
+
+class LinearGroup:
+    """bf16 shadows for one or several Linear layers that share their input and are evaluated
+    as ONE GEMM (q/k/v -> N = 3*d).  Rebuilt only when a parameter changed."""
+
+    def __init__(self):
+        self.key = None
+        self.W = self.WT = self.bias = None
+        self.lkey = None
+        self.Am = self.AmT = self.Bb = self.BbT = None
+
+    @staticmethod
+    def dims(weights: Sequence[torch.Tensor]):
+        """(n, k, n_pad): out-features summed over the group, in-features, n rounded up to 128."""
+        n = sum(w.shape[0] for w in weights)
+        k = weights[0][0].numel()
+        if k % 128 != 0:
+            raise L.WftError(f"in_features={k} must be a multiple of 128 (pad the operand)")
+        return n, k, K.round_up(n, 128)
+
+    def shadows(self, weights, biases, need_t: bool):
+        want_t = need_t or self.WT is not None
+        key = (tuple(_ver(w) for w in weights), tuple(_ver(b) for b in biases), want_t, _SHADOW_EPOCH[0])
+        if key != self.key:
+            n, k, npad = self.dims(weights)
+            dev = weights[0].device
+            if self.W is None or self.W.shape != (npad, k):
+                self.W = torch.zeros((npad, k), dtype=BF16, device=dev)
+                self.WT = None
+            if want_t and self.WT is None:
+                self.WT = torch.zeros((k, npad), dtype=BF16, device=dev)
+            off = 0
+            for w in weights:
+                o = w.shape[0]
+                K.weight_shadow(w.detach(), o, k, want_t, out=self.W[off:off + o],
+                                out_t=self.WT[:, off:off + o] if want_t else None)
+                off += o
+            if any(b is not None for b in biases):
+                self.bias = torch.zeros(npad, dtype=F32, device=dev)
+                off = 0
+                for w, b in zip(weights, biases):
+                    if b is not None:
+                        self.bias[off:off + w.shape[0]].copy_(b.detach())
+                    off += w.shape[0]
+            else:
+                self.bias = None
+            self.key = key
+        return self.W, self.WT, self.bias
+
+    def lora_shadows(self, weights, loras: Sequence[Optional[LoraSpec]]):
+        """(A*mask) stacked [Rpad, Kpad] (+T) and block-diagonal scaling*B [Npad, Rpad] (+T)."""
+        key = tuple(None if s is None else (_ver(s.A), _ver(s.B), _ver(s.mask), s.scaling) for s in loras) + (_SHADOW_EPOCH[0],)
+        if key != self.lkey:
+            n, k, npad = self.dims(weights)
+            kpad = k
+            dev = weights[0].device
+            rtot = sum(s.A.shape[0] for s in loras if s is not None)
+            rpad = K.round_up(rtot, 128)
+            Am = torch.zeros((rpad, k), dtype=F32, device=dev)
+            Bb = torch.zeros((n, rpad), dtype=F32, device=dev)
+            ro = no = 0
+            for w, s in zip(weights, loras):
+                if s is not None:
+                    r = s.A.shape[0]
+                    a = s.A.detach() if s.mask is None else s.A.detach() * s.mask
+                    Am[ro:ro + r] = a
+                    Bb[no:no + w.shape[0], ro:ro + r] = s.B.detach() * s.scaling
+                    ro += r
+                no += w.shape[0]
+            self.Am, self.AmT = K.weight_shadow(Am, rpad, kpad, True)
+            self.Bb, self.BbT = K.weight_shadow(Bb, npad, rpad, True)
+            self.lkey = key
+        return self.Am, self.AmT, self.Bb, self.BbT
+
+
+class _LinearCfg:
+    __slots__ = ("group", "n_w", "has_bias", "loras", "gelu_out", "gelu_in", "out_features")
+
+    def __init__(self, group, n_w, has_bias, loras, gelu_out, gelu_in, out_features):
+        self.group, self.n_w, self.has_bias, self.loras = group, n_w, has_bias, loras
+        self.gelu_out, self.gelu_in, self.out_features = gelu_out, gelu_in, out_features
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x @ Wcat^T + bias (+ LoRA) (GELU) (+ residual) as libwft GEMMs.
+
+    inputs : x bf16 [M, K]; residual bf16 [M, N] or None; gelu_pre bf16 [M, K] or None
+             (if given, x == gelu(gelu_pre) and the backward returns d(gelu_pre): the GELU
+             derivative is fused into the backward-data GEMM epilogue);
+             cfg; then weights..., biases (only the non-None ones)..., lora A..., lora B...
+    outputs: y   (gelu_out=False)   |   (pre, act) with act non-differentiable (gelu_out=True)
+    """
+
+    @staticmethod
+    def forward(ctx, x, residual, gelu_pre, cfg: _LinearCfg, *params):
+        n_w = cfg.n_w
+        weights = list(params[:n_w])
+        nb = sum(cfg.has_bias)
+        bias_list = list(params[n_w:n_w + nb])
+        biases, bi = [], 0
+        for hb in cfg.has_bias:
+            biases.append(bias_list[bi] if hb else None)
+            bi += int(hb)
+        need_dx = ctx.needs_input_grad[0] or (gelu_pre is not None and ctx.needs_input_grad[2])
+        W, WT, bias = cfg.group.shadows(weights, biases, need_t=need_dx)
+        n, k, npad = LinearGroup.dims(weights)
+        kpad = k
+        assert x.dtype == BF16 and x.dim() == 2 and x.is_contiguous() and x.shape[1] == kpad, (x.shape, kpad)
+        M = x.shape[0]
+        has_lora = any(s is not None for s in cfg.loras)
+        u = None
+        out_pre = None
+        if not has_lora:
+            if cfg.gelu_out:
+                out_pre = torch.empty((M, npad), dtype=BF16, device=x.device)
+                y = K.gemm_nt(x, W, bias=bias, epilogue=L.EPI_GELU, aux=out_pre, residual=residual)
+            else:
+                y = K.gemm_nt(x, W, bias=bias, residual=residual)
+        else:
+            Am, AmT, Bb, BbT = cfg.group.lora_shadows(weights, cfg.loras)
+            u = K.gemm_nt(x, Am)  # [M, Rpad]
+            y0 = K.gemm_nt(x, W, bias=bias, residual=None if cfg.gelu_out else residual)
+            if cfg.gelu_out:
+                out_pre = torch.empty((M, npad), dtype=BF16, device=x.device)
+                y = K.gemm_nt(u, Bb, residual=y0, residual_first=True, epilogue=L.EPI_GELU, aux=out_pre)
+            else:
+                y = K.gemm_nt(u, Bb, residual=y0)
+        ctx.cfg = cfg
+        ctx.has_res = residual is not None
+        ctx.dims = (n, k, npad, kpad)
+        ctx.save_for_backward(x, gelu_pre, out_pre, u, *params)
+        if cfg.gelu_out:
+            ctx.mark_non_differentiable(y)
+            return out_pre, y
+        return y
+
+    @staticmethod
+    def backward(ctx, *grads):
+        cfg: _LinearCfg = ctx.cfg
+        x, gelu_pre, out_pre, u, *params = ctx.saved_tensors
+        n, k, npad, kpad = ctx.dims
+        n_w = cfg.n_w
+        weights = list(params[:n_w])
+        nb = sum(cfg.has_bias)
+        has_lora = any(s is not None for s in cfg.loras)
+        dy = grads[0]
+        if dy is None:
+            return (None,) * (4 + len(params))
+        if dy.dtype != BF16:
+            dy = dy.to(BF16)
+        dy = dy.contiguous()
+        W, WT, _ = cfg.group.shadows(weights, _bias_list(cfg, params), need_t=True)
+        # NB: with GELU-out the incoming grad is w.r.t. the pre-activation already (act is non-diff)
+        dx = dpre = None
+        need_dx = ctx.needs_input_grad[0] or (gelu_pre is not None and ctx.needs_input_grad[2])
+        du = None
+        if has_lora:
+            Am, AmT, Bb, BbT = cfg.group.lora_shadows(weights, cfg.loras)
+            du = K.gemm_nt(dy, BbT)  # [M, Rpad] = dy @ (s*B)
+        if need_dx:
+            if gelu_pre is not None:
+                if has_lora:
+                    d0 = K.gemm_nt(dy, WT)
+                    dpre = K.gemm_nt(du, AmT, residual=d0, residual_first=True, epilogue=L.EPI_DGELU, aux=gelu_pre)
+                else:
+                    dpre = K.gemm_nt(dy, WT, epilogue=L.EPI_DGELU, aux=gelu_pre)
+            else:
+                if has_lora:
+                    d0 = K.gemm_nt(dy, WT)
+                    dx = K.gemm_nt(du, AmT, residual=d0)
+                else:
+                    dx = K.gemm_nt(dy, WT)
+        out: List[Optional[torch.Tensor]] = [dx, dy if ctx.has_res else None, dpre, None]
+        # parameter grads: weights
+        w_need = [ctx.needs_input_grad[4 + i] for i in range(n_w)]
+        if any(w_need):
+            dW = K.gemm_tn(dy, x)  # f32 [Npad, Kpad]
+            off = 0
+            for i, w in enumerate(weights):
+                o = w.shape[0]
+                out.append(dW[off:off + o, :k].reshape(w.shape) if w_need[i] else None)
+                off += o
+        else:
+            out.extend([None] * n_w)
+        # biases
+        b_need = [ctx.needs_input_grad[4 + n_w + i] for i in range(nb)]
+        if any(b_need):
+            db = K.colsum(dy)
+            off = bi = 0
+            for w, hb in zip(weights, cfg.has_bias):
+                if hb:
+                    out.append(db[off:off + w.shape[0]] if b_need[bi] else None)
+                    bi += 1
+                off += w.shape[0]
+        else:
+            out.extend([None] * nb)
+        # LoRA A / B
+        n_l = sum(1 for s in cfg.loras if s is not None)
+        if has_lora:
+            base = 4 + n_w + nb
+            a_need = [ctx.needs_input_grad[base + i] for i in range(n_l)]
+            b2_need = [ctx.needs_input_grad[base + n_l + i] for i in range(n_l)]
+            dA_full = K.gemm_tn(du, x) if any(a_need) else None  # [Rpad, Kpad]
+            dB_full = K.gemm_tn(dy, u) if any(b2_need) else None  # [Npad, Rpad]
+            dAs, dBs = [], []
+            ro = no = li = 0
+            for w, s in zip(weights, cfg.loras):
+                if s is not None:
+                    r = s.A.shape[0]
+                    if a_need[li]:
+                        g = dA_full[ro:ro + r, :k]
+                        dAs.append(g * s.mask if s.mask is not None else g)
+                    else:
+                        dAs.append(None)
+                    dBs.append(dB_full[no:no + w.shape[0], ro:ro + r] * s.scaling if b2_need[li] else None)
+                    ro += r
+                    li += 1
+                no += w.shape[0]
+            out.extend(dAs)
+            out.extend(dBs)
+        return tuple(out)
+
+
+def _bias_list(cfg, params):
+    n_w = cfg.n_w
+    bl = list(params[n_w:n_w + sum(cfg.has_bias)])
+    res, bi = [], 0
+    for hb in cfg.has_bias:
+        res.append(bl[bi] if hb else None)
+        bi += int(hb)
+    return res
+
+
+def linear(x, group: LinearGroup, weights, biases, loras=None, residual=None, gelu_out=False, gelu_pre=None):
+    """Functional front door of LinearFn. x bf16 [M, K] contiguous."""
+    loras = list(loras) if loras is not None else [None] * len(weights)
+    cfg = _LinearCfg(group, len(weights), tuple(b is not None for b in biases), tuple(loras), gelu_out,
+                     gelu_pre is not None, sum(w.shape[0] for w in weights))
+    params = list(weights) + [b for b in biases if b is not None]
+    params += [s.A for s in loras if s is not None] + [s.B for s in loras if s is not None]
+    return LinearFn.apply(x, residual, gelu_pre, cfg, *params)
+
+
+# --------------------------------------------------------------------------- LayerNorm
+class LayerNormFn(torch.autograd.Function):
+    """whisper.model.LayerNorm (fp32 statistics, bf16 in/out) + optional deep-SpecAugment mask
+    (rows_per_batch, t0, t1, c0, c1) fused in the same pass (model/model_utils.py:409-417)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, mask):
+        shape = x.shape
+        y, mean, rstd = K.layernorm_fwd(x.reshape(-1, shape[-1]), gamma.detach(), beta.detach(), eps, mask)
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.mask = mask
+        return y.view(shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        shape = x.shape
+        dx, dg, db = K.layernorm_bwd(dy.reshape(-1, shape[-1]).to(BF16), x.reshape(-1, shape[-1]), gamma.detach(), mean,
+                                     rstd, None, ctx.mask)
+        return dx.view(shape), dg, db, None, None
+
+
+class LayerNormForkFn(torch.autograd.Function):
+    """(ln(x), x): the residual stream forks here; the backward fuses the add of the residual
+    gradient into the LayerNorm backward kernel (one pass instead of LN-bwd + add)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, mask):
+        shape = x.shape
+        y, mean, rstd = K.layernorm_fwd(x.reshape(-1, shape[-1]), gamma.detach(), beta.detach(), eps, mask)
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.mask = mask
+        return y.view(shape), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dres):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        shape = x.shape
+        if dy is None:
+            return dres, None, None, None, None
+        dr = None if dres is None else dres.reshape(-1, shape[-1]).to(BF16)
+        dx, dg, db = K.layernorm_bwd(dy.reshape(-1, shape[-1]).to(BF16), x.reshape(-1, shape[-1]), gamma.detach(), mean,
+                                     rstd, dr, ctx.mask)
+        return dx.view(shape), dg, db, None, None
+
+
+# --------------------------------------------------------------------------- attention
+class SelfAttnFn(torch.autograd.Function):
+    """qkv bf16 [B, T, 3*d] (fused projection output, consumed in place) -> o bf16 [B, T, d]."""
+
+    @staticmethod
+    def forward(ctx, qkv, n_head, causal):
+        d = qkv.shape[-1] // 3
+        q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+        scale = 64 ** -0.5
+        o, lse = K.attn_fwd(q, k, v, n_head, causal, scale)
+        ctx.save_for_backward(qkv, o, lse)
+        ctx.cfg = (n_head, causal, scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, o, lse = ctx.saved_tensors
+        n_head, causal, scale = ctx.cfg
+        d = qkv.shape[-1] // 3
+        dqkv = torch.empty_like(qkv)
+        K.attn_bwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], o, lse, do.to(BF16), n_head, causal, scale,
+                   dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:])
+        return dqkv, None, None
+
+
+class CrossAttnFn(torch.autograd.Function):
+    """q bf16 [B, S, d], kv bf16 [B, T, 2*d] -> o bf16 [B, S, d] (no mask)."""
+
+    @staticmethod
+    def forward(ctx, q, kv, n_head):
+        d = q.shape[-1]
+        scale = 64 ** -0.5
+        o, lse = K.attn_fwd(q, kv[..., :d], kv[..., d:], n_head, False, scale)
+        ctx.save_for_backward(q, kv, o, lse)
+        ctx.cfg = (n_head, scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, kv, o, lse = ctx.saved_tensors
+        n_head, scale = ctx.cfg
+        d = q.shape[-1]
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        K.attn_bwd(q, kv[..., :d], kv[..., d:], o, lse, do.to(BF16), n_head, False, scale, dq=dq, dk=dkv[..., :d], dv=dkv[..., d:])
+        return dq, dkv, None
+
+
+# --------------------------------------------------------------------------- conv stem
+class ConvStemFn(torch.autograd.Function):
+    """AudioEncoder stem (model/model_utils.py:276-281): gelu(conv1(mel)) -> gelu(conv2(.)) ->
+    permute -> + positional_embedding, as im2col-free GEMMs over a time-major, zero-haloed layout.
+
+    mel_t bf16 [B, T+2, c_pad] (wft_mel_to_tmajor_bf16); w1 f32 [d, n_mels, 3]; w2 f32 [d, d, 3];
+    pos f32 [T/2, d] (a buffer)  ->  x bf16 [B, T/2, d].
+    """
+
+    @staticmethod
+    def forward(ctx, mel_t, w1, b1, w2, b2, pos, cache):
+        B, Tp, c_pad = mel_t.shape
+        T = Tp - 2
+        d = w1.shape[0]
+        dev = mel_t.device
+        key = (_ver(w1), _ver(w2), _ver(pos), _SHADOW_EPOCH[0])
+        if cache.get("key") != key:
+            n_mels = w1.shape[1]
+            w1p = torch.zeros((d, 3, c_pad), dtype=F32, device=dev)
+            w1p[:, :, :n_mels] = w1.detach().permute(0, 2, 1)
+            cache["w1"] = K.cast_bf16(w1p.reshape(d, 3 * c_pad))
+            w2k = w2.detach().permute(0, 2, 1).contiguous()  # [co, kk, ci]
+            cache["w2"] = K.cast_bf16(w2k.reshape(d, 3 * d))
+            # backward-data shadows: odd rows use W2[:,:,1]^T, even rows [W2[:,:,2]^T | W2[:,:,0]^T]
+            cache["w2_odd"] = K.cast_bf16(w2.detach()[:, :, 1].t().contiguous())  # [ci, co]
+            cache["w2_even"] = K.cast_bf16(torch.cat([w2.detach()[:, :, 2].t(), w2.detach()[:, :, 0].t()], dim=1).contiguous())  # [ci, 2*co]
+            cache["pos"] = K.cast_bf16(pos.detach().contiguous())
+            cache["key"] = key
+        T2 = T // 2
+        pre1 = torch.empty((B, Tp, d), dtype=BF16, device=dev)
+        act1 = torch.empty((B, Tp, d), dtype=BF16, device=dev)
+        act1[:, 0].zero_(); act1[:, T + 1].zero_()
+        K.gemm_nt(mel_t, cache["w1"], M=T, N=d, K=3 * c_pad, lda=c_pad, ldb=3 * c_pad, out=act1[:, 1:], ldc=d,
+                  bias=b1.detach(), epilogue=L.EPI_GELU, aux=pre1[:, 1:], batch=B, strideA=Tp * c_pad, strideC=Tp * d,
+                  strideAux=Tp * d)
+        pre2 = torch.empty((B, T2, d), dtype=BF16, device=dev)
+        x = torch.empty((B, T2, d), dtype=BF16, device=dev)
+        K.gemm_nt(act1, cache["w2"], M=T2, N=d, K=3 * d, lda=2 * d, ldb=3 * d, out=x, ldc=d, bias=b2.detach(),
+                  epilogue=L.EPI_GELU, aux=pre2, residual=cache["pos"], batch=B, strideA=Tp * d, strideC=T2 * d,
+                  strideAux=T2 * d, strideR=0)
+        ctx.save_for_backward(mel_t, pre1, act1, pre2)
+        ctx.cache = cache
+        ctx.shapes = (B, T, c_pad, d, w1.shape[1])
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        mel_t, pre1, act1, pre2 = ctx.saved_tensors
+        cache = ctx.cache
+        B, T, c_pad, d, n_mels = ctx.shapes
+        Tp, T2 = T + 2, T // 2
+        dev = dx.device
+        dx = dx.to(BF16).contiguous()
+        # through gelu of conv2 (positional embedding is a buffer: no grad)
+        dpre2 = torch.zeros((B, T2 + 2, d), dtype=BF16, device=dev)  # zero halo rows 0 and T2+1
+        tmp = K.dgelu_mul(dx.view(-1), pre2.view(-1)).view(B, T2, d)
+        dpre2[:, 1:T2 + 1] = tmp
+        db2 = K.colsum(tmp.view(B * T2, d))
+        # dW2[co, kk*d + ci] = sum_{b,t'} dpre2[b,t',co] * act1pad[b, 2t'+kk, ci]
+        dW2 = K.gemm_tn(dpre2[:, 1:], act1, R=T2, P=d, Q=3 * d, lda=d, ldb=2 * d, batch=B,
+                        strideA=(T2 + 2) * d, strideB=Tp * d)
+        dW2 = dW2.view(d, 3, d).permute(0, 2, 1)  # -> [co, ci, kk]
+        # backward-data into the padded conv1 activation, fused with gelu'(pre1)
+        dpre1 = torch.zeros((B, Tp, d), dtype=BF16, device=dev)
+        # odd padded rows tau = 2j+1 (j = 0..T2-1): dpre2[j] @ W2[:,:,1]
+        K.gemm_nt(dpre2[:, 1:], cache["w2_odd"], M=T2, N=d, K=d, lda=d, ldb=d, out=dpre1[:, 1:], ldc=2 * d,
+                  epilogue=L.EPI_DGELU, aux=pre1[:, 1:], ldaux=2 * d, batch=B, strideA=(T2 + 2) * d, strideC=Tp * d,
+                  strideAux=Tp * d)
+        # even padded rows tau = 2j (j = 1..T2): [dpre2[j-1], dpre2[j]] @ [W2[:,:,2]; W2[:,:,0]]
+        aux_even = pre1[:, 2:]
+        K.gemm_nt(dpre2[:, 1:], cache["w2_even"], M=T2, N=d, K=2 * d, lda=d, ldb=2 * d, out=dpre1[:, 2:], ldc=2 * d,
+                  epilogue=L.EPI_DGELU, aux=aux_even, ldaux=2 * d, batch=B, strideA=(T2 + 2) * d, strideC=Tp * d,
+                  strideAux=Tp * d)
+        db1 = K.colsum(dpre1.view(B * Tp, d))
+        dW1 = K.gemm_tn(dpre1[:, 1:], mel_t, R=T, P=d, Q=3 * c_pad, lda=d, ldb=c_pad, batch=B, strideA=Tp * d,
+                        strideB=Tp * c_pad)
+        dW1 = dW1.view(d, 3, c_pad)[:, :, :n_mels].permute(0, 2, 1)
+        return None, dW1, db1, dW2, db2, None, None
+
+
+# --------------------------------------------------------------------------- embedding / logits / loss
+class EmbedFn(torch.autograd.Function):
+    """token_embedding(tokens) + positional_embedding[:S] -> bf16 (model/model_utils.py:317-318)."""
+
+    @staticmethod
+    def forward(ctx, tokens, emb, pos):
+        out = K.embed_fwd(tokens, emb.detach(), pos.detach())
+        ctx.save_for_backward(tokens)
+        ctx.shapes = (emb.shape, pos.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (tokens,) = ctx.saved_tensors
+        es, ps = ctx.shapes
+        demb = torch.zeros(es, dtype=F32, device=dout.device)
+        dpos = torch.zeros(ps, dtype=F32, device=dout.device)
+        K.embed_bwd(tokens, dout.to(BF16), demb, dpos)
+        return None, demb, dpos
+
+
+class TiedLogitsFn(torch.autograd.Function):
+    """logits = x @ E^T (tied output projection, model/model_utils.py:325), bf16 [M, Vpad]."""
+
+    @staticmethod
+    def forward(ctx, x, emb, group: LinearGroup):
+        W, WT, _ = group.shadows([emb], [None], need_t=True)
+        logits = K.gemm_nt(x, W)
+        ctx.save_for_backward(x, emb)
+        ctx.group = group
+        return logits
+
+    @staticmethod
+    def backward(ctx, dl):
+        x, emb = ctx.saved_tensors
+        W, WT, _ = ctx.group.shadows([emb], [None], need_t=True)
+        dl = dl.to(BF16).contiguous()
+        dx = K.gemm_nt(dl, WT) if ctx.needs_input_grad[0] else None
+        dE = K.gemm_tn(dl, x)[: emb.shape[0], : emb.shape[1]] if ctx.needs_input_grad[1] else None
+        return dx, dE, None
+
+
+class FusedCEFn(torch.autograd.Function):
+    """mean label-smoothed CE over non-ignored targets from padded bf16 logits; the backward
+    overwrites the logits buffer with dlogits (no second [M, V] tensor)."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, V, eps):
+        row_loss, row_lse, stats, _ = K.ce_fwd(logits, targets, V, eps)
+        ctx.save_for_backward(logits, targets, row_lse, stats)
+        ctx.cfg = (V, eps)
+        return stats[0] / stats[1]
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, targets, row_lse, stats = ctx.saved_tensors
+        V, eps = ctx.cfg
+        dl = K.ce_bwd(logits, targets, V, eps, row_lse, stats, g, inplace=True)
+        return dl, None, None, None

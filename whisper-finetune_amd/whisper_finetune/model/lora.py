@@ -1,0 +1,216 @@
+"""LoRA for the MI355X build: same entry points as the reference's `model/lora.py`
+(apply_lora :30-71, disable_all_but_parametrized_grads :14-27, remove_lora/merge_lora :74-89,
+print_lora_info, is_lora_enabled, get_lora_debug_stats, LoRAUpdateTracker,
+log_lora_debug_info), same parameter / state-dict names as minLoRA's weight parametrization
+(`<linear>.parametrizations.weight.original`, `.0.lora_A`, `.0.lora_B`,
+`.0.lora_dropout_mask` — SURVEY.md App. A.3) — but evaluated NATIVELY in low-rank form:
+
+    y = x W^T + b + (alpha/r) * ((x * m) A^T) B^T        (never materialising W + s*B@A)
+
+by engine/ops.LinearFn, so a frozen base Linear costs two rank-r GEMMs in the backward
+instead of the full d_out x d_in weight-gradient GEMM the parametrization form pays
+(SURVEY.md finding 7).  `layer.weight` still returns the effective weight for code that
+reads it (merge / save / debugging).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+from torch import nn
+
+from whisper_finetune.engine import ops
+from whisper_finetune.engine.whisper_model import Linear as WLinear
+
+
+class LoRAParametrization(nn.Module):
+    """minLoRA's LoRAParametrization.from_linear: A = kaiming_uniform_(a=sqrt(5)) [r, in], B = zeros
+    [out, r], scaling = alpha / rank, dropout applied to a [1, in] ones mask (so it drops whole
+    input COLUMNS of A, shared by every token of the batch)."""
+
+    def __init__(self, fan_in: int, fan_out: int, rank: int = 4, lora_dropout_p: float = 0.0, lora_alpha: float = 1.0,
+                 device=None):
+        super().__init__()
+        self.lora_A = nn.Parameter(torch.zeros(rank, fan_in, device=device))
+        self.lora_B = nn.Parameter(torch.zeros(fan_out, rank, device=device))
+        nn.init.kaiming_uniform_(self.lora_A, a=math.sqrt(5))
+        self.lora_alpha, self.rank = lora_alpha, rank
+        self.scaling = lora_alpha / rank
+        self.lora_dropout_p = float(lora_dropout_p)
+        self.register_buffer("lora_dropout_mask", torch.ones(1, fan_in, dtype=self.lora_A.dtype, device=device))
+        self.enabled = True
+
+    def draw_mask(self, training: bool) -> Optional[torch.Tensor]:
+        if self.lora_dropout_p > 0.0 and training:
+            return torch.nn.functional.dropout(self.lora_dropout_mask, self.lora_dropout_p, True)
+        return None
+
+    def spec(self, training: bool) -> Optional[ops.LoraSpec]:
+        if not self.enabled:
+            return None
+        return ops.LoraSpec(self.lora_A, self.lora_B, self.scaling, self.draw_mask(training))
+
+    def forward(self, W: torch.Tensor) -> torch.Tensor:
+        """Effective weight (off the hot path: merge / inspection)."""
+        if not self.enabled:
+            return W
+        m = self.draw_mask(self.training)
+        A = self.lora_A if m is None else self.lora_A * m
+        return W + (self.lora_B @ A).view(W.shape) * self.scaling
+
+
+class ParametrizationList(nn.ModuleList):
+    """Holds `original` (the base weight) and the adapter at index 0 — the key layout
+    torch.nn.utils.parametrize produces and the reference's checkpoints carry."""
+
+    def __init__(self, original: nn.Parameter, adapter: LoRAParametrization):
+        super().__init__([adapter])
+        self.original = original
+
+
+def _effective_weight(self):
+    plist = self.parametrizations.weight
+    return plist[0](plist.original)
+
+
+def add_lora_to_linear(layer: WLinear, rank: int, lora_alpha: float, lora_dropout_p: float) -> None:
+    if "parametrizations" in layer._modules:
+        return
+    W = layer._parameters.pop("weight")
+    adapter = LoRAParametrization(W.shape[1], W.shape[0], rank=rank, lora_dropout_p=lora_dropout_p,
+                                  lora_alpha=lora_alpha, device=W.device)
+    layer.parametrizations = nn.ModuleDict({"weight": ParametrizationList(W, adapter)})
+    cls = layer.__class__
+    layer.__class__ = type(f"Parametrized{cls.__name__}", (cls,), {"weight": property(_effective_weight), "_wft_base_cls": cls})
+
+
+def disable_all_but_parametrized_grads(model: nn.Module) -> None:
+    """Freeze every parameter whose name does not contain "lora" (model/lora.py:14-27)."""
+    for name, p in model.named_parameters():
+        if "lora" not in name.lower():
+            p.requires_grad = False
+
+
+def apply_lora(model: nn.Module, lora_config: dict, train_only_decoder: bool = False, train_only_encoder: bool = False) -> None:
+    """Attach adapters to every whisper Linear (q, k, v, out, mlp.0, mlp.2 — not conv / embedding) of the
+    model, or of the decoder / encoder only, then freeze the rest (model/lora.py:30-71).
+    lora_config keys: rank, lora_alpha, lora_dropout."""
+    cfg = dict(lora_config)
+    p_drop = cfg.pop("lora_dropout", cfg.pop("lora_dropout_p", 0.0))
+    rank = int(cfg.pop("rank", 4))
+    alpha = cfg.pop("lora_alpha", 1)
+    root = model.decoder if train_only_decoder else model.encoder if train_only_encoder else model
+    for m in root.modules():
+        if isinstance(m, WLinear):
+            add_lora_to_linear(m, rank, alpha, p_drop)
+    disable_all_but_parametrized_grads(model)
+
+
+def _strip(layer: nn.Module, merge: bool) -> None:
+    if "parametrizations" not in layer._modules:
+        return
+    plist = layer.parametrizations.weight
+    with torch.no_grad():
+        W = plist[0].eval()(plist.original) if merge else plist.original
+        new = nn.Parameter(W.detach().clone(), requires_grad=plist.original.requires_grad)
+    del layer._modules["parametrizations"]
+    layer.__class__ = layer.__class__._wft_base_cls
+    layer._parameters["weight"] = new
+    layer.__dict__.pop("_wft_group", None)
+
+
+def remove_lora(model: nn.Module) -> None:
+    """Drop the adapters and restore the original base weights (model/lora.py:74-80)."""
+    model.apply(lambda m: _strip(m, merge=False))
+
+
+def merge_lora(model: nn.Module) -> None:
+    """Fold W + s*B@A into the base weights (model/lora.py:83-89)."""
+    model.apply(lambda m: _strip(m, merge=True))
+
+
+def print_lora_info(model: nn.Module) -> None:
+    total = sum(p.numel() for p in model.parameters())
+    train = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    print(f"LoRA trainable parameters: {train:,}")
+    print(f"Total parameters: {total:,}")
+    print(f"Trainable %: {100 * train / total:.4f}%")
+
+
+def is_lora_enabled(model: nn.Module) -> bool:
+    return any("lora" in n.lower() for n, _ in model.named_parameters())
+
+
+_REP = "decoder.blocks.0.cross_attn.query.parametrizations.weight"
+
+
+def _representative(model: nn.Module, pattern: str):
+    """First lora_A / lora_B pair, preferring names that contain `pattern` (model/lora.py:127,194)."""
+    a = b = None
+    named = list(model.named_parameters())
+    for pool in ([x for x in named if pattern in x[0]], named):
+        for n, p in pool:
+            if a is None and "lora_A" in n:
+                a = (n, p)
+            if b is None and "lora_B" in n:
+                b = (n, p)
+        if a is not None and b is not None:
+            break
+    return a, b
+
+
+def get_lora_debug_stats(model: nn.Module, representative_module_pattern: str = _REP) -> dict:
+    stats = dict.fromkeys(["lora_A_norm", "lora_B_norm", "lora_A_grad_norm", "lora_B_grad_norm",
+                           "lora_A_grad_abs_max", "lora_B_grad_abs_max", "param_name"])
+    a, b = _representative(model, representative_module_pattern)
+    for tag, item in (("A", a), ("B", b)):
+        if item is None:
+            continue
+        n, p = item
+        if tag == "A":
+            stats["param_name"] = n.replace(".lora_A", "")
+        stats[f"lora_{tag}_norm"] = p.detach().float().norm().item()
+        if p.grad is not None:
+            g = p.grad.detach().float()
+            stats[f"lora_{tag}_grad_norm"] = g.norm().item()
+            stats[f"lora_{tag}_grad_abs_max"] = g.abs().max().item()
+    return stats
+
+
+class LoRAUpdateTracker:
+    """||dA||, ||dB|| of one representative adapter across optimizer steps (model/lora.py:180-252)."""
+
+    def __init__(self, model: nn.Module, representative_module_pattern: str = _REP):
+        self.model = model
+        a, b = _representative(model, representative_module_pattern)
+        self.A_name, self._A = a if a else (None, None)
+        self.B_name, self._B = b if b else (None, None)
+        self.prev_A = self.prev_B = None
+
+    def snapshot(self):
+        if self._A is not None:
+            self.prev_A = self._A.detach().clone().float()
+        if self._B is not None:
+            self.prev_B = self._B.detach().clone().float()
+
+    def get_update_norms(self) -> dict:
+        out = {"lora_A_update_norm": None, "lora_B_update_norm": None}
+        if self.prev_A is not None:
+            out["lora_A_update_norm"] = (self._A.detach().float() - self.prev_A).norm().item()
+        if self.prev_B is not None:
+            out["lora_B_update_norm"] = (self._B.detach().float() - self.prev_B).norm().item()
+        return out
+
+
+def log_lora_debug_info(model: nn.Module, step: int, tracker: Optional[LoRAUpdateTracker] = None, log_to_wandb: bool = True) -> dict:
+    """Collect the adapter norms / grad norms / last update norms and log them on rank 0
+    (called from train_step at eval steps, model/model_utils.py:95-105)."""
+    import whisper_finetune.runtime as rt
+
+    stats = get_lora_debug_stats(model)
+    if tracker is not None:
+        stats.update(tracker.get_update_norms())
+    if log_to_wandb:
+        rt.log({f"lora_debug/{k}": v for k, v in stats.items() if isinstance(v, (int, float))}, step=step)
+    return stats

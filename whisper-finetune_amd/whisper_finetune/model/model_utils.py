@@ -1,0 +1,258 @@
+"""Train step and model wrappers — same names and semantics as the reference's
+`model/model_utils.py` (train_step :23-127, save_model :130-135, resize_whisper_layers :138-206,
+infinite_iter :209-217, StochasticDepthMixin :220-250, CheckpointedStochastic{AudioEncoder,
+TextDecoder} :253-327, register_deep_spec_augment_hooks :382-437), driving the libwft engine.
+
+What is different, and why it is still a drop-in:
+  * train_step uses `model.forward_loss(...)` (logits GEMM + label-smoothed CE fused, bf16 logits
+    never up-cast / re-read 4x) when the un-wrapped model offers it; any other nn.Module takes the
+    reference's `model(x, y_in)` + F.cross_entropy route unchanged;
+  * autocast is entered for the device the model lives on (the reference hard-codes "cuda");
+  * deep-SpecAugment draws its mask spans on the host in torchaudio's order and hands them to the
+    LayerNorm kernel instead of running permute + 2 masked_fill + permute per block.
+"""
+from __future__ import annotations
+
+import copy
+from dataclasses import asdict
+from functools import partial
+from typing import Callable, Iterator, Optional
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+from torch.utils.checkpoint import checkpoint
+
+import whisper_finetune.runtime as rt
+from whisper_finetune.engine.whisper_model import AudioEncoder, TextDecoder, Whisper
+
+_ILLEGAL = "CUDA error: an illegal memory"
+
+
+def _micro_batch_loss(model, x, y_in, y_out, label_smoothing: float) -> Tensor:
+    if hasattr(rt.unwrap_model(model), "forward_loss"):
+        # engine model (possibly inside a DDP wrapper): fused logits + CE, same value as the two-step form
+        return model(x, y_in, targets=y_out, label_smoothing=label_smoothing)
+    logits = model(x, y_in)
+    return F.cross_entropy(logits.transpose(1, 2), y_out, label_smoothing=label_smoothing)
+
+
+def train_step(
+    model,
+    train_iter: Iterator,
+    optimizer: torch.optim.Optimizer,
+    lr_scheduler,
+    t_config: dict,
+    lora_tracker=None,
+    step: int = None,
+    scaler: Optional[torch.amp.GradScaler] = None,
+) -> float:
+    """One optimizer step = `accum_grad_steps` micro-batches.  Returns the sum over micro-batches of
+    (mean CE / accum) on this rank (not all-reduced), exactly as the reference."""
+    model.train()
+    mixed = t_config["mixed_precision_training"]
+    accum = t_config["accum_grad_steps"]
+    max_grad_norm = t_config["max_grad_norm"]
+    fp16 = mixed and t_config["mp_dtype"] == "fp16"
+    amp_dtype = torch.float16 if t_config["mp_dtype"] == "fp16" else torch.bfloat16
+    label_smoothing = t_config.get("label_smoothing", 0.0)
+    is_lora_run = t_config.get("is_lora_run", False)
+    if fp16 and scaler is None:
+        raise ValueError("fp16 mixed precision training requires a persistent GradScaler.")
+    if not fp16:
+        scaler = None
+
+    device = next(model.parameters()).device
+    total_loss = 0.0
+    for micro in range(accum):
+        last = micro == accum - 1
+        for attempt in range(3):
+            try:
+                x, y_in, y_out = next(train_iter)
+                x = x.to(device, non_blocking=True)
+                y_in = y_in.to(device, non_blocking=True)
+                y_out = y_out.to(device, non_blocking=True)
+                with rt.maybe_no_sync(model, enabled=rt.IS_DISTRIBUTED and not last):
+                    with torch.autocast(device_type=device.type, enabled=mixed, dtype=amp_dtype):
+                        loss = _micro_batch_loss(model, x, y_in, y_out, label_smoothing) / accum
+                    (scaler.scale(loss) if scaler else loss).backward()
+                total_loss += loss.item()
+                break
+            except RuntimeError as err:
+                # the reference retries sporadic illegal-memory-access errors 3x on one GPU and
+                # aborts immediately under DDP (a retry would desynchronise the ranks)
+                if _ILLEGAL not in str(err):
+                    raise
+                if rt.IS_DISTRIBUTED:
+                    print("Caught illegal memory access under DDP; aborting instead of retrying.")
+                    raise
+                print(f"Caught illegal memory access, retry {attempt + 1}")
+                if attempt == 2:
+                    print("Max retries reached. Something is wrong.")
+                    raise
+
+    if scaler:
+        scaler.unscale_(optimizer)
+
+    val_steps, train_steps = t_config.get("val_steps"), t_config.get("train_steps")
+    if is_lora_run and step is not None and val_steps is not None and (step % val_steps == 0 or step == train_steps):
+        from whisper_finetune.model.lora import log_lora_debug_info
+
+        log_lora_debug_info(rt.unwrap_model(model), step=step, tracker=lora_tracker, log_to_wandb=rt.IS_MAIN)
+
+    torch.nn.utils.clip_grad_norm_(model.parameters(), max_grad_norm)
+
+    if is_lora_run and lora_tracker is not None:
+        lora_tracker.snapshot()
+
+    if scaler:
+        before = scaler.get_scale()
+        scaler.step(optimizer)
+        scaler.update()
+        if scaler.get_scale() >= before:  # the step was not skipped for overflow
+            lr_scheduler.step()
+    else:
+        optimizer.step()
+        lr_scheduler.step()
+    optimizer.zero_grad(set_to_none=True)
+    return total_loss
+
+
+def save_model(model, save_path: str) -> None:
+    """fp16 state dict + dims, loadable by `whisper.load_model` (model/model_utils.py:130-135)."""
+    m = copy.deepcopy(rt.unwrap_model(model)).half()
+    torch.save({"model_state_dict": m.state_dict(), "dims": asdict(m.dims)}, save_path)
+
+
+def _resample_block_list(blocks: torch.nn.ModuleList, target_layers: int) -> torch.nn.ModuleList:
+    """Keep / drop / duplicate blocks proportionally so that exactly target_layers remain: block i is
+    repeated floor((i+1)*t/n) - floor(i*t/n) times (model/model_utils.py:138-168)."""
+    if target_layers < 1:
+        raise ValueError(f"target_layers must be >= 1, got {target_layers}")
+    n = len(blocks)
+    if n < 1:
+        raise ValueError("Cannot resize an empty block list")
+    if target_layers == n:
+        return blocks
+    out = []
+    for i, blk in enumerate(blocks):
+        reps = (i + 1) * target_layers // n - i * target_layers // n
+        out.extend([blk] + [copy.deepcopy(blk) for _ in range(reps - 1)] if reps > 0 else [])
+    if len(out) != target_layers:
+        raise RuntimeError(f"Layer resizing produced {len(out)} blocks, expected {target_layers}.")
+    return torch.nn.ModuleList(out)
+
+
+def resize_whisper_layers(model, target_encoder_layers: Optional[int] = None, target_decoder_layers: Optional[int] = None) -> bool:
+    changed = False
+    if target_encoder_layers is not None and target_encoder_layers != len(model.encoder.blocks):
+        old = len(model.encoder.blocks)
+        model.encoder.blocks = _resample_block_list(model.encoder.blocks, target_encoder_layers)
+        model.dims.n_audio_layer = target_encoder_layers
+        print(f"Resized encoder layers: {old} -> {target_encoder_layers}")
+        changed = True
+    if target_decoder_layers is not None and target_decoder_layers != len(model.decoder.blocks):
+        old = len(model.decoder.blocks)
+        model.decoder.blocks = _resample_block_list(model.decoder.blocks, target_decoder_layers)
+        model.dims.n_text_layer = target_decoder_layers
+        heads = torch.zeros(target_decoder_layers, model.dims.n_text_head, dtype=torch.bool)
+        heads[target_decoder_layers // 2:] = True
+        model.register_buffer("alignment_heads", heads.to_sparse(), persistent=False)
+        print(f"Resized decoder layers: {old} -> {target_decoder_layers}")
+        changed = True
+    return changed
+
+
+def infinite_iter(data_loader) -> Iterator:
+    """Cycle a DataLoader forever, calling sampler.set_epoch(0, 1, 2, ...) (DistributedSampler reshuffle)."""
+    epoch = 0
+    while True:
+        sampler = getattr(data_loader, "sampler", None)
+        if hasattr(sampler, "set_epoch"):
+            sampler.set_epoch(epoch)
+        yield from data_loader
+        epoch += 1
+
+
+class StochasticDepthMixin:
+    """Stochastic depth with per-block gradient checkpointing (https://arxiv.org/abs/1603.09382)."""
+
+    def stochastic_depth(self, x: Tensor, layer: Callable[[Tensor], Tensor], p: float) -> Tensor:
+        # the skip decision is a HOST draw from the default CPU generator (RNG parity with the reference)
+        if self.training and p > 0.0 and torch.rand(1).item() < p:
+            return x
+        out = checkpoint(layer, x, use_reentrant=False)
+        if self.training and p > 0.0:
+            keep = 1.0 - p
+            if keep <= 0.0:
+                return x
+            return x + (out - x) / keep  # block(x) already contains the skip connection
+        return out
+
+
+class CheckpointedStochasticAudioEncoder(StochasticDepthMixin, AudioEncoder):
+    def __init__(self, n_mels: int, n_ctx: int, n_state: int, n_head: int, n_layer: int, stochastic_depth_prob: float):
+        super().__init__(n_mels, n_ctx, n_state, n_head, n_layer)
+        self.stochastic_depth_prob = stochastic_depth_prob
+
+    def forward(self, x: Tensor):
+        x = self.stem(x)  # gelu(conv1) -> gelu(conv2) -> permute -> + positional_embedding
+        for block in self.blocks:
+            x = self.stochastic_depth(x, partial(block), self.stochastic_depth_prob)
+        return self.ln_post(x)
+
+
+class CheckpointedStochasticTextDecoder(StochasticDepthMixin, TextDecoder):
+    def __init__(self, n_vocab: int, n_ctx: int, n_state: int, n_head: int, n_layer: int, stochastic_depth_prob: float):
+        super().__init__(n_vocab, n_ctx, n_state, n_head, n_layer)
+        self.stochastic_depth_prob = stochastic_depth_prob
+
+    def hidden(self, x: Tensor, xa: Tensor, kv_cache: Optional[dict] = None) -> Tensor:
+        x = self.embed(x)
+        for block in self.blocks:
+            x = self.stochastic_depth(x, partial(block, xa=xa, mask=self.mask, kv_cache=kv_cache), self.stochastic_depth_prob)
+        return self.ln(x)
+
+
+def register_deep_spec_augment_hooks(model, time_mask_param: int, freq_mask_param: int, p: float = 1.0,
+                                     layer_indices: Optional[list] = None) -> None:
+    """SpecAugment on the normalised features after `attn_ln` of encoder blocks (all but the last by
+    default): one time span <= time_mask_param and one channel span <= freq_mask_param are zeroed for
+    the whole batch; on/off is decided once per encoder forward with probability p."""
+    p = float(p)
+    if not 0.0 <= p <= 1.0:
+        raise ValueError(f"deep_spec_augment p must be between 0 and 1, got {p}")
+    n_blocks = len(model.encoder.blocks)
+    state = {"apply": False}
+
+    def decide(module, inputs):
+        # kept until the next encoder forward so a checkpoint recompute sees the same on/off state
+        state["apply"] = True if p >= 1.0 else False if p <= 0.0 else torch.rand(1).item() < p
+
+    def span(param: int, size: int):
+        # torchaudio mask_along_axis draw order: value, then min_value (both torch.rand(1), CPU generator)
+        value = torch.rand(1) * param
+        lo = torch.rand(1) * (size - value)
+        start = int(lo.long())
+        return start, start + int(value.long())
+
+    def make_drawer(ln):
+        def draw():
+            if not state["apply"]:
+                return None
+            n_ctx, n_state = model.encoder.positional_embedding.shape
+            t0, t1 = span(time_mask_param, n_ctx)    # time mask first ...
+            c0, c1 = span(freq_mask_param, n_state)  # ... then the "frequency" (= channel) mask
+            return t0, t1, c0, c1
+        return draw
+
+    if layer_indices is None:
+        layer_indices = range(n_blocks - 1)
+    for idx in layer_indices:
+        if idx >= n_blocks:
+            raise ValueError(f"Layer index {idx} out of range")
+        if idx == n_blocks - 1:
+            continue  # never augment the last block: let the model recover
+        ln = model.encoder.blocks[idx].attn_ln
+        ln.deep_spec_augment = make_drawer(ln)
+    model.encoder.register_forward_pre_hook(decide)

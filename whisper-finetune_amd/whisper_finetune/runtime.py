@@ -1,0 +1,133 @@
+"""Process/rank runtime for the MI355X build — same public surface as the reference's
+`whisper_finetune.runtime` (runtime.py:10-119): module globals RANK / LOCAL_RANK /
+WORLD_SIZE / IS_DISTRIBUTED / IS_MAIN, setup_distributed(), barrier(), maybe_no_sync(),
+unwrap_model(), print_once(), cleanup() and the rank-0 wandb shims.
+
+One process per GPU (torchrun); backend "nccl" is RCCL on ROCm and runs over xGMI inside a
+node.  Differences from the reference, all additive: WFT_DIST_BACKEND=gloo selects the gloo
+backend so the multi-process plumbing can be exercised on CPU (tests), and wandb is
+imported lazily and only when enabled.
+"""
+from __future__ import annotations
+
+import contextlib
+import datetime
+import os
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+RANK = 0
+LOCAL_RANK = 0
+WORLD_SIZE = 1
+IS_DISTRIBUTED = False
+IS_MAIN = True
+
+_wandb = None
+_NCCL_TIMEOUT = datetime.timedelta(hours=2)  # rank 0 evaluates while the others wait (runtime.py:29)
+
+
+def _env_int(name: str, default: int) -> int:
+    return int(os.environ.get(name, default))
+
+
+def setup_distributed() -> torch.device:
+    """Initialise the process group from torchrun's env (RANK / LOCAL_RANK / WORLD_SIZE) and pin
+    this process to its GPU.  Returns the device this rank trains on."""
+    global RANK, LOCAL_RANK, WORLD_SIZE, IS_DISTRIBUTED, IS_MAIN
+    backend = os.environ.get("WFT_DIST_BACKEND", "nccl")
+    world = _env_int("WORLD_SIZE", 1)
+    IS_DISTRIBUTED = world > 1 and "RANK" in os.environ
+    have_gpu = torch.cuda.is_available()
+    if backend == "nccl" and not have_gpu:
+        raise RuntimeError("This training script requires a ROCm GPU (set WFT_DIST_BACKEND=gloo only for CPU plumbing tests).")
+    if IS_DISTRIBUTED:
+        RANK, LOCAL_RANK, WORLD_SIZE = _env_int("RANK", 0), _env_int("LOCAL_RANK", 0), world
+        if have_gpu:
+            torch.cuda.set_device(LOCAL_RANK)
+        if not dist.is_initialized():
+            dist.init_process_group(backend=backend, timeout=_NCCL_TIMEOUT)
+    else:
+        RANK, LOCAL_RANK, WORLD_SIZE = 0, 0, 1
+        if have_gpu:
+            torch.cuda.set_device(0)
+    IS_MAIN = RANK == 0
+    return torch.device("cuda", LOCAL_RANK) if have_gpu else torch.device("cpu")
+
+
+def is_main() -> bool:
+    return IS_MAIN
+
+
+def print_once(*args, **kwargs) -> None:
+    if IS_MAIN:
+        print(*args, **kwargs)
+
+
+def barrier() -> None:
+    if not IS_DISTRIBUTED:
+        return
+    if dist.get_backend() == "nccl":
+        dist.barrier(device_ids=[LOCAL_RANK])
+    else:
+        dist.barrier()
+
+
+def cleanup() -> None:
+    if IS_DISTRIBUTED and dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def unwrap_model(model: torch.nn.Module) -> torch.nn.Module:
+    return getattr(model, "module", model)
+
+
+def maybe_no_sync(model: torch.nn.Module, enabled: bool):
+    """`model.no_sync()` on all but the last micro-batch of an accumulation window
+    (model/model_utils.py:63); a null context for un-wrapped models."""
+    no_sync = getattr(model, "no_sync", None)
+    if enabled and no_sync is not None:
+        return no_sync()
+    return contextlib.nullcontext()
+
+
+# ---------------------------------------------------------------- wandb (rank 0 only)
+def setup_wandb(**kwargs) -> None:
+    global _wandb
+    _wandb = None
+    if IS_MAIN:
+        import wandb  # optional dependency
+
+        wandb.init(**kwargs)
+        _wandb = wandb
+
+
+def log(data: dict, step: Optional[int] = None) -> None:
+    if _wandb is not None:
+        _wandb.log(data, step=step)
+
+
+def watch(model: torch.nn.Module, **kwargs) -> None:
+    if _wandb is not None:
+        _wandb.watch(unwrap_model(model), **kwargs)
+
+
+def save_wandb_file(path: str) -> None:
+    if _wandb is not None:
+        _wandb.save(path)
+
+
+def update_wandb_config(data: dict, **kwargs) -> None:
+    if _wandb is not None:
+        _wandb.config.update(data, **kwargs)
+
+
+def set_wandb_summary(key: str, value) -> None:
+    if _wandb is not None:
+        _wandb.summary[key] = value
+
+
+def finish_wandb() -> None:
+    if _wandb is not None:
+        _wandb.finish()
