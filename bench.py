@@ -1,0 +1,224 @@
+#!/usr/bin/env python
+"""bench.py — audio-seconds/sec training throughput, whisper-large-v3 bf16 (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one optimizer step of the hot path on every rank: synthetic 30 s clips already
+resident in HBM -> log-mel -> SpecAugment -> encoder/decoder forward -> label-smoothed CE ->
+backward -> (DDP gradient all-reduce over RCCL, overlapped with backward) -> grad-norm clip ->
+AdamW.  Weights: random init of the whisper-large-v3 architecture; data: synthetic (no network).
+Rank 0 prints ONE JSON line (contract in the task statement); it also carries
+  "roofline":     the dominant kernel (gemm_nt_kernel: every Linear/conv/logits forward and
+                  backward-data GEMM), algorithmic FLOPs / HIP-event time of its launches
+                  during one instrumented step that follows the timed region;
+  "cpu_baseline": the CPU oracle (oracle/whisper_oracle.py, torch fp32) forward+backward on a
+                  bounded sample, timed on this box's host cores (N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+import torch.distributed as dist
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT / "whisper-finetune_amd"))
+
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def fwd_flops_per_clip(d, S: int) -> float:
+    """SURVEY.md §8d algorithmic forward FLOPs per 30 s clip."""
+    T, dm, V = d.n_audio_ctx, d.n_audio_state, d.n_vocab
+    conv = 2 * d.n_mels * dm * 3 * 3000 + 2 * dm * dm * 3 * 1500
+    enc = d.n_audio_layer * (24 * T * dm * dm + 4 * T * T * dm)
+    dec = d.n_text_layer * (28 * S * dm * dm + 4 * T * dm * dm + 4 * S * S * dm + 4 * S * T * dm)
+    return conv + enc + dec + 2 * S * dm * V
+
+
+def build_model(name: str, device):
+    from whisper_finetune.engine.whisper_model import MODEL_DIMS, Whisper, sinusoids
+
+    dims = MODEL_DIMS[name]
+    torch.manual_seed(0)
+    with torch.device(device):
+        model = Whisper(dims)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.dim() >= 2:
+                p.normal_(0.0, 0.02)
+            elif n.endswith("bias"):
+                p.zero_()
+            else:
+                p.fill_(1.0)
+        model.encoder.positional_embedding.copy_(sinusoids(dims.n_audio_ctx, dims.n_audio_state))
+    return model, dims
+
+
+def synthetic_tokens(B: int, S: int, device, seed: int):
+    g = torch.Generator().manual_seed(4321 + seed)
+    specials = torch.tensor([50258, 50261, 50359, 50363])
+    body = torch.randint(0, 50257, (B, S - 4), generator=g)
+    y_in = torch.cat([specials.expand(B, -1), body], dim=1)
+    y_out = torch.cat([y_in[:, 1:], torch.full((B, 1), 50257)], dim=1)
+    return y_in.to(device), y_out.to(device)
+
+
+def cpu_baseline(model_name: str, S: int, budget_s: float = 30.0):
+    """Oracle fwd+bwd (fp32, torch CPU) on ONE synthetic clip of the same architecture, or of a
+    smaller one if a forward pass alone would blow the time budget."""
+    sys.path.insert(0, str(ROOT))
+    from oracle import whisper_oracle as O
+
+    cores = torch.get_num_threads()
+    name = model_name
+    t_probe0 = time.perf_counter()
+    dims = O.DIMS[name]
+    params = {k: v.requires_grad_(k != "encoder.positional_embedding") for k, v in O.init_params(dims, seed=0).items()}
+    audio, y_in, y_out = O.synthetic_batch(dims, 1, S)
+    t0 = time.perf_counter()
+    mel = O.log_mel_spectrogram(audio, dims.n_mels)
+    loss = O.cross_entropy(O.Oracle(dims, params).forward(mel, y_in), y_out, 0.1)
+    loss.backward()
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(30.0 / dt, 3), "unit": "audio-s/s", "cores": cores, "kind": "port",
+        "sample": f"1 synthetic 30 s clip, whisper-{name} fp32, S={S}: log-mel + forward + CE + backward "
+                  f"(no optimizer step), {dt:.1f} s on {cores} torch threads ({os.cpu_count()} logical CPUs)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="large-v3")
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU per step")
+    ap.add_argument("--seq", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        if args.gpus != 1 or world != 1:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl")  # RCCL over xGMI
+
+    from whisper_finetune.data.gpu_frontend import GpuFrontend
+    from whisper_finetune.engine import kernels as K
+    from whisper_finetune.engine import lib as L
+
+    L.load()
+    model, dims = build_model(args.model, device)
+    model.train()
+    B, S = args.batch, args.seq
+    torch.manual_seed(1234 + rank)  # per-rank host RNG (finetune.py:325)
+    gen = torch.Generator(device=device).manual_seed(1234 + rank)
+    audio = torch.randn(B, 480000, device=device, generator=gen) * 0.1  # resident in HBM
+    y_in, y_out = synthetic_tokens(B, S, device, rank)
+    frontend = GpuFrontend(dims.n_mels, device, spec_augment=True,
+                           spec_augment_params={"time_mask_param": 100, "freq_mask_param": 43, "time_warp_w": 80, "p": 1.0})
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-5, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.1, fused=True)
+    net = model
+    if world > 1:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+
+        net = DDP(model, device_ids=[local_rank], output_device=local_rank, broadcast_buffers=False,
+                  gradient_as_bucket_view=True, bucket_cap_mb=64)
+
+    def step():
+        mel = frontend(audio, training=True)
+        loss = net(mel, y_in, targets=y_out, label_smoothing=0.1)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    final_loss = loss.item()
+
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        # one more step with HIP events around every gemm_nt launch (on the launch stream)
+        K.PROFILE_NT = []
+        step()
+        torch.cuda.synchronize()
+        recs, K.PROFILE_NT = K.PROFILE_NT, None
+        ms = sum(s.elapsed_time(e) for s, e, _ in recs)
+        flops = sum(f for _, _, f in recs)
+        ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        roofline = {
+            "kernel": "gemm_nt_kernel", "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "launches": len(recs), "avg_launch_us": round(ms * 1e3 / max(len(recs), 1), 2),
+            "flops_per_launch_avg": round(flops / max(len(recs), 1)),
+        }
+
+    if rank == 0:
+        clips = B * world * args.steps
+        value = clips * 30.0 / dt
+        step_flops = 3.0 * fwd_flops_per_clip(dims, S) * B * world
+        out = {
+            "metric": "audio-seconds/sec training throughput, whisper-large-v3 bf16",
+            "value": round(value, 1), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {
+                "workload": f"whisper-{args.model} full fine-tune, bf16 MFMA / fp32 master weights, {B} synthetic 30 s clips per GPU "
+                            f"per step, decoder S={S}, log-mel + SpecAugment on GPU, label smoothing 0.1, clip 1.0, AdamW, "
+                            f"local accumulation 1 (global window = {world})",
+                "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world}",
+            },
+            "step_tflops_per_gpu": round(step_flops / world / (dt / args.steps) / 1e12, 1),
+            "step_frac_of_bf16_peak": round(step_flops / world / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "final_loss": round(final_loss, 4),
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.model if args.model in ("tiny", "base", "small", "large-v3", "large-v3-turbo") else "large-v3", S)
+            except Exception as exc:  # the baseline is informative; never lose the GPU number over it
+                out["cpu_baseline"] = {"value": None, "unit": "audio-s/s", "cores": torch.get_num_threads(), "kind": "port",
+                                       "sample": f"failed: {exc!r}"}
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -13,11 +13,11 @@ are restated from SURVEY.md Appendix A, anchored on the reference's own call sit
 Parity pinning (tests/golden/, generator scripts committed next to the fixtures):
   * model forward / loss / gradients: an independent implementation of the same
     architecture (HF transformers WhisperForConditionalGeneration, bridged with the
-    reference's key map scripts/convert_openai_to_hf.py:89-110) -> whisper_tiny_fwd_bwd.npz
+    reference's key map scripts/convert_openai_to_hf.py:89-110) -> whisper_arch.npz
   * log-mel: HF WhisperFeatureExtractor (numpy STFT path) -> logmel.npz
   * time warp / extremes masking / pad_or_trim / stochastic depth / deep-SpecAugment hooks /
     train_step control flow: the REFERENCE'S OWN Python imported in this container with
-    import stubs for the missing third-party packages -> specaug.npz, host_logic.npz
+    import stubs for the missing third-party packages -> ref_host.npz
   * LoRA algebra: the invariants the reference's tests pin (tests/test_lora.py:42-44,
     124-127,262-273,612-614,762-766), restated in tests/test_oracle.py.
 """
@@ -131,19 +131,27 @@ def time_warp(spec: Tensor, warp_p: int, warp_d: int) -> Tensor:
     warp_p in [W, L-W) and warp_d in [-W, W) (data/utils.py:107,111): cubic Hermite
     through (0,-1), (warp_p, y1), (L-1, 1) then bilinear grid_sample(align_corners=True)."""
     num_rows, spec_len = spec.shape
-    x = torch.tensor([0.0, float(warp_p), spec_len - 1.0])
-    y = torch.tensor([-1.0, (warp_p - warp_d) * 2 / (spec_len - 1.0) - 1.0, 1.0])
-    xs = torch.linspace(0, spec_len - 1, spec_len)
-    # hspline_interpolate_1D (data/utils.py:71-85)
-    m = (y[1:] - y[:-1]) / (x[1:] - x[:-1])
-    m = torch.cat([m[[0]], (m[1:] + m[:-1]) / 2, m[[-1]]])
-    idxs = torch.searchsorted(x[1:].contiguous(), xs)
-    dx = x[idxs + 1] - x[idxs]
-    t = (xs - x[idxs]) / dx
+    # integer control points and fp32 arithmetic exactly as the reference forms them (data/utils.py:113-136)
+    wp = torch.tensor([warp_p], dtype=torch.int64)
+    wd = torch.tensor([warp_d], dtype=torch.int64)
+    x = torch.stack([torch.tensor([0]), wp, torch.tensor([spec_len - 1])], 1)  # int64 [1, 3]
+    y = torch.stack([torch.tensor([-1.0]), (wp - wd) * 2 / (spec_len - 1.0) - 1.0, torch.tensor([1.0])], 1)
+    xs = torch.linspace(0, spec_len - 1, spec_len).unsqueeze(0)
+    # hspline_interpolate_1D (data/utils.py:66-85)
+    m = (y[..., 1:] - y[..., :-1]) / (x[..., 1:] - x[..., :-1])
+    m = torch.cat([m[..., [0]], (m[..., 1:] + m[..., :-1]) / 2, m[..., [-1]]], -1)
+    idxs = torch.searchsorted(x[..., 1:], xs)
+    dx = x.gather(dim=-1, index=idxs + 1) - x.gather(dim=-1, index=idxs)
+    t = (xs - x.gather(dim=-1, index=idxs)) / dx
     tt = t.unsqueeze(-2) ** torch.arange(4).view(-1, 1)
     A = torch.tensor([[1, 0, -3, 2], [0, 1, -2, 1], [0, 0, 3, -2], [0, 0, -1, 1]], dtype=t.dtype)
     hh = A @ tt
-    ys = hh[0] * y[idxs] + hh[1] * m[idxs] * dx + hh[2] * y[idxs + 1] + hh[3] * m[idxs + 1] * dx
+    ys = (
+        hh[..., 0, :] * y.gather(dim=-1, index=idxs)
+        + hh[..., 1, :] * m.gather(dim=-1, index=idxs) * dx
+        + hh[..., 2, :] * y.gather(dim=-1, index=idxs + 1)
+        + hh[..., 3, :] * m.gather(dim=-1, index=idxs + 1) * dx
+    )
     grid = torch.cat(
         (
             ys.view(1, 1, -1, 1).expand(-1, num_rows, -1, -1),

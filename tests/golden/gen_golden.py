@@ -1,0 +1,271 @@
+"""Generates the golden fixtures in tests/golden/*.npz.  Run ONLY in the build container
+(it reads /root/reference and uses HF transformers); the fixtures are committed, this script
+is their provenance.
+
+    python tests/golden/gen_golden.py
+
+Sources of truth
+  whisper_arch.npz   HF transformers WhisperForConditionalGeneration (independent implementation
+                     of the architecture) loaded with oracle-named weights through the REFERENCE's
+                     key map (scripts/convert_openai_to_hf.py:89-110): logits, loss, gradients.
+  logmel.npz         HF WhisperFeatureExtractor (numpy STFT, slaney filterbank) on seeded clips,
+                     and transformers.audio_utils.mel_filter_bank for the filterbank itself.
+  ref_host.npz       the REFERENCE'S OWN Python (imported with import stubs for the third-party
+                     packages that are not installed): TimeWarpAugmenter, ExtremesFrequencyMasking,
+                     pad_or_trim, StochasticDepthMixin, register_deep_spec_augment_hooks,
+                     calculate_training_steps / val_steps / resolve_local_accum_grad_steps.
+"""
+import sys
+import tempfile
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parents[1]
+sys.path.insert(0, str(ROOT))
+from oracle import whisper_oracle as O  # noqa: E402
+
+REF = Path("/root/reference")
+
+# small dims that still satisfy the kernels' constraints (d % 128 == 0, head_dim 64)
+ARCH_DIMS = O.ModelDimensions(n_mels=80, n_audio_ctx=100, n_audio_state=128, n_audio_head=2, n_audio_layer=2,
+                              n_vocab=1000, n_text_ctx=64, n_text_state=128, n_text_head=2, n_text_layer=2)
+
+
+def arch_params(dims, seed):
+    p = O.init_params(dims, seed=seed, std=0.08)
+    g = torch.Generator().manual_seed(seed + 100)
+    for k, v in p.items():
+        if k.endswith(".bias"):
+            p[k] = torch.randn(v.shape, generator=g) * 0.05
+        elif "ln" in k and k.endswith(".weight"):
+            p[k] = 1 + torch.randn(v.shape, generator=g) * 0.1
+    return p
+
+
+def arch_inputs(dims, seed):
+    g = torch.Generator().manual_seed(seed)
+    mel = torch.randn(2, dims.n_mels, 2 * dims.n_audio_ctx, generator=g)
+    y_in = torch.randint(0, dims.n_vocab, (2, 12), generator=g)
+    y_out = torch.randint(0, dims.n_vocab, (2, 12), generator=g)
+    y_out[0, :3] = -100
+    y_out[1, -2:] = -100
+    return mel, y_in, y_out
+
+
+def gen_arch():
+    from transformers import WhisperConfig, WhisperForConditionalGeneration
+
+    sys.path.insert(0, str(REF / "src"))
+    src = (REF / "src/whisper_finetune/scripts/convert_openai_to_hf.py").read_text()
+    ns = {}
+    start = src.index("WHISPER_MAPPING = {")
+    exec(src[start: src.index("}", start) + 1], ns)  # only the key map literal
+    mapping = ns["WHISPER_MAPPING"]
+
+    dims = ARCH_DIMS
+    params = arch_params(dims, 3)
+    hf_sd = {}
+    for k, v in params.items():
+        nk = k
+        for a, b in mapping.items():
+            if a in nk:
+                nk = nk.replace(a, b)
+        hf_sd[nk] = v.clone()
+    cfg = WhisperConfig(vocab_size=dims.n_vocab, encoder_ffn_dim=4 * dims.n_audio_state, decoder_ffn_dim=4 * dims.n_text_state,
+                        num_mel_bins=dims.n_mels, d_model=dims.n_audio_state, max_target_positions=dims.n_text_ctx,
+                        encoder_layers=dims.n_audio_layer, encoder_attention_heads=dims.n_audio_head,
+                        decoder_layers=dims.n_text_layer, decoder_attention_heads=dims.n_text_head,
+                        max_source_positions=dims.n_audio_ctx, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0,
+                        eos_token_id=1, bos_token_id=1, pad_token_id=1, decoder_start_token_id=2, attn_implementation="eager")
+    model = WhisperForConditionalGeneration(cfg)
+    missing, unexpected = model.model.load_state_dict(hf_sd, strict=False)
+    assert not unexpected, unexpected
+    assert all("embed_positions" in m for m in missing), missing
+    model.proj_out.weight = model.model.decoder.embed_tokens.weight  # tied (convert_openai_to_hf.py:223-224)
+    model.train()
+    mel, y_in, y_out = arch_inputs(dims, 11)
+    logits = model(input_features=mel, decoder_input_ids=y_in).logits
+    loss = torch.nn.functional.cross_entropy(logits.transpose(1, 2), y_out, label_smoothing=0.1)
+    loss.backward()
+    inv = {}
+    for k in params:
+        nk = k
+        for a, b in mapping.items():
+            if a in nk:
+                nk = nk.replace(a, b)
+        inv[k] = nk
+    named = dict(model.model.named_parameters())
+    out = {"logits": logits.detach().numpy(), "loss": np.float64(loss.item())}
+    norms = {}
+    for k, nk in inv.items():
+        if nk in named and named[nk].grad is not None:
+            norms[k] = named[nk].grad.norm().item()
+    out["grad_norm_names"] = np.array(sorted(norms))
+    out["grad_norms"] = np.array([norms[k] for k in sorted(norms)])
+    for k in ["encoder.conv1.weight", "encoder.blocks.0.attn.key.weight", "encoder.blocks.1.mlp.0.bias",
+              "decoder.blocks.1.cross_attn.query.weight", "decoder.blocks.0.attn_ln.weight", "decoder.positional_embedding"]:
+        out["grad::" + k] = named[inv[k]].grad.numpy()
+    np.savez_compressed(HERE / "whisper_arch.npz", **out)
+    print("whisper_arch.npz: loss", loss.item(), "params with grads:", len(norms))
+
+
+def gen_logmel():
+    from transformers import WhisperFeatureExtractor
+    from transformers.audio_utils import mel_filter_bank
+
+    out = {}
+    clips = []
+    for i in range(2):
+        g = torch.Generator().manual_seed(1234 + i)
+        a = torch.randn(O.N_SAMPLES, generator=g) * 0.1
+        if i == 1:
+            a[200000:] = 0.0  # zero-padded tail (data_loader.py:346)
+            a[:200000] *= torch.linspace(0.0, 1.0, 200000)
+        clips.append(a.numpy())
+    t = np.arange(O.N_SAMPLES) / 16000.0
+    clips.append((0.3 * np.sin(2 * np.pi * (200.0 + 120.0 * t) * t)).astype(np.float32))  # sine sweep
+    for n_mels in (80, 128):
+        fe = WhisperFeatureExtractor(feature_size=n_mels)
+        feats = fe(clips, sampling_rate=16000, return_tensors="np")["input_features"]  # [3, n_mels, 3000]
+        out[f"mel{n_mels}_sub"] = feats[:, :, ::7].astype(np.float32)
+        out[f"filters{n_mels}"] = mel_filter_bank(201, n_mels, 0.0, 8000.0, 16000, norm="slaney", mel_scale="slaney").T.astype(np.float32)
+    np.savez_compressed(HERE / "logmel.npz", **out)
+    print("logmel.npz written")
+
+
+def _install_stubs(tmp: Path):
+    (tmp / "whisper").mkdir()
+    (tmp / "whisper/__init__.py").write_text(
+        "class Whisper: pass\n_ALIGNMENT_HEADS={}\n_MODELS={}\ndef _download(*a,**k): raise RuntimeError\n"
+        "def available_models(): return []\ndef load_model(*a,**k): raise RuntimeError\n")
+    (tmp / "whisper/audio.py").write_text(
+        "SAMPLE_RATE=16000\nN_FFT=400\nHOP_LENGTH=160\nCHUNK_LENGTH=30\nN_SAMPLES=480000\nN_FRAMES=3000\n"
+        "def log_mel_spectrogram(*a,**k): raise RuntimeError\n")
+    (tmp / "whisper/tokenizer.py").write_text("LANGUAGES={}\nTO_LANGUAGE_CODE={}\nclass Tokenizer: pass\ndef get_tokenizer(*a,**k): raise RuntimeError\n")
+    (tmp / "whisper/model.py").write_text(
+        "import torch\nclass Linear(torch.nn.Linear): pass\nclass AudioEncoder(torch.nn.Module):\n    def __init__(self,*a,**k): super().__init__()\n"
+        "class TextDecoder(torch.nn.Module):\n    def __init__(self,*a,**k): super().__init__()\nclass Whisper(torch.nn.Module): pass\n")
+    (tmp / "torchaudio").mkdir()
+    (tmp / "torchaudio/__init__.py").write_text("")
+    # torchaudio.transforms restated from the published mask_along_axis
+    (tmp / "torchaudio/transforms.py").write_text(
+        "import torch\n"
+        "class _M(torch.nn.Module):\n"
+        "    def __init__(self, p, axis):\n        super().__init__(); self.p=p; self.axis=axis\n"
+        "    def forward(self, x):\n"
+        "        size=x.size(self.axis)\n        value=torch.rand(1)*self.p\n        mn=torch.rand(1)*(size-value)\n"
+        "        s=int(mn.long()); e=s+int(value.long())\n        x=x.clone()\n"
+        "        idx=[slice(None)]*x.dim(); idx[self.axis]=slice(s,e); x[tuple(idx)]=0.0\n        return x\n"
+        "class TimeMasking(_M):\n    def __init__(self, time_mask_param): super().__init__(time_mask_param, -1)\n"
+        "class FrequencyMasking(_M):\n    def __init__(self, freq_mask_param): super().__init__(freq_mask_param, -2)\n")
+    (tmp / "jiwer.py").write_text("def wer(*a,**k): raise RuntimeError\ndef cer(*a,**k): raise RuntimeError\n")
+
+
+def gen_ref_host():
+    tmp = Path(tempfile.mkdtemp())
+    _install_stubs(tmp)
+    sys.path.insert(0, str(tmp))
+    sys.path.insert(0, str(REF / "src"))
+    sys.dont_write_bytecode = True
+    from whisper_finetune import utils as rutils
+    from whisper_finetune.data import utils as rdata
+    from whisper_finetune.model import model_utils as rmu
+
+    out = {}
+    # --- time warp (data/utils.py:41-143) on a smooth + noisy spectrogram, several draws
+    g = torch.Generator().manual_seed(7)
+    spec = torch.randn(16, 300, generator=g).cumsum(1) * 0.1
+    out["tw_spec"] = spec.numpy()
+    for i, seed in enumerate((0, 1, 2)):
+        torch.manual_seed(seed)
+        W = 20
+        # replay the two draws the reference makes to record them
+        st = torch.get_rng_state()
+        wp = int(torch.randint(W, 300 - W, (1,)))
+        wd = int(torch.randint(-W, W, (1,)))
+        torch.set_rng_state(st)
+        warped = rdata.TimeWarpAugmenter(W=W)(spec.clone())
+        out[f"tw_params{i}"] = np.array([wp, wd])
+        out[f"tw_out{i}"] = warped.numpy()
+    # --- extremes frequency masking (data/utils.py:146-190)
+    torch.manual_seed(5)
+    st = torch.get_rng_state()
+    r = torch.rand(1).item()
+    torch.set_rng_state(st)
+    ex = rdata.ExtremesFrequencyMasking(low_freq_range=6, high_freq_range=4)(torch.ones(16, 10))
+    out["ext_r"] = np.float64(r)
+    out["ext_out"] = ex.numpy()
+    # --- pad_or_trim with the minimum (data/utils.py:380-394)
+    short = torch.arange(12, dtype=torch.float32).reshape(3, 4) - 5
+    out["pad_in"] = short.numpy()
+    out["pad_out"] = rdata.pad_or_trim(short, 7).numpy()
+    out["trim_out"] = rdata.pad_or_trim(short, 2).numpy()
+    # --- stochastic depth arithmetic (model/model_utils.py:226-250)
+    class SD(rmu.StochasticDepthMixin, torch.nn.Module):
+        pass
+    sd = SD(); sd.train()
+    x = torch.tensor([[1.0, -2.0, 3.0]])
+    torch.manual_seed(0)
+    draws = []
+    outs = []
+    for _ in range(6):
+        st = torch.get_rng_state(); d = torch.rand(1).item(); torch.set_rng_state(st)
+        draws.append(d)
+        outs.append(sd.stochastic_depth(x, lambda t: t * 2 + 1, 0.4).detach().numpy())
+    out["sd_draws"] = np.array(draws)
+    out["sd_outs"] = np.stack(outs)
+    sd.eval()
+    out["sd_eval"] = sd.stochastic_depth(x, lambda t: t * 2 + 1, 0.4).detach().numpy()
+    # --- deep SpecAugment hooks (model/model_utils.py:382-437): which rows / channels get zeroed
+    class Blk(torch.nn.Module):
+        def __init__(self):
+            super().__init__(); self.attn_ln = torch.nn.Identity()
+        def forward(self, x): return self.attn_ln(x)
+    class Enc(torch.nn.Module):
+        def __init__(self):
+            super().__init__(); self.blocks = torch.nn.ModuleList([Blk() for _ in range(3)])
+        def forward(self, x):
+            outs = []
+            for b in self.blocks: outs.append(b(x))
+            return outs
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__(); self.encoder = Enc()
+    m = M(); m.train()
+    rmu.register_deep_spec_augment_hooks(m, time_mask_param=30, freq_mask_param=20, p=1.0)
+    torch.manual_seed(42)
+    ys = m.encoder(torch.ones(2, 150, 128))
+    for i, y in enumerate(ys):
+        z = (y == 0)
+        out[f"dsa_rows{i}"] = z.all(dim=2)[0].numpy()    # [T] time steps fully zeroed
+        out[f"dsa_cols{i}"] = z.all(dim=1)[0].numpy()    # [d] channels fully zeroed
+    # --- step arithmetic tables (utils.py:14-53)
+    rows = []
+    for n in (1000, 1234, 99):
+        for world in (1, 2, 4, 8):
+            for bs in (4, 32):
+                for ep in (1, 2.5):
+                    for acc in (1, 4):
+                        for dl in (True, False):
+                            cfg = {"training": {"epochs": ep, "accum_grad_steps": acc}, "dataset": {"batch_size": bs}}
+                            rows.append([n, world, bs, ep, acc, int(dl), rutils.calculate_training_steps(cfg, range(n), world, dl)])
+    out["train_steps_table"] = np.array(rows, dtype=np.float64)
+    vs = []
+    for ts in (10, 137, 1000):
+        for ep in (1, 3):
+            for ev in (0.1, 0.25, 1.0):
+                vs.append([ts, ep, ev, rutils.calculate_val_steps({"training": {"train_steps": ts, "epochs": ep, "eval_steps": ev}})])
+    out["val_steps_table"] = np.array(vs, dtype=np.float64)
+    out["local_accum"] = np.array([[a, w, rutils.resolve_local_accum_grad_steps(a, w)] for a, w in ((8, 1), (8, 2), (8, 4), (8, 8), (4, 2))])
+    np.savez_compressed(HERE / "ref_host.npz", **out)
+    print("ref_host.npz written", {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
+
+
+if __name__ == "__main__":
+    gen_arch()
+    gen_logmel()
+    gen_ref_host()

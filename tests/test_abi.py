@@ -1,0 +1,56 @@
+"""The C-ABI library builds, loads without a GPU and exports exactly what include/wft.h declares."""
+import ctypes
+import re
+from pathlib import Path
+
+from whisper_finetune.engine import lib as L
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _declared():
+    text = (ROOT / "include" / "wft.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(wft_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_functions():
+    names = _declared()
+    assert len(names) >= 20
+    assert "wft_gemm_nt_bf16" in names and "wft_attn_bwd_bf16" in names and "wft_logmel" in names
+
+
+def test_library_exports_every_declared_symbol():
+    assert L.LIB_PATH.exists(), "run __graft_entry__.build() first"
+    handle = ctypes.CDLL(str(L.LIB_PATH))
+    for name in _declared():
+        assert hasattr(handle, name), f"{name} declared in wft.h but not exported by libwft.so"
+
+
+def test_python_binding_covers_the_header():
+    assert sorted(L.SIGNATURES) == _declared()
+    handle = L.load()
+    assert handle.wft_version().decode().endswith("gfx950")
+    assert handle.wft_layernorm_bwd_workspace(1000, 384) > 0  # pure host function: callable without a GPU
+
+
+def test_struct_sizes_match_header_layout():
+    # 8-byte aligned C structs: pointers/int64 interleaved with ints exactly as in wft.h
+    assert ctypes.sizeof(L.GemmArgs) % 8 == 0 and ctypes.sizeof(L.AttnArgs) % 8 == 0
+    assert L.GemmArgs.M.offset - L.GemmArgs.alpha.offset == 4
+    assert L.AttnArgs.d_o.offset % 8 == 0
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", tmp_path / "nope.so")
+    try:
+        L.load()
+    except L.WftError as e:
+        assert "no CPU fallback" in str(e)
+    else:
+        raise AssertionError("load() must raise when libwft.so is absent")
+    finally:
+        monkeypatch.undo()
+        L._lib = None
+        L.load()

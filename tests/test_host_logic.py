@@ -1,0 +1,252 @@
+"""Host-side mirror of the reference interface (whisper_finetune.*): step arithmetic, train_step
+control flow (DDP faked exactly as the reference's own tests do, tests/test_training_utils.py:400-533),
+stochastic depth, deep-SpecAugment draws, SpecAugment draw order, LoRA module structure.  CPU only."""
+import contextlib
+
+import numpy as np
+import pytest
+import torch
+
+import whisper_finetune.runtime as rt
+from whisper_finetune import utils
+from whisper_finetune.data.gpu_frontend import GpuFrontend, mel_filters
+from whisper_finetune.engine.whisper_model import MODEL_DIMS, Linear, Whisper
+from whisper_finetune.model import lora, model_utils
+
+
+def test_step_tables_match_reference(golden_host):
+    for n, world, bs, ep, acc, dl, ref in golden_host["train_steps_table"]:
+        cfg = {"training": {"epochs": ep if ep != int(ep) else int(ep), "accum_grad_steps": int(acc)}, "dataset": {"batch_size": int(bs)}}
+        assert utils.calculate_training_steps(cfg, range(int(n)), int(world), bool(dl)) == int(ref)
+    for ts, ep, ev, ref in golden_host["val_steps_table"]:
+        assert utils.calculate_val_steps({"training": {"train_steps": int(ts), "epochs": int(ep), "eval_steps": ev}}) == int(ref)
+    for a, w, ref in golden_host["local_accum"]:
+        assert utils.resolve_local_accum_grad_steps(int(a), int(w)) == int(ref)
+    with pytest.raises(ValueError):
+        utils.resolve_local_accum_grad_steps(8, 3)
+    with pytest.raises(ValueError):
+        utils.resolve_local_accum_grad_steps(0, 1)
+
+
+def test_set_seed_reproducible():
+    utils.set_seed(5); a = torch.rand(3)
+    utils.set_seed(5); b = torch.rand(3)
+    assert torch.equal(a, b)
+
+
+class _TinyDDPModel(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.lin = torch.nn.Linear(4, 6)
+        self.no_sync_entries = 0
+
+    def forward(self, x, y_in):
+        return self.lin(x).unsqueeze(1).expand(-1, y_in.shape[1], -1)
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        self.no_sync_entries += 1
+        yield
+
+
+def _batches(n):
+    for _ in range(n):
+        yield torch.randn(2, 4), torch.zeros(2, 3, dtype=torch.long), torch.randint(0, 6, (2, 3))
+
+
+class _Sched:
+    def __init__(self): self.steps = 0
+    def step(self): self.steps += 1
+
+
+T_CFG = {"mixed_precision_training": False, "accum_grad_steps": 4, "max_grad_norm": 1.0, "mp_dtype": "bf16"}
+
+
+def test_train_step_enters_no_sync_on_all_but_last_microbatch(monkeypatch):
+    monkeypatch.setattr(rt, "IS_DISTRIBUTED", True)
+    m, s = _TinyDDPModel(), _Sched()
+    opt = torch.optim.SGD(m.parameters(), lr=0.1)
+    before = m.lin.weight.detach().clone()
+    loss = model_utils.train_step(m, _batches(4), opt, s, dict(T_CFG))
+    assert m.no_sync_entries == 3 and s.steps == 1
+    assert isinstance(loss, float) and loss > 0
+    assert not torch.equal(before, m.lin.weight)
+    assert all(p.grad is None for p in m.parameters())  # zero_grad(set_to_none=True)
+
+
+def test_train_step_no_sync_not_used_without_ddp(monkeypatch):
+    monkeypatch.setattr(rt, "IS_DISTRIBUTED", False)
+    m = _TinyDDPModel()
+    model_utils.train_step(m, _batches(4), torch.optim.SGD(m.parameters(), lr=0.1), _Sched(), dict(T_CFG))
+    assert m.no_sync_entries == 0
+
+
+def test_train_step_loss_is_sum_of_scaled_microbatch_means(monkeypatch):
+    monkeypatch.setattr(rt, "IS_DISTRIBUTED", False)
+    torch.manual_seed(0)
+    m = _TinyDDPModel()
+    data = list(_batches(4))
+    expect = sum(torch.nn.functional.cross_entropy(m(x, yi).transpose(1, 2), yo, label_smoothing=0.1).item() / 4 for x, yi, yo in data)
+    got = model_utils.train_step(m, iter(data), torch.optim.SGD(m.parameters(), lr=0.0), _Sched(), {**T_CFG, "label_smoothing": 0.1})
+    assert abs(got - expect) < 1e-6
+
+
+def test_train_step_illegal_memory_reraised_under_ddp(monkeypatch):
+    monkeypatch.setattr(rt, "IS_DISTRIBUTED", True)
+    calls = {"n": 0}
+
+    class Bad(_TinyDDPModel):
+        def forward(self, x, y_in):
+            calls["n"] += 1
+            raise RuntimeError("CUDA error: an illegal memory access was encountered")
+
+    m = Bad()
+    with pytest.raises(RuntimeError, match="illegal memory"):
+        model_utils.train_step(m, _batches(8), torch.optim.SGD(m.parameters(), lr=0.1), _Sched(), dict(T_CFG))
+    assert calls["n"] == 1  # no retry under DDP
+    monkeypatch.setattr(rt, "IS_DISTRIBUTED", False)
+    calls["n"] = 0
+    with pytest.raises(RuntimeError):
+        model_utils.train_step(m, _batches(8), torch.optim.SGD(m.parameters(), lr=0.1), _Sched(), dict(T_CFG))
+    assert calls["n"] == 3  # three attempts on a single GPU
+
+
+def test_train_step_fp16_needs_scaler():
+    m = _TinyDDPModel()
+    with pytest.raises(ValueError, match="GradScaler"):
+        model_utils.train_step(m, _batches(1), torch.optim.SGD(m.parameters(), lr=0.1), _Sched(),
+                               {**T_CFG, "mixed_precision_training": True, "mp_dtype": "fp16"})
+
+
+def test_infinite_iter_cycles_and_sets_epoch():
+    class S:
+        def __init__(self): self.epochs = []
+        def set_epoch(self, e): self.epochs.append(e)
+
+    class DL(list):
+        pass
+
+    dl = DL([1, 2]); dl.sampler = S()
+    it = model_utils.infinite_iter(dl)
+    assert [next(it) for _ in range(5)] == [1, 2, 1, 2, 1]
+    assert dl.sampler.epochs == [0, 1, 2]
+
+
+def test_stochastic_depth_matches_reference(golden_host):
+    class SD(model_utils.StochasticDepthMixin, torch.nn.Module):
+        pass
+    sd = SD().train()
+    x = torch.tensor([[1.0, -2.0, 3.0]])
+    torch.manual_seed(0)
+    for ref in golden_host["sd_outs"]:
+        np.testing.assert_allclose(sd.stochastic_depth(x, lambda t: t * 2 + 1, 0.4).detach().numpy(), ref, rtol=1e-6)
+    sd.eval()
+    np.testing.assert_allclose(sd.stochastic_depth(x, lambda t: t * 2 + 1, 0.4).detach().numpy(), golden_host["sd_eval"], rtol=1e-6)
+    sd.train()
+    assert torch.equal(sd.stochastic_depth(x, lambda t: t * 2 + 1, 1.0), x)  # keep_prob 0 or skipped: identity
+
+
+def test_resample_block_list():
+    blocks = torch.nn.ModuleList([torch.nn.Linear(1, 1) for _ in range(4)])
+    assert len(model_utils._resample_block_list(blocks, 2)) == 2
+    up = model_utils._resample_block_list(blocks, 6)
+    assert len(up) == 6 and up[0] is blocks[0]
+    with pytest.raises(ValueError):
+        model_utils._resample_block_list(blocks, 0)
+
+
+def _tiny():
+    return Whisper(MODEL_DIMS["tiny"])
+
+
+def test_deep_spec_augment_draws_match_reference(golden_host):
+    """Same torch.manual_seed -> same zeroed time rows / channels as the reference's hooks produced."""
+    from whisper_finetune.engine.whisper_model import ModelDimensions
+    m = Whisper(ModelDimensions(80, 150, 128, 2, 3, 100, 16, 128, 2, 1)).train()
+    model_utils.register_deep_spec_augment_hooks(m, time_mask_param=30, freq_mask_param=20, p=1.0)
+    torch.manual_seed(42)
+    for hook in m.encoder._forward_pre_hooks.values():
+        hook(m.encoder, None)
+    for i, blk in enumerate(m.encoder.blocks):
+        drawer = blk.attn_ln.deep_spec_augment
+        if i == 2:
+            assert drawer is None  # last block never augmented
+            continue
+        t0, t1, c0, c1 = drawer()
+        rows = np.zeros(150, bool); rows[t0:t1] = True
+        cols = np.zeros(128, bool); cols[c0:c1] = True
+        np.testing.assert_array_equal(rows, golden_host[f"dsa_rows{i}"])
+        np.testing.assert_array_equal(cols, golden_host[f"dsa_cols{i}"])
+    with pytest.raises(ValueError):
+        model_utils.register_deep_spec_augment_hooks(m, 1, 1, p=1.5)
+
+
+def test_gpu_frontend_draw_order_is_the_references():
+    """warp randint x2 -> time rand x2 -> freq rand x2 per clip (data_loader.py:284-287, data/utils.py:107,111)."""
+    fe = GpuFrontend.__new__(GpuFrontend)
+    fe.n_mels, fe.spec_augment, fe.p, fe.extremes = 80, True, 1.0, True
+    fe.time_mask_param, fe.freq_mask_param, fe.time_warp_w = 100, 27, 80
+    fe.low_freq_range, fe.high_freq_range = 10, 6
+    torch.manual_seed(123)
+    params, ext = fe.draw(2)
+    torch.manual_seed(123)
+    for b in range(2):
+        wp = int(torch.randint(80, 3000 - 80, (1,))); wd = int(torch.randint(-80, 80, (1,)))
+        v = torch.rand(1) * 100; mn = torch.rand(1) * (3000 - v); t0 = int(mn.long()); t1 = t0 + int(v.long())
+        v = torch.rand(1) * 27; mn = torch.rand(1) * (80 - v); f0 = int(mn.long()); f1 = f0 + int(v.long())
+        r = torch.rand(1).item()
+        assert params[b].tolist() == [1, wp, wd, t0, t1, f0, f1, 0]
+        assert ext[b].tolist() == [int(round(r * 10)), int(round(r * 6))]
+
+
+def test_mel_filters_match_golden(golden_logmel):
+    for n in (80, 128):
+        np.testing.assert_allclose(mel_filters(n).numpy(), golden_logmel[f"filters{n}"], atol=2e-7)
+
+
+def test_lora_structure_and_merge():
+    m = _tiny()
+    n_lin = sum(isinstance(x, Linear) for x in m.modules())
+    assert n_lin == 64  # 64 Linears in whisper-tiny
+    lora.apply_lora(m, {"rank": 16, "lora_alpha": 32, "lora_dropout": 0.1})
+    names = dict(m.named_parameters())
+    assert "decoder.blocks.0.cross_attn.query.parametrizations.weight.0.lora_A" in names
+    assert "decoder.blocks.0.cross_attn.query.parametrizations.weight.original" in names
+    trainable = [n for n, p in names.items() if p.requires_grad]
+    assert trainable and all("lora" in n for n in trainable)
+    assert sum(names[n].numel() for n in trainable) == 1081344  # 1.08 M
+    q = m.decoder.blocks[0].cross_attn.query
+    ad = q.parametrizations.weight[0]
+    assert ad.lora_A.shape == (16, 384) and ad.lora_B.shape == (384, 16) and ad.scaling == 2.0
+    assert ad.lora_B.norm() == 0 and ad.lora_A.norm() > 0
+    assert "decoder.blocks.0.cross_attn.query.parametrizations.weight.0.lora_dropout_mask" in m.state_dict()
+    m.eval()
+    assert torch.equal(q.weight, q.parametrizations.weight.original)  # B = 0: effective weight unchanged
+    with torch.no_grad():
+        ad.lora_B.normal_()
+    expect = q.parametrizations.weight.original + 2.0 * ad.lora_B @ ad.lora_A
+    torch.testing.assert_close(q.weight, expect)
+    assert lora.is_lora_enabled(m)
+    stats = lora.get_lora_debug_stats(m)
+    assert stats["param_name"].startswith("decoder.blocks.0.cross_attn.query")
+    lora.merge_lora(m)
+    assert not lora.is_lora_enabled(m)
+    torch.testing.assert_close(m.decoder.blocks[0].cross_attn.query.weight, expect, atol=1e-5, rtol=0)
+    assert type(m.decoder.blocks[0].cross_attn.query) is Linear
+
+
+def test_state_dict_keys_are_openai_whisper_names():
+    keys = set(_tiny().state_dict())
+    for k in ("encoder.conv1.weight", "encoder.positional_embedding", "encoder.blocks.0.attn.key.weight",
+              "encoder.blocks.3.mlp.2.bias", "encoder.ln_post.weight", "decoder.token_embedding.weight",
+              "decoder.positional_embedding", "decoder.blocks.0.cross_attn_ln.bias", "decoder.ln.bias"):
+        assert k in keys
+    assert "encoder.blocks.0.attn.key.bias" not in keys  # K projection has no bias
+    assert "decoder.mask" not in keys  # non-persistent
+
+
+def test_product_path_refuses_cpu_tensors():
+    from whisper_finetune.engine import lib as L
+    m = _tiny()
+    with pytest.raises(L.WftError):
+        m(torch.zeros(1, 80, 3000), torch.zeros(1, 4, dtype=torch.long))

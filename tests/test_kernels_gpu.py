@@ -1,0 +1,298 @@
+"""GPU parity tests of every libwft kernel, called through the C ABI (ctypes), against fp32 CPU
+math (torch CPU / the oracle).  Tolerances: bit-exact for integer / index / pure-copy results;
+fp32-accumulated results from bf16 inputs compare at 1e-5 (relative to max) when the output is
+fp32 and at bf16 resolution (<= 1e-2 of max) when the output itself is rounded to bf16."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import whisper_oracle as O  # noqa: E402
+from whisper_finetune.engine import kernels as K  # noqa: E402
+from whisper_finetune.engine import lib as L  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def close(got, ref, tol, what=""):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item() + 1e-12
+    assert math.isfinite(err) and err <= tol * scale + 1e-30, f"{what}: max|err|={err:.3e} rel-to-max={err / scale:.3e} tol={tol}"
+
+
+def test_casts_bit_exact():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1000, 77, generator=g)
+    assert torch.equal(K.cast_bf16(x.to(DEV)).cpu(), bf(x))
+    w = torch.randn(300, 256, generator=g)
+    d, dt = K.weight_shadow(w.to(DEV), 384, 256, True)
+    ref = torch.zeros(384, 256); ref[:300] = w
+    assert torch.equal(d.cpu(), bf(ref)) and torch.equal(dt.cpu(), bf(ref).t())
+    a, b = bf(torch.randn(4097, generator=g)), bf(torch.randn(4097, generator=g))
+    assert torch.equal(K.add_bf16(a.to(DEV), b.to(DEV)).cpu(), bf(a.float() + b.float()))
+
+
+@pytest.mark.parametrize("rows,cols", [(3000, 384), (777, 1280), (1, 512), (130, 2048)])
+def test_layernorm_fwd_bwd(rows, cols):
+    g = torch.Generator().manual_seed(rows)
+    x = bf(torch.randn(rows, cols, generator=g) * 2 + 0.5)
+    gamma = torch.randn(cols, generator=g); beta = torch.randn(cols, generator=g)
+    y, mean, rstd = K.layernorm_fwd(x.to(DEV), gamma.to(DEV), beta.to(DEV))
+    xr = x.float().requires_grad_(True); gr = gamma.clone().requires_grad_(True); br = beta.clone().requires_grad_(True)
+    ref = O.layer_norm(xr, gr, br)
+    close(y, ref, 1e-2, "ln fwd")
+    close(mean, x.float().mean(-1), 1e-5, "mean")
+    dy = bf(torch.randn(rows, cols, generator=g)); dres = bf(torch.randn(rows, cols, generator=g))
+    ref.backward(dy.float())
+    dx, dg, db = K.layernorm_bwd(dy.to(DEV), x.to(DEV), gamma.to(DEV), mean, rstd, dres.to(DEV))
+    close(dx, xr.grad + dres.float(), 1e-2, "dx")
+    close(dg, gr.grad, 1e-4, "dgamma")
+    close(db, br.grad, 1e-4, "dbeta")
+
+
+def test_layernorm_deep_specaug_mask():
+    B, T, cols = 2, 150, 384
+    g = torch.Generator().manual_seed(1)
+    x = bf(torch.randn(B * T, cols, generator=g)); gamma = torch.randn(cols, generator=g); beta = torch.randn(cols, generator=g)
+    y, mean, rstd = K.layernorm_fwd(x.to(DEV), gamma.to(DEV), beta.to(DEV), mask=(T, 10, 35, 100, 120))
+    ref = O.layer_norm(x.float(), gamma, beta).view(B, T, cols).clone()
+    ref[:, 10:35] = 0; ref[:, :, 100:120] = 0
+    close(y, ref.view(B * T, cols), 1e-2)
+    yc = y.view(B, T, cols)
+    assert (yc[:, 10:35] == 0).all() and (yc[:, :, 100:120] == 0).all()  # exact zeros, as masked_fill gives
+
+
+@pytest.mark.parametrize("M,N,Kd", [(256, 128, 64), (300, 256, 128), (1500, 384, 384), (4096, 1280, 1280), (1, 128, 64), (777, 1536, 5120)])
+def test_gemm_nt_and_epilogues(M, N, Kd):
+    g = torch.Generator().manual_seed(M + N)
+    a = bf(torch.randn(M, Kd, generator=g)); b = bf(torch.randn(N, Kd, generator=g))
+    bias = torch.randn(N, generator=g); res = bf(torch.randn(M, N, generator=g))
+    ref = a.float() @ b.float().t()
+    ad, bd = a.to(DEV), b.to(DEV)
+    close(K.gemm_nt(ad, bd, out_f32=True), ref, 1e-5, "f32 out")
+    close(K.gemm_nt(ad, bd, bias=bias.to(DEV), residual=res.to(DEV)), ref + bias + res.float(), 1e-2, "bias+res")
+    aux = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    out = K.gemm_nt(ad, bd, bias=bias.to(DEV), epilogue=L.EPI_GELU, aux=aux)
+    close(out, torch.nn.functional.gelu(ref + bias), 1e-2, "gelu")
+    close(aux, ref + bias, 1e-2, "gelu pre")
+    pre = aux.float().cpu().requires_grad_(True)
+    torch.nn.functional.gelu(pre).backward(torch.ones_like(pre))
+    close(K.gemm_nt(ad, bd, epilogue=L.EPI_DGELU, aux=aux), ref * pre.grad, 1e-2, "dgelu")
+    close(K.gemm_nt(ad, bd, residual=res.to(DEV), residual_first=True, epilogue=L.EPI_GELU, aux=aux),
+          torch.nn.functional.gelu(ref + res.float()), 1e-2, "residual-first gelu")
+
+
+def test_gemm_nt_rejects_bad_shapes():
+    a = torch.zeros(10, 70, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(L.WftError, match="K must be a multiple of 64"):
+        K.gemm_nt(a, torch.zeros(128, 70, dtype=torch.bfloat16, device=DEV), K=70, lda=72, ldb=72)
+    with pytest.raises(L.WftError, match="N must be a multiple of 128"):
+        K.gemm_nt(torch.zeros(10, 64, dtype=torch.bfloat16, device=DEV), torch.zeros(200, 64, dtype=torch.bfloat16, device=DEV), N=200)
+
+
+def test_conv1d_as_gemm_matches_conv():
+    B, T, Cin, Cout = 2, 100, 128, 256
+    g = torch.Generator().manual_seed(3)
+    x = bf(torch.randn(B, Cin, T, generator=g)); w = bf(torch.randn(Cout, Cin, 3, generator=g)); bias = torch.randn(Cout, generator=g)
+    xt = torch.zeros(B, T + 2, Cin); xt[:, 1:T + 1] = x.float().transpose(1, 2)
+    xt = bf(xt).to(DEV)
+    wk = w.permute(0, 2, 1).reshape(Cout, 3 * Cin).contiguous().to(DEV)
+    ref1 = torch.nn.functional.conv1d(x.float(), w.float(), bias, padding=1).transpose(1, 2)
+    out = torch.zeros((B, T + 2, Cout), dtype=torch.bfloat16, device=DEV)
+    K.gemm_nt(xt, wk, M=T, N=Cout, K=3 * Cin, lda=Cin, ldb=3 * Cin, out=out[:, 1:], ldc=Cout, bias=bias.to(DEV), batch=B,
+              strideA=(T + 2) * Cin, strideC=(T + 2) * Cout)
+    close(out[:, 1:T + 1], ref1, 1e-2, "stride 1")
+    assert (out[:, 0] == 0).all() and (out[:, T + 1] == 0).all()
+    ref2 = torch.nn.functional.conv1d(x.float(), w.float(), bias, padding=1, stride=2).transpose(1, 2)
+    out2 = K.gemm_nt(xt, wk, M=T // 2, N=Cout, K=3 * Cin, lda=2 * Cin, ldb=3 * Cin, bias=bias.to(DEV), batch=B,
+                     strideA=(T + 2) * Cin, strideC=(T // 2) * Cout)
+    close(out2.view(B, T // 2, Cout), ref2, 1e-2, "stride 2")
+
+
+@pytest.mark.parametrize("R,P,Q", [(64, 128, 128), (100, 128, 256), (1, 128, 128), (1500, 384, 384), (4097, 1280, 256), (48000, 256, 128)])
+def test_gemm_tn(R, P, Q):
+    g = torch.Generator().manual_seed(R)
+    a = bf(torch.randn(R, P, generator=g)); b = bf(torch.randn(R, Q, generator=g))
+    ref = a.float().t() @ b.float()
+    close(K.gemm_tn(a.to(DEV), b.to(DEV)), ref, 2e-5, "tn")
+    c = torch.ones(P, Q, device=DEV)
+    K.gemm_tn(a.to(DEV), b.to(DEV), out=c, accumulate=True)
+    close(c, ref + 1, 2e-5, "tn accumulate")
+
+
+def _ref_attn(q, k, v, H, causal, scale):
+    B, Tq, D = q.shape
+    Tk = k.shape[1]
+    qh = q.view(B, Tq, H, 64).transpose(1, 2); kh = k.view(B, Tk, H, 64).transpose(1, 2); vh = v.view(B, Tk, H, 64).transpose(1, 2)
+    s = (qh @ kh.transpose(-1, -2)) * scale
+    if causal:
+        s = s + torch.full((Tq, Tk), float("-inf")).triu_(1)
+    return (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, Tq, D), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk,causal", [(2, 6, 1500, 1500, False), (2, 4, 128, 128, True), (3, 2, 37, 37, True),
+                                              (2, 6, 50, 1500, False), (1, 20, 448, 448, True), (2, 2, 200, 77, False), (1, 1, 1, 1, True)])
+def test_attention_fwd_bwd(B, H, Tq, Tk, causal):
+    D = H * 64
+    g = torch.Generator().manual_seed(Tq * 7 + Tk)
+    q = bf(torch.randn(B, Tq, D, generator=g)); kv = bf(torch.randn(B, Tk, 2 * D, generator=g))
+    k, v = kv[..., :D], kv[..., D:]
+    qd, kvd = q.to(DEV), kv.to(DEV)
+    o, lse = K.attn_fwd(qd, kvd[..., :D], kvd[..., D:], H, causal, 0.125)
+    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
+    oref, lref = _ref_attn(qr, kr, vr, H, causal, 0.125)
+    close(o, oref, 2e-2, "o"); close(lse, lref, 1e-4, "lse")
+    do = bf(torch.randn(B, Tq, D, generator=g))
+    oref.backward(do.float())
+    dq, dk, dv = K.attn_bwd(qd, kvd[..., :D], kvd[..., D:], o, lse, do.to(DEV), H, causal, 0.125)
+    close(dq, qr.grad, 2e-2, "dq"); close(dk, kr.grad, 2e-2, "dk"); close(dv, vr.grad, 2e-2, "dv")
+
+
+def test_attention_forced_rescale_branch():
+    """online-softmax rescale: one key far above the rest in a late tile (cdna guide rule 26)."""
+    B, H, T = 1, 1, 256
+    g = torch.Generator().manual_seed(0)
+    q = torch.randn(B, T, 64, generator=g); k = torch.randn(B, T, 64, generator=g); v = torch.randn(B, T, 64, generator=g)
+    k[0, 200] = q[0, 17] * 40.0
+    qd, kd, vd = (bf(t).to(DEV) for t in (q, k, v))
+    o, lse = K.attn_fwd(qd, kd, vd, H, False, 0.125)
+    oref, lref = _ref_attn(bf(q).float(), bf(k).float(), bf(v).float(), H, False, 0.125)
+    close(o, oref, 2e-2); close(lse, lref, 1e-4)
+
+
+def test_embedding_and_cross_entropy():
+    B, S, d, V = 3, 17, 384, 1000
+    g = torch.Generator().manual_seed(2)
+    tok = torch.randint(0, V, (B, S), generator=g); emb = torch.randn(V, d, generator=g); pos = torch.randn(448, d, generator=g)
+    out = K.embed_fwd(tok.to(DEV), emb.to(DEV), pos.to(DEV))
+    close(out, emb[tok] + pos[:S], 1e-2)
+    dout = bf(torch.randn(B, S, d, generator=g))
+    demb = torch.zeros(V, d, device=DEV); dpos = torch.zeros(448, d, device=DEV)
+    K.embed_bwd(tok.to(DEV), dout.to(DEV), demb, dpos)
+    close(demb, torch.zeros(V, d).index_add_(0, tok.view(-1), dout.float().view(-1, d)), 1e-6)
+    close(dpos[:S], dout.float().sum(0), 1e-6)
+    for V, eps in ((51865, 0.0), (51866, 0.1), (1000, 0.05)):
+        rows, ld = 50, K.round_up(V, 128)
+        logits = bf(torch.randn(rows, ld, generator=g) * 3)
+        tgt = torch.randint(0, V, (rows,), generator=g); tgt[::7] = -100
+        lr = logits[:, :V].float().requires_grad_(True)
+        ref = O.cross_entropy(lr.unsqueeze(0), tgt.unsqueeze(0), eps)
+        (ref * 0.25).backward()
+        ld_dev = logits.to(DEV)
+        row_loss, row_lse, stats, am = K.ce_fwd(ld_dev, tgt.to(DEV), V, eps, want_argmax=True)
+        close((stats[0] / stats[1]).reshape(1), ref.reshape(1), 2e-5, "loss")  # fp32 sum of 5e4 exps, different order
+        assert torch.equal(am.cpu(), lr.argmax(-1))  # teacher-forced argmax: bit-exact token ids
+        dl = K.ce_bwd(ld_dev, tgt.to(DEV), V, eps, row_lse, stats, torch.tensor([0.25], device=DEV))
+        close(dl[:, :V], lr.grad, 1e-2, "dlogits")
+        assert (dl[:, V:] == 0).all()
+    # all-ignored batch edge case: loss 0/0 is NaN in torch as well; here stats[1] == 0
+    _, _, stats, _ = K.ce_fwd(bf(torch.randn(4, 128)).to(DEV), torch.full((4,), -100).to(DEV), 100, 0.0)
+    assert stats[1].item() == 0 and stats[0].item() == 0
+
+
+@pytest.mark.parametrize("n_mels", [80, 128])
+def test_logmel_matches_oracle_and_golden(n_mels, golden_logmel):
+    clips = []
+    for i in range(2):
+        a = torch.randn(O.N_SAMPLES, generator=torch.Generator().manual_seed(1234 + i)) * 0.1
+        if i == 1:
+            a[200000:] = 0.0
+            a[:200000] *= torch.linspace(0.0, 1.0, 200000)
+        clips.append(a)
+    t = np.arange(O.N_SAMPLES) / 16000.0
+    clips.append(torch.from_numpy((0.3 * np.sin(2 * np.pi * (200.0 + 120.0 * t) * t)).astype(np.float32)))
+    audio = torch.stack(clips)
+    got = K.logmel(audio.to(DEV), O.mel_filters(n_mels).to(DEV)).cpu()
+    ref = O.log_mel_spectrogram(audio, n_mels)
+    d = (got - ref).abs()
+    assert d.max() < 2e-3 and d.mean() < 1e-5, (d.max(), d.mean())
+    dg = np.abs(got[:, :, ::7].numpy() - golden_logmel[f"mel{n_mels}_sub"])
+    assert np.quantile(dg, 0.999) < 2e-4 and dg.max() < 5e-3
+
+
+def test_specaug_matches_reference_golden(golden_host):
+    """time-warp + masks kernel vs the reference's own TimeWarpAugmenter output.  Tolerance 1e-3 absolute: the
+    warped sample position (~1e3 frames) carries fp32 rounding of ~1e-4 frames in both implementations."""
+    spec = torch.from_numpy(golden_host["tw_spec"])
+    for i in range(3):
+        wp, wd = (int(v) for v in golden_host[f"tw_params{i}"])
+        params = torch.tensor([[1, wp, wd, 0, 0, 0, 0, 0]], dtype=torch.int32, device=DEV)
+        got = K.specaug(spec[None].to(DEV), params).cpu()[0]
+        assert (got - torch.from_numpy(golden_host[f"tw_out{i}"])).abs().max() < 1e-3
+    # masks + extremes are exact
+    mel = torch.randn(2, 16, 300)
+    params = torch.tensor([[0, 0, 0, 100, 180, 3, 9, 0], [0, 0, 0, 290, 300, 0, 0, 0]], dtype=torch.int32, device=DEV)
+    ext = torch.tensor([[2, 3], [0, 0]], dtype=torch.int32, device=DEV)
+    got = K.specaug(mel.to(DEV), params, ext).cpu()
+    ref0 = O.spec_augment(mel[0], None, (100, 180), (3, 9), (2, 3)); ref1 = O.spec_augment(mel[1], None, (290, 300), (0, 0))
+    assert torch.equal(got[0], ref0) and torch.equal(got[1], ref1)
+    tm = K.mel_to_tmajor(mel.to(DEV), 128).cpu()
+    ref_t = torch.zeros(2, 302, 128); ref_t[:, 1:301, :16] = mel.transpose(1, 2)
+    assert torch.equal(tm, bf(ref_t))
+
+
+def test_adamw_matches_torch():
+    n = 100003
+    g = torch.Generator().manual_seed(0)
+    p0 = torch.randn(n, generator=g); grad = torch.randn(n, generator=g)
+    pr = torch.nn.Parameter(p0.clone()); pr.grad = grad * 0.5
+    opt = torch.optim.AdamW([pr], lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.1)
+    p = p0.to(DEV); gd = grad.to(DEV); m = torch.zeros(n, device=DEV); v = torch.zeros(n, device=DEV)
+    gs = torch.tensor([0.5], device=DEV)
+    for step in (1, 2, 3):
+        opt.step()
+        K.adamw_step(p, gd, m, v, None, 1e-3, 0.9, 0.98, 1e-6, 0.1, 1 - 0.9 ** step, 1 - 0.98 ** step, gs)
+    close(p, pr.data, 1e-6)
+    out = torch.zeros(1, device=DEV)
+    K.sumsq(gd, out)
+    close(out, (grad.double() ** 2).sum().float().reshape(1), 1e-5)
+
+
+# ---- BASELINE-size (large-v3, 32 clips) size-independent properties -------------------------------------------
+def test_full_size_gemm_linearity_and_identity():
+    M, N, Kd = 48000, 1280, 1280
+    g = torch.Generator(device=DEV).manual_seed(0)
+    a1 = bf(torch.randn(M, Kd, device=DEV, generator=g)); a2 = bf(torch.randn(M, Kd, device=DEV, generator=g))
+    eye = bf(torch.eye(N, Kd, device=DEV))
+    assert torch.equal(K.gemm_nt(a1, eye), a1)  # A @ I^T == A exactly
+    w = bf(torch.randn(N, Kd, device=DEV, generator=g) * 0.05)
+    y1 = K.gemm_nt(a1, w, out_f32=True); y2 = K.gemm_nt(a2, w, out_f32=True)
+    s = bf(a1.float() + a2.float())  # rounded sum: compare against the GEMM of exactly that operand
+    r = K.gemm_nt(s, w, out_f32=True)
+    lin = y1 + y2
+    resid = (s.float() - (a1.float() + a2.float()))
+    corr = K.gemm_nt(bf(resid), w, out_f32=True)  # first-order correction for the operand rounding
+    assert ((r - lin - corr).abs().max() / lin.abs().max()).item() < 2e-3
+
+
+def test_full_size_attention_rows_are_convex_combinations():
+    B, H, T = 4, 20, 1500
+    g = torch.Generator(device=DEV).manual_seed(1)
+    q = bf(torch.randn(B, T, H * 64, device=DEV, generator=g)); k = bf(torch.randn(B, T, H * 64, device=DEV, generator=g))
+    v = torch.ones(B, T, H * 64, device=DEV, dtype=torch.bfloat16)
+    o, lse = K.attn_fwd(q, k, v, H, False, 0.125)
+    assert (o.float() - 1).abs().max().item() < 1e-2  # softmax weights sum to 1
+    dq, dk, dv = K.attn_bwd(q, k, v, o, lse, torch.ones_like(o), H, False, 0.125)
+    assert dq.float().abs().max().item() < 2e-2 and dk.float().abs().max().item() < 2e-2  # d(softmax)·1 = 0
+    assert (dv.float().view(B, T, H, 64).sum(1) - T).abs().max().item() < 0.02 * T  # each head's weights sum to T over queries
+
+
+def test_full_size_ce_gradient_rows_sum_to_zero():
+    rows, V = 4096, 51866
+    ld = K.round_up(V, 128)
+    g = torch.Generator(device=DEV).manual_seed(2)
+    logits = bf(torch.randn(rows, ld, device=DEV, generator=g))
+    tgt = torch.randint(0, V, (rows,), device=DEV, generator=g)
+    _, lse, stats, am = K.ce_fwd(logits, tgt, V, 0.1, want_argmax=True)
+    assert torch.equal(am, logits[:, :V].float().argmax(-1))
+    dl = K.ce_bwd(logits, tgt, V, 0.1, lse, stats, torch.ones(1, device=DEV), inplace=False)
+    assert dl[:, :V].float().sum(-1).abs().max().item() < 1e-4

@@ -1,0 +1,228 @@
+"""Whole-path GPU parity: the libwft engine (through whisper_finetune's reference-shaped interface) against the
+golden fixture (HF transformers), the CPU oracle, and the reference's training-time extras.
+bf16 tolerance (stated per check): activations are rounded to bf16 between kernels (8 mantissa bits), so
+logits agree to ~1e-2 relative L2, the mean loss to 2e-3 relative, gradients to 5e-2 relative L2."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import whisper_oracle as O  # noqa: E402
+from tests.golden.gen_golden import ARCH_DIMS, arch_inputs, arch_params  # noqa: E402
+from whisper_finetune.engine import kernels as K  # noqa: E402
+from whisper_finetune.engine.whisper_model import MODEL_DIMS, ModelDimensions, Whisper  # noqa: E402
+from whisper_finetune.model import lora as lora_mod  # noqa: E402
+from whisper_finetune.model import model_utils  # noqa: E402
+
+DEV = torch.device("cuda:0")
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-20)).item()
+
+
+def _engine(dims: O.ModelDimensions, params):
+    m = Whisper(ModelDimensions(**vars(dims)))
+    m.load_state_dict(params)
+    return m.to(DEV)
+
+
+def test_engine_matches_hf_golden(golden_arch):
+    dims = ARCH_DIMS
+    m = _engine(dims, arch_params(dims, 3)).train()
+    mel, y_in, y_out = arch_inputs(dims, 11)
+    loss = m(mel.to(DEV), y_in.to(DEV), targets=y_out.to(DEV), label_smoothing=0.1)
+    loss.backward()
+    ref_loss = float(golden_arch["loss"])
+    assert abs(loss.item() - ref_loss) < 2e-3 * ref_loss, (loss.item(), ref_loss)
+    m.eval()
+    with torch.no_grad():
+        logits = m(mel.to(DEV), y_in.to(DEV))
+    assert logits.dtype == torch.float32 and logits.shape == (2, 12, dims.n_vocab)
+    assert rel(logits, torch.from_numpy(golden_arch["logits"])) < 2e-2
+    named = dict(m.named_parameters())
+    for n, ref in zip([str(x) for x in golden_arch["grad_norm_names"]], golden_arch["grad_norms"]):
+        got = named[n].grad.norm().item()
+        assert abs(got - ref) < 6e-2 * ref + 1e-6, (n, got, ref)
+    for key in golden_arch.files:
+        if key.startswith("grad::"):
+            assert rel(named[key[6:]].grad, torch.from_numpy(golden_arch[key])) < 6e-2, key
+
+
+def _tiny_case(B=2, S=24, seed=0):
+    dims = O.DIMS["tiny"]
+    params = O.init_params(dims, seed=seed)
+    g = torch.Generator().manual_seed(5)
+    for k, v in params.items():
+        if k.endswith("bias"):
+            params[k] = torch.randn(v.shape, generator=g) * 0.02
+        elif "ln" in k and k.endswith("weight"):
+            params[k] = 1 + torch.randn(v.shape, generator=g) * 0.05
+    audio, y_in, y_out = O.synthetic_batch(dims, B, S)
+    y_out[0, :3] = -100
+    return dims, params, audio, y_in, y_out
+
+
+def test_tiny_training_step_matches_oracle():
+    """configs[0]-shaped case (whisper-tiny, 2 synthetic 30 s clips): log-mel on the GPU, forward, fused
+    label-smoothed CE, backward — against the fp32 CPU oracle."""
+    dims, params, audio, y_in, y_out = _tiny_case()
+    p_req = {k: v.clone().requires_grad_(k != "encoder.positional_embedding") for k, v in params.items()}
+    mel_ref = O.log_mel_spectrogram(audio, dims.n_mels)
+    loss_ref = O.cross_entropy(O.Oracle(dims, p_req).forward(mel_ref, y_in), y_out, 0.1)
+    loss_ref.backward()
+    m = _engine(dims, params).train()
+    mel = K.logmel(audio.to(DEV), O.mel_filters(dims.n_mels).to(DEV))
+    assert (mel.cpu() - mel_ref).abs().max() < 2e-3
+    loss = m(mel, y_in.to(DEV), targets=y_out.to(DEV), label_smoothing=0.1)
+    loss.backward()
+    assert abs(loss.item() - loss_ref.item()) < 2e-3 * loss_ref.item()
+    errs = {n: rel(p.grad, p_req[n].grad) for n, p in m.named_parameters()}
+    assert max(errs.values()) < 8e-2, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    assert float(np.median(list(errs.values()))) < 2e-2
+    # fused loss == the reference's two-step form on the same logits
+    m.eval()
+    with torch.no_grad():
+        logits = m(mel, y_in.to(DEV))
+        two_step = torch.nn.functional.cross_entropy(logits.transpose(1, 2), y_out.to(DEV), label_smoothing=0.1)
+    assert abs(two_step.item() - loss.item()) < 1e-3 * loss.item()
+
+
+def test_teacher_forced_argmax_is_bit_exact_on_the_same_logits():
+    """eval/evaluator.py:70-73: argmax over the padded batch.  The kernel's argmax equals torch's argmax of the
+    logits the engine returns (ids bit-exact); against the fp32 oracle only near-ties may differ."""
+    dims, params, audio, y_in, y_out = _tiny_case(S=16)
+    m = _engine(dims, params).eval()
+    mel = K.logmel(audio.to(DEV), O.mel_filters(dims.n_mels).to(DEV))
+    with torch.no_grad():
+        h = m.decoder.hidden(y_in.to(DEV), m.encoder(mel))
+        padded = m.decoder.padded_logits(h)
+        _, _, _, am = K.ce_fwd(padded, y_out.reshape(-1).to(DEV), dims.n_vocab, 0.0, want_argmax=True)
+        logits = m(mel, y_in.to(DEV))
+    assert torch.equal(am.view(2, 16), logits.argmax(-1))
+    ref = O.Oracle(dims, params).forward(O.log_mel_spectrogram(audio, dims.n_mels), y_in)
+    lr = logits.cpu()
+    top2 = ref.topk(2, -1).values
+    decisive = (top2[..., 0] - top2[..., 1]) > 0.05  # margin larger than the bf16 logit error
+    assert torch.equal(lr.argmax(-1)[decisive], ref.argmax(-1)[decisive])
+
+
+def test_lora_low_rank_path_matches_oracle_parametrization():
+    dims, params, audio, y_in, y_out = _tiny_case()
+    m = Whisper(MODEL_DIMS["tiny"]); m.load_state_dict(params)
+    lora_mod.apply_lora(m, {"rank": 8, "lora_alpha": 16, "lora_dropout": 0.0})
+    gl = torch.Generator().manual_seed(9)
+    cfg = {}
+    for n, mod in m.named_modules():
+        if "parametrizations" in mod._modules:
+            ad = mod.parametrizations.weight[0]
+            with torch.no_grad():
+                ad.lora_B.copy_(torch.randn(ad.lora_B.shape, generator=gl) * 0.05)
+            cfg[n] = (ad.lora_A.detach().clone().requires_grad_(True), ad.lora_B.detach().clone().requires_grad_(True), ad.scaling, None)
+    m.to(DEV).train()
+    mel = O.log_mel_spectrogram(audio, dims.n_mels)
+    loss_ref = O.cross_entropy(O.Oracle(dims, params, lora=cfg).forward(mel, y_in), y_out, 0.1)
+    loss_ref.backward()
+    loss = m(mel.to(DEV), y_in.to(DEV), targets=y_out.to(DEV), label_smoothing=0.1)
+    loss.backward()
+    assert abs(loss.item() - loss_ref.item()) < 2e-3 * loss_ref.item()
+    mods = dict(m.named_modules())
+    errs = []
+    for n, (A, Bm, _, _) in cfg.items():
+        ad = mods[n].parametrizations.weight[0]
+        errs += [rel(ad.lora_A.grad, A.grad), rel(ad.lora_B.grad, Bm.grad)]
+    assert max(errs) < 0.12 and float(np.median(errs)) < 3e-2, (max(errs), np.median(errs))
+    assert all(p.grad is None for n, p in m.named_parameters() if "lora" not in n)  # base stays frozen
+
+
+def test_lora_dropout_mask_is_per_input_column():
+    """minLoRA drops whole input columns of A (mask [1, in] shared by the batch): with a fixed mask the engine
+    equals the oracle's W + s*B@(A*mask)."""
+    from whisper_finetune.engine import ops
+    from whisper_finetune.engine.whisper_model import Linear
+    g = torch.Generator().manual_seed(0)
+    lin = Linear(256, 384)
+    lora_mod.add_lora_to_linear(lin, 4, 8, 0.5)
+    lin.to(DEV)
+    ad = lin.parametrizations.weight[0]
+    with torch.no_grad():
+        ad.lora_B.normal_(generator=None)
+    mask = (torch.rand(1, 256, generator=g) > 0.5).float().to(DEV) / 0.5
+    ad.draw_mask = lambda training: mask
+    x = torch.randn(10, 256, generator=g).to(DEV)
+    y = lin(x)
+    W = O.lora_effective_weight(lin.parametrizations.weight.original.detach().cpu(), ad.lora_A.detach().cpu(), ad.lora_B.detach().cpu(),
+                                ad.scaling, mask.cpu())
+    ref = x.cpu().to(torch.bfloat16).float() @ W.T + lin.bias.detach().cpu()
+    assert rel(y, ref) < 1e-2
+
+
+def test_stochastic_depth_and_deep_specaug_semantics():
+    """S1/A4: CheckpointedStochastic encoder/decoder + deep-SpecAugment hooks give the oracle's result when the
+    same host draws are replayed (skip decisions, mask spans)."""
+    dims, params, audio, y_in, y_out = _tiny_case()
+    from whisper_finetune.model.model_utils import CheckpointedStochasticAudioEncoder, CheckpointedStochasticTextDecoder
+    m = Whisper(MODEL_DIMS["tiny"])
+    m.encoder = CheckpointedStochasticAudioEncoder(dims.n_mels, dims.n_audio_ctx, dims.n_audio_state, dims.n_audio_head, dims.n_audio_layer, 0.3)
+    m.decoder = CheckpointedStochasticTextDecoder(dims.n_vocab, dims.n_text_ctx, dims.n_text_state, dims.n_text_head, dims.n_text_layer, 0.3)
+    m.load_state_dict(params)
+    m.to(DEV).train()
+    model_utils.register_deep_spec_augment_hooks(m, time_mask_param=100, freq_mask_param=27, p=1.0)
+    mel = O.log_mel_spectrogram(audio, dims.n_mels)
+    # replay the host RNG to know what the engine will draw: per encoder block [skip?] then (if kept and not the last
+    # block) 4 rands for the masks; then per decoder block [skip?]
+    torch.manual_seed(77)
+    state = torch.get_rng_state()
+    enc_skips, masks = [], {}
+    for i in range(dims.n_audio_layer):
+        s = torch.rand(1).item() < 0.3
+        enc_skips.append(s)
+        if not s and i < dims.n_audio_layer - 1:
+            t0, t1 = O.draw_mask_span(100, dims.n_audio_ctx)
+            c0, c1 = O.draw_mask_span(27, dims.n_audio_state)
+            masks[i] = (t0, t1, c0, c1)
+    dec_skips = [torch.rand(1).item() < 0.3 for _ in range(dims.n_text_layer)]
+    ref_logits = O.Oracle(dims, params).forward(mel, y_in, enc_sd_p=0.3, enc_training=True, enc_skips=enc_skips, enc_ln_masks=masks,
+                                                dec_sd_p=0.3, dec_training=True, dec_skips=dec_skips)
+    ref_loss = O.cross_entropy(ref_logits, y_out, 0.0)
+    torch.set_rng_state(state)
+    loss = m(mel.to(DEV), y_in.to(DEV), targets=y_out.to(DEV), label_smoothing=0.0)
+    assert abs(loss.item() - ref_loss.item()) < 3e-3 * ref_loss.item(), (loss.item(), ref_loss.item(), enc_skips, dec_skips)
+    loss.backward()  # checkpoint recompute replays the same draws
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+
+
+def test_train_step_loss_sequence_decreases_and_matches_first_step():
+    """T: the reference-shaped train_step (accumulation 2, clip, AdamW) over the engine; first-step loss equals the
+    oracle's, and a few steps on a fixed batch reduce the loss."""
+    dims, params, audio, y_in, y_out = _tiny_case(B=2, S=12)
+    mel = O.log_mel_spectrogram(audio, dims.n_mels)
+    m = _engine(dims, params)
+    opt = torch.optim.AdamW(m.parameters(), lr=2e-4)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: 1.0)
+    t_cfg = {"mixed_precision_training": True, "accum_grad_steps": 2, "max_grad_norm": 1.0, "mp_dtype": "bf16", "label_smoothing": 0.1}
+
+    def batches():
+        while True:
+            yield mel, y_in, y_out
+
+    first = model_utils.train_step(m, batches(), opt, sched, t_cfg)
+    ref = O.train_step_loss(O.Oracle(dims, params), [(mel, y_in, y_out)] * 2, 2, 0.1).item()
+    assert abs(first - ref) < 2e-3 * ref
+    last = first
+    for _ in range(4):
+        last = model_utils.train_step(m, batches(), opt, sched, t_cfg)
+    assert last < first - 0.05
+
+
+def test_save_model_round_trip(tmp_path):
+    dims, params, *_ = _tiny_case()
+    m = _engine(dims, params)
+    path = tmp_path / "ckpt.pt"
+    model_utils.save_model(m, str(path))
+    ck = torch.load(path, map_location="cpu")
+    assert set(ck) == {"model_state_dict", "dims"} and ck["dims"]["n_audio_state"] == 384
+    assert all(v.dtype == torch.float16 for k, v in ck["model_state_dict"].items() if v.is_floating_point())
+    assert set(ck["model_state_dict"]) == set(params)

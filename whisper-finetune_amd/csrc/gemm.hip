@@ -183,7 +183,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmP p) {
   const int p0 = tp << 7, q0 = tq << 7;
 
   const int tpb = (R + 63) >> 6;  // reduction tiles per batch item
-  const int nsteps = tpb * p.batch;
+  const int nsteps_all = tpb * p.batch;
+  // split-K: blockIdx.y owns a contiguous range of reduction steps; partial tiles are summed into C
+  // with fp32 atomics issued as whole 256-byte rows (MI355X_MICROARCH.md "Global float atomics")
+  const int nsplit = gridDim.y;
+  const int per = (nsteps_all + nsplit - 1) / nsplit;
+  const int s_begin = blockIdx.y * per;
+  const int s_end = (s_begin + per) < nsteps_all ? (s_begin + per) : nsteps_all;
+  const int nsteps = s_end - s_begin;
+  if (nsteps <= 0) return;
 
   // staging: instruction i (0..15) covers r rows 4i..4i+3; lane -> (rr = lane>>4, c' = lane&15)
   const int rr = lane >> 4, cp = lane & 15;
@@ -225,9 +233,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmP p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  stage(0, 0);
+  stage(0, s_begin);
   __syncthreads();
-  if (zero_tail(0, 0)) __syncthreads();
+  if (zero_tail(0, s_begin)) __syncthreads();
 
   const int g = lane >> 4, li = lane & 15;
   const int r_in = (li >> 2);               // row within the 4-row block
@@ -236,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmP p) {
   const int colp = wp * 64 + 4 * (li & 3);  // + jp*16
   for (int step = 0; step < nsteps; ++step) {
     const int cur = step & 1;
-    if (step + 1 < nsteps) stage(cur ^ 1, step + 1);
+    if (step + 1 < nsteps) stage(cur ^ 1, s_begin + step + 1);
     const char* sa = smem + cur * 32768;
     const char* sb = sa + 16384;
 #pragma unroll
@@ -269,8 +277,28 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmP p) {
     }
     __syncthreads();
     if (step + 1 < nsteps) {
-      if (zero_tail(cur ^ 1, step + 1)) __syncthreads();
+      if (zero_tail(cur ^ 1, s_begin + step + 1)) __syncthreads();
     }
+  }
+
+  if (nsplit > 1) {
+    // stage the wave's 64(p) x 64(q) fp32 tile through LDS (two halves of 32 p-rows, row pitch 68
+    // floats) so that every atomic wave-instruction adds one contiguous 256-byte row of C
+    float* lds = (float*)(smem + wave * 16384);
+    float* cbase = (float*)p.C + (long)(p0 + wp * 64) * p.ldc + q0 + wq * 64 + lane;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          *(f32x4*)(lds + (jj * 16 + li) * 68 + i * 16 + 4 * g) = acc[i][half * 2 + jj] * p.alpha;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 8
+      for (int r = 0; r < 32; ++r) atomicAdd(cbase + (long)(half * 32 + r) * p.ldc, lds[r * 68 + lane]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    return;
   }
 
   // epilogue: D[q][p]: col (lane&15) = p index, rows 4*(lane>>4)+e = q index
@@ -354,8 +382,22 @@ extern "C" int wft_gemm_tn_bf16(const wft_gemm_args* a, void* stream) {
   GemmP p;
   fill_params(a, p);
   const long tiles = (a->M / 128) * (a->N / 128);
-  dim3 grid((unsigned)tiles), block(256);
+  // split-K factor: fill the 512 resident-block slots (256 CUs x 2) in whole waves
+  const long nsteps = ((a->K + 63) / 64) * a->batch;
+  int nsplit = 1;
+  if (a->c_is_f32) {
+    double best = 0.0;
+    for (int sp = 1; sp <= 8; ++sp) {
+      if (sp > 1 && nsteps / sp < 16) break;
+      const double waves = (double)(tiles * sp) / 512.0;
+      const double eff = waves / (double)((long)(waves + 0.999999));
+      if (eff > best + 0.03) { best = eff; nsplit = sp; }
+    }
+  }
   hipStream_t s = (hipStream_t)stream;
+  if (nsplit > 1 && !a->accumulate)
+    (void)hipMemset2DAsync(a->C, (size_t)a->ldc * 4, 0, (size_t)a->N * 4, (size_t)a->M, s);
+  dim3 grid((unsigned)tiles, (unsigned)nsplit), block(256);
   if (a->c_is_f32) hipLaunchKernelGGL((gemm_tn_kernel<true>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((gemm_tn_kernel<false>), grid, block, 0, s, p);
   WFT_CHECK_LAUNCH();

@@ -185,22 +185,37 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const unsigned short* dy, c
   }
 }
 
+// sums the per-block partials: block = 32 columns x 8 row-lanes, LDS tree over the row-lanes
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* partial, int nblocks, int cols,
                                                              float* dgamma, float* dbeta) {
-  const int col = blockIdx.x * 256 + threadIdx.x;
-  if (col >= cols) return;
+  __shared__ float red[2][8][33];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + cx;
   float sg = 0.f, sb = 0.f;
-  for (int b = 0; b < nblocks; ++b) {
-    sg += partial[(long)b * 2 * cols + col];
-    sb += partial[(long)b * 2 * cols + cols + col];
+  if (col < cols) {
+    for (int b = ry; b < nblocks; b += 8) {
+      sg += partial[(long)b * 2 * cols + col];
+      sb += partial[(long)b * 2 * cols + cols + col];
+    }
   }
-  dgamma[col] += sg;
-  dbeta[col] += sb;
+  red[0][ry][cx] = sg;
+  red[1][ry][cx] = sb;
+  __syncthreads();
+  if (ry == 0 && col < cols) {
+    float tg = 0.f, tb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      tg += red[0][k][cx];
+      tb += red[1][k][cx];
+    }
+    dgamma[col] += tg;
+    dbeta[col] += tb;
+  }
 }
 
 static int ln_grid(long rows) {
   long g = (rows + 3) / 4;
-  if (g > 1024) g = 1024;
+  if (g > 512) g = 512;
   if (g < 1) g = 1;
   return (int)g;
 }
@@ -229,7 +244,7 @@ extern "C" int wft_layernorm_bwd(const wft_bf16* dy, const wft_bf16* x, const fl
   const int grid = ln_grid(rows);
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean, rstd,
                      dres, dx, (float*)partial, (long)rows, cols, rows_per_batch, t0, t1, c0, c1);
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((cols + 31) / 32), dim3(256), 0, (hipStream_t)stream,
                      (const float*)partial, grid, cols, dgamma, dbeta);
   WFT_CHECK_LAUNCH();
   return WFT_OK;

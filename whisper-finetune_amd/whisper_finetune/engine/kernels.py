@@ -15,6 +15,10 @@ from . import lib as L
 BF16 = torch.bfloat16
 F32 = torch.float32
 
+# bench.py sets this to a list to time every gemm_nt launch with HIP events recorded on the
+# launch stream: entries are (start_event, end_event, algorithmic_flops).
+PROFILE_NT = None
+
 
 def _p(t: Optional[torch.Tensor]):
     return C.c_void_p(0 if t is None else t.data_ptr())
@@ -180,6 +184,13 @@ def gemm_nt(a, b, *, M=None, N=None, K=None, lda=None, ldb=None, out=None, out_f
     args.M, args.N, args.K, args.batch = M, N, K, batch
     args.valid_rows_period, args.valid_rows = valid_rows_period, valid_rows
     args.residual_first = int(residual_first)
+    if PROFILE_NT is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        L.check(L.load().wft_gemm_nt_bf16(C.byref(args), L.stream_ptr()), "wft_gemm_nt_bf16")
+        ev1.record()
+        PROFILE_NT.append((ev0, ev1, 2.0 * M * N * K * batch))
+        return out
     L.check(L.load().wft_gemm_nt_bf16(C.byref(args), L.stream_ptr()), "wft_gemm_nt_bf16")
     return out
 
