@@ -60,12 +60,24 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// erf with |abs err| < 1.5e-7 (Abramowitz & Stegun 7.1.26): 1 rcp + 1 exp + 6 fma instead of
+// ocml's erff (~3x the VALU); far below the bf16 resolution of every consumer.
+__device__ __forceinline__ float erf_fast(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float y = 1.0f - poly * t * __expf(-ax * ax);
+  return copysignf(y, x);
+}
 // exact-erf GELU (torch.nn.GELU default / F.gelu)
 __device__ __forceinline__ float gelu_f(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f));
 }
 __device__ __forceinline__ float dgelu_f(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f));
   const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
   return cdf + x * pdf;
 }

@@ -12,6 +12,7 @@
 // MFMA operands are swapped (D^T = B·A^T) so that each lane ends up with 4 consecutive
 // output columns of one row: 8-byte bf16 / 16-byte f32 stores.
 #include "common.h"
+#include <stdlib.h>
 
 struct GemmP {
   const unsigned short* A; long lda; long sA;
@@ -25,6 +26,7 @@ struct GemmP {
   int accumulate;
   int period, valid;
   int res_first;
+  int diag;  // timing-only diagnostic builds of the 256 kernel (WFT_GEMM_DIAG): 1 no vmcnt wait, 2 no staging loads, 3 = 2 + no barrier
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int ntile) {
@@ -160,6 +162,242 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
         unsigned short* cp = (unsigned short*)p.C + cb + (long)m * p.ldc + n;
         u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
         *(u32x2*)cp = pk;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------- NT 256x256
+// Large-shape variant: 256x256 output tile, 512 threads (8 waves as 2(M) x 4(N), 128x64 per wave), one
+// workgroup per CU, LDS = ring of four 32-deep k-slabs (4 x {A [256][32], B [256][32]} = 128 KiB).
+//
+// Measured on the first version (all waves in lockstep, 64-deep tiles): the MFMA pipe was busy 44 % of
+// the time; removing the global_load_lds (timing-only build) gave +38 %, i.e. the ~100-cycle issue cost
+// of each LDS-DMA instruction was serialised in front of the MFMAs of BOTH waves of a SIMD.  This version
+// is a ping-pong: waves 0-3 and 4-7 (SIMD partners) run half a period apart, separated by s_barrier —
+//   L-unit: issue 4 global_load_lds (this wave's share of slab u+3) + 12 ds_read_b128 (slab u fragments)
+//   C-unit: 32 MFMAs (16x16x32 bf16) on those fragments
+// so one partner's loads always sit beside the other partner's MFMAs.  Loads run three slabs (six
+// half-periods) ahead behind a COUNTED s_waitcnt vmcnt(8): never drained inside the loop.
+__device__ __forceinline__ int nt_g(int row) { return (4 - ((row >> 2) & 3)) & 3; }  // 64-byte-row swizzle
+
+template <int EPI, bool C_F32>
+__global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char dsmem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const bool grp_b = wave >= 4;
+  const int tiles_n = p.N >> 8;
+  const int tiles_m = (p.M + 255) >> 8;
+  const int sid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int tm = sid / tiles_n, tn = sid - tm * tiles_n;
+  const int m0 = tm << 8, n0 = tn << 8;
+  const int bz = blockIdx.z;
+
+  // staging share of this wave: group A (waves 0-3) loads the A part of every slab, group B the B part;
+  // wave-instruction = 16 rows x 64 B; this wave owns rows 64*(wave&3) .. +63 of its part (4 instructions)
+  const int rr = lane >> 2, cc = lane & 3;
+  const unsigned short* src[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (wave & 3) * 64 + j * 16 + rr;
+    const int chunk = cc ^ nt_g(rr);
+    if (!grp_b) {
+      int gm = m0 + row;
+      gm = gm < p.M ? gm : p.M - 1;
+      src[j] = p.A + (long)bz * p.sA + (long)gm * p.lda + chunk * 8;
+    } else {
+      src[j] = p.B + (long)bz * p.sB + (long)(n0 + row) * p.ldb + chunk * 8;
+    }
+  }
+  char* const stage_dst = dsmem + (grp_b ? 16384 : 0) + (wave & 3) * 4096;
+  auto stage = [&](int u) {  // this wave's 4 KiB of slab u -> ring slot u & 3
+    char* dst = stage_dst + (u & 3) * 32768;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) glds16(src[j] + u * 32, dst + j * 1024);
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nslab = p.K >> 5;
+  const int frow = lane & 15, fg = lane >> 4;
+  const int coff = (fg ^ nt_g(frow)) << 4;
+  const int a_off = (wm * 128 + frow) * 64 + coff;
+  const int b_off = 16384 + (wn * 64 + frow) * 64 + coff;
+  bf16x8 af[8], bq[4];
+
+  // prologue: shares of slabs 0..2 in flight, slab 0 complete
+  stage(0);
+  if (nslab > 1) stage(1);
+  if (nslab > 2) stage(2);
+  if (nslab > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (nslab > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (grp_b) __builtin_amdgcn_s_barrier();  // group B runs half a period behind group A
+
+  for (int u = 0; u < nslab; ++u) {
+    // ---------------- L-unit
+    if (u + 3 < nslab) stage(u + 3);
+    {
+      const char* sl = dsmem + (u & 3) * 32768;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bq[j] = *(const bf16x8*)(sl + b_off + j * 1024);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) af[i] = *(const bf16x8*)(sl + a_off + i * 1024);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // slab u+1's share (issued three L-units ago) must have landed before the partner group reads it
+    const int ahead = nslab - 1 - u;
+    if (ahead >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (ahead == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---------------- C-unit
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[j], af[i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  }
+  if (!grp_b) __builtin_amdgcn_s_barrier();  // group A idles through group B's last C-unit
+
+  const long cb = (long)bz * p.sC;
+  if (!C_F32 && p.diag != 6) {
+    // ---- epilogue through LDS: the ring is free now.  Each wave round-trips its 128x64 fp32 tile in four
+    // passes of 32 rows (row pitch 68 floats) so that every global access below is 16 bytes per lane with 8
+    // lanes covering one full 128-byte line (bias / residual / aux / C), instead of 8-byte pieces of 16 lines.
+    float* lds = (float*)(dsmem + wave * 8704);
+    const int er = lane >> 3, ec = (lane & 7) * 8;  // row within an 8-row group, first of this lane's 8 columns
+    const int ncol = n0 + wn * 64 + ec;
+    float bias8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+    if (p.bias) {
+      const f32x4 b0 = *(const f32x4*)(p.bias + ncol), b1 = *(const f32x4*)(p.bias + ncol + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
+    }
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+          *(f32x4*)(lds + (ii * 16 + frow) * 68 + jj * 16 + fg * 4) = acc[pass * 2 + ii][jj];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int g8 = 0; g8 < 4; ++g8) {
+        const int lr = g8 * 8 + er;
+        const int m = m0 + wm * 128 + pass * 32 + lr;
+        const f32x4 x0 = *(const f32x4*)(lds + lr * 68 + ec), x1 = *(const f32x4*)(lds + lr * 68 + ec + 4);
+        if (m < p.M) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] = x0[e] * p.alpha + bias8[e]; v[4 + e] = x1[e] * p.alpha + bias8[4 + e]; }
+          const long roff = (long)m;
+          if (p.res && p.res_first) {
+            const u32x4 r4 = *(const u32x4*)(p.res + (long)bz * p.sR + roff * p.ldr + ncol);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] += bf2f((unsigned short)(r4[e] & 0xffff)); v[2 * e + 1] += bf2f((unsigned short)(r4[e] >> 16)); }
+          }
+          if (EPI == WFT_EPI_GELU) {
+            if (p.aux) {
+              u32x4 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+              *(u32x4*)(p.aux + (long)bz * p.sAux + roff * p.ldaux + ncol) = pk;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+          } else if (EPI == WFT_EPI_DGELU) {
+            const u32x4 a4 = *(const u32x4*)(p.aux + (long)bz * p.sAux + roff * p.ldaux + ncol);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[2 * e] *= dgelu_f(bf2f((unsigned short)(a4[e] & 0xffff)));
+              v[2 * e + 1] *= dgelu_f(bf2f((unsigned short)(a4[e] >> 16)));
+            }
+          }
+          if (p.res && !p.res_first) {
+            const u32x4 r4 = *(const u32x4*)(p.res + (long)bz * p.sR + roff * p.ldr + ncol);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] += bf2f((unsigned short)(r4[e] & 0xffff)); v[2 * e + 1] += bf2f((unsigned short)(r4[e] >> 16)); }
+          }
+          if (p.period > 0 && (m % p.period) >= p.valid) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+          }
+          u32x4 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+          *(u32x4*)((unsigned short*)p.C + cb + roff * p.ldc + ncol) = pk;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + wm * 128 + i * 16 + frow;
+    if (m >= p.M) continue;
+    const bool zero_row = p.period > 0 && (m % p.period) >= p.valid;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + fg * 4;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * p.alpha;
+      if (p.bias) {
+        const f32x4 b4 = *(const f32x4*)(p.bias + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += b4[e];
+      }
+      if (p.res && p.res_first) {
+        const u32x2 r2 = *(const u32x2*)(p.res + (long)bz * p.sR + (long)m * p.ldr + n);
+        v[0] += bf2f((unsigned short)(r2[0] & 0xffff));
+        v[1] += bf2f((unsigned short)(r2[0] >> 16));
+        v[2] += bf2f((unsigned short)(r2[1] & 0xffff));
+        v[3] += bf2f((unsigned short)(r2[1] >> 16));
+      }
+      if (EPI == WFT_EPI_GELU) {
+        if (p.aux) {
+          u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+          *(u32x2*)(p.aux + (long)bz * p.sAux + (long)m * p.ldaux + n) = pk;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+      } else if (EPI == WFT_EPI_DGELU) {
+        const u32x2 a2 = *(const u32x2*)(p.aux + (long)bz * p.sAux + (long)m * p.ldaux + n);
+        v[0] *= dgelu_f(bf2f((unsigned short)(a2[0] & 0xffff)));
+        v[1] *= dgelu_f(bf2f((unsigned short)(a2[0] >> 16)));
+        v[2] *= dgelu_f(bf2f((unsigned short)(a2[1] & 0xffff)));
+        v[3] *= dgelu_f(bf2f((unsigned short)(a2[1] >> 16)));
+      }
+      if (p.res && !p.res_first) {
+        const u32x2 r2 = *(const u32x2*)(p.res + (long)bz * p.sR + (long)m * p.ldr + n);
+        v[0] += bf2f((unsigned short)(r2[0] & 0xffff));
+        v[1] += bf2f((unsigned short)(r2[0] >> 16));
+        v[2] += bf2f((unsigned short)(r2[1] & 0xffff));
+        v[3] += bf2f((unsigned short)(r2[1] >> 16));
+      }
+      if (zero_row) { v[0] = v[1] = v[2] = v[3] = 0.f; }
+      if (C_F32) {
+        float* cp = (float*)p.C + cb + (long)m * p.ldc + n;
+        f32x4 o = {v[0], v[1], v[2], v[3]};
+        if (p.accumulate) o += *(const f32x4*)cp;
+        *(f32x4*)cp = o;
+      } else {
+        unsigned short* cp = (unsigned short*)p.C + cb + (long)m * p.ldc + n;
+        u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+        if (p.diag != 5 || (pk[0] == 0x12345678u && n == 0)) *(u32x2*)cp = pk;
       }
     }
   }
@@ -322,7 +560,191 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmP p) {
   }
 }
 
+// ---------------------------------------------------------------------------------- TN 256x256
+// Weight-gradient GEMM, large-shape variant: 256(p) x 256(q) output tile, 8 waves as 2(q) x 4(p)
+// (128 q x 64 p per wave), LDS tiles [64 r][256 cols] (512-byte rows) for A and B, double buffered
+// (128 KiB).  Same transposed-read fragments and pair swizzle as the 128 kernel; split-K partials are
+// added to C with fp32 atomics as contiguous 256-byte half rows staged through LDS.
+template <bool C_F32>
+__global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char dsmem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wq = wave >> 2, wp = wave & 3;
+  const int P = p.M, Q = p.N, R = p.K;
+  const int tiles_q = Q >> 8;
+  const int tiles_p = P >> 8;
+  const int sid = xcd_remap(blockIdx.x, tiles_p * tiles_q);
+  const int tp = sid / tiles_q, tq = sid - tp * tiles_q;
+  const int p0 = tp << 8, q0 = tq << 8;
+
+  const int tpb = (R + 63) >> 6;
+  const int nsteps_all = tpb * p.batch;
+  const int nsplit = gridDim.y;
+  const int per = (nsteps_all + nsplit - 1) / nsplit;
+  const int s_begin = blockIdx.y * per;
+  const int s_end = (s_begin + per) < nsteps_all ? (s_begin + per) : nsteps_all;
+  const int nsteps = s_end - s_begin;
+  if (nsteps <= 0) return;
+
+  // staging: one wave-instruction = 2 rows of 512 B; tile = 32 instructions; wave w issues 4w..4w+3
+  const int rr = lane >> 5, cp = lane & 31;
+  auto stage = [&](int buf, int step) {
+    const int b = step / tpb, t = step - b * tpb;
+    const unsigned short* Ab = p.A + (long)b * p.sA;
+    const unsigned short* Bb = p.B + (long)b * p.sB;
+    char* sa = dsmem + buf * 65536 + wave * 4096;
+    char* sb = sa + 32768;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = (wave * 4 + j) * 2 + rr;
+      int gr = t * 64 + r;
+      gr = gr < R ? gr : R - 1;
+      const int c = cp ^ (tn_f(r) << 1);
+      glds16(Ab + (long)gr * p.lda + p0 + (c << 3), sa + j * 1024);
+      glds16(Bb + (long)gr * p.ldb + q0 + (c << 3), sb + j * 1024);
+    }
+  };
+  auto zero_tail = [&](int buf, int step) {
+    const int t = step % tpb;
+    const int rem = R - t * 64;
+    if (rem >= 64) return false;
+    char* base = dsmem + buf * 65536;
+    const int nchunk = (64 - rem) * 32;  // 16-byte chunks per operand
+    for (int c = tid; c < nchunk; c += 512) {
+      const int off = (rem * 32 + c) * 16;
+      *(u32x4*)(base + off) = u32x4{0, 0, 0, 0};
+      *(u32x4*)(base + 32768 + off) = u32x4{0, 0, 0, 0};
+    }
+    return true;
+  };
+
+  f32x4 acc[8][4];  // [q tile][p tile]
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  stage(0, s_begin);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (zero_tail(0, s_begin)) __syncthreads();
+
+  const int g = lane >> 4, li = lane & 15;
+  const int r_in = li >> 2;
+  const int fsw = (r_in | ((g & 1) << 2)) << 1;
+  const int colq = wq * 128 + 4 * (li & 3);  // + i*16
+  const int colp = wp * 64 + 4 * (li & 3);   // + j*16
+  // fragment = two transposed reads (rows 8g+4t+r_in of the 32-row k-step s)
+  auto frag = [&](const char* tile, int s, int col) -> bf16x8 {
+    s16x8 o;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int r = 32 * s + 8 * g + 4 * t + r_in;
+      const s16x4 x = lds_read_tr16(tile + r * 512 + (((col >> 3) ^ fsw) << 4) + ((col & 7) << 1));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[4 * t + e] = x[e];
+    }
+    return __builtin_bit_cast(bf16x8, o);
+  };
+
+  for (int step = 0; step < nsteps; ++step) {
+    const int cur = step & 1;
+    if (step + 1 < nsteps) stage(cur ^ 1, s_begin + step + 1);
+    const char* sa = dsmem + cur * 65536;
+    const char* sb = sa + 32768;
+    bf16x8 qf[4][2], pf[4][2];
+    // phase 1: q tiles 0..3, p tiles 0..1
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { pf[j][0] = frag(sa, 0, colp + j * 16); pf[j][1] = frag(sa, 1, colp + j * 16); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { qf[i][0] = frag(sb, 0, colq + i * 16); qf[i][1] = frag(sb, 1, colq + i * 16); }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[i][s], pf[j][s], acc[i][j], 0, 0, 0);
+    // phase 2: p tiles 2..3
+#pragma unroll
+    for (int j = 2; j < 4; ++j) { pf[j][0] = frag(sa, 0, colp + j * 16); pf[j][1] = frag(sa, 1, colp + j * 16); }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 2; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[i][s], pf[j][s], acc[i][j], 0, 0, 0);
+    // phase 3: q tiles 4..7
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { qf[i][0] = frag(sb, 0, colq + (i + 4) * 16); qf[i][1] = frag(sb, 1, colq + (i + 4) * 16); }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 2; j < 4; ++j)
+          acc[i + 4][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[i][s], pf[j][s], acc[i + 4][j], 0, 0, 0);
+    // phase 4
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i + 4][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[i][s], pf[j][s], acc[i + 4][j], 0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (step + 1 < nsteps) {
+      if (zero_tail(cur ^ 1, s_begin + step + 1)) __syncthreads();
+    }
+  }
+
+  // D[q][p]: lane (li, g) holds acc[i][j][e] = C[p = j*16 + li][q = i*16 + 4g + e] of the wave tile
+  if (nsplit > 1) {
+    float* lds = (float*)(dsmem + wave * 8448);  // [16 p][132] fp32 per pass
+    float* cbase = (float*)p.C + (long)(p0 + wp * 64) * p.ldc + q0 + wq * 128 + lane;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) *(f32x4*)(lds + li * 132 + i * 16 + 4 * g) = acc[i][j] * p.alpha;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 4
+      for (int r = 0; r < 16; ++r) {
+        float* crow = cbase + (long)(j * 16 + r) * p.ldc;
+        atomicAdd(crow, lds[r * 132 + lane]);
+        atomicAdd(crow + 64, lds[r * 132 + 64 + lane]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int pp = p0 + wp * 64 + j * 16 + li;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int qq = q0 + wq * 128 + i * 16 + g * 4;
+      f32x4 o = acc[i][j] * p.alpha;
+      if (C_F32) {
+        float* cptr = (float*)p.C + (long)pp * p.ldc + qq;
+        if (p.accumulate) o += *(const f32x4*)cptr;
+        *(f32x4*)cptr = o;
+      } else {
+        unsigned short* cptr = (unsigned short*)p.C + (long)pp * p.ldc + qq;
+        u32x2 pk = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+        *(u32x2*)cptr = pk;
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------- host
+static int g_diag = 0;
+static bool g_force_128 = false;  // debugging / A-B switch: WFT_GEMM_FORCE_128=1
+static struct EnvInit { EnvInit() { const char* e = getenv("WFT_GEMM_FORCE_128"); g_force_128 = e && e[0] == '1'; const char* d = getenv("WFT_GEMM_DIAG"); g_diag = d ? atoi(d) : 0; } } g_env_init;
+
 static int fill_params(const wft_gemm_args* a, GemmP& p) {
   p.A = a->A; p.lda = a->lda; p.sA = a->strideA;
   p.B = a->B; p.ldb = a->ldb; p.sB = a->strideB;
@@ -335,6 +757,7 @@ static int fill_params(const wft_gemm_args* a, GemmP& p) {
   p.accumulate = a->accumulate;
   p.period = a->valid_rows_period; p.valid = a->valid_rows;
   p.res_first = a->residual_first;
+  p.diag = g_diag;
   return 0;
 }
 
@@ -351,9 +774,37 @@ extern "C" int wft_gemm_nt_bf16(const wft_gemm_args* a, void* stream) {
   WFT_CHECK_ARG(a->M < (1ll << 31) && a->N < (1ll << 31) && a->K < (1ll << 31), "dims exceed int32");
   GemmP p;
   fill_params(a, p);
+  hipStream_t s = (hipStream_t)stream;
+  // big, 256-aligned-N problems go to the 256x256 kernel (one workgroup per CU, 128 KiB LDS)
+  const bool wide_ok = a->c_is_f32 || (a->ldc % 8 == 0 && (!a->residual || (a->ldr % 8 == 0 && ((uintptr_t)a->residual & 15) == 0)) &&
+                                       (!a->aux || (a->ldaux % 8 == 0 && ((uintptr_t)a->aux & 15) == 0)) &&
+                                       (!a->bias || ((uintptr_t)a->bias & 15) == 0));
+  const bool big = !g_force_128 && wide_ok && a->N % 256 == 0 && a->M >= 1024 &&
+                   ((a->M + 255) / 256) * (a->N / 256) * a->batch >= 192;
+  if (big) {
+    static bool attr_done = false;
+    const long t256 = ((a->M + 255) / 256) * (a->N / 256);
+    dim3 grid((unsigned)t256, 1, (unsigned)a->batch), block(512);
+#define LAUNCH_256(E, F)                                                                                   \
+  do {                                                                                                    \
+    auto kfn = gemm_nt256_kernel<E, F>;                                                                   \
+    static bool done = false;                                                                             \
+    if (!done) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); done = true; } \
+    hipLaunchKernelGGL(kfn, grid, block, 131072, s, p);                                                   \
+  } while (0)
+    (void)attr_done;
+    switch (a->epilogue) {
+      case WFT_EPI_NONE: if (a->c_is_f32) LAUNCH_256(WFT_EPI_NONE, true); else LAUNCH_256(WFT_EPI_NONE, false); break;
+      case WFT_EPI_GELU: if (a->c_is_f32) LAUNCH_256(WFT_EPI_GELU, true); else LAUNCH_256(WFT_EPI_GELU, false); break;
+      case WFT_EPI_DGELU: if (a->c_is_f32) LAUNCH_256(WFT_EPI_DGELU, true); else LAUNCH_256(WFT_EPI_DGELU, false); break;
+      default: wft_set_error("wft_gemm_nt_bf16: unknown epilogue %d", a->epilogue); return WFT_ERR_ARG;
+    }
+#undef LAUNCH_256
+    WFT_CHECK_LAUNCH();
+    return WFT_OK;
+  }
   const long tiles = ((a->M + 127) / 128) * (a->N / 128);
   dim3 grid((unsigned)tiles, 1, (unsigned)a->batch), block(256);
-  hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_NT(E)                                                               \
   do {                                                                             \
     if (a->c_is_f32) hipLaunchKernelGGL((gemm_nt_kernel<E, true>), grid, block, 0, s, p);  \
@@ -381,9 +832,30 @@ extern "C" int wft_gemm_tn_bf16(const wft_gemm_args* a, void* stream) {
   WFT_CHECK_ARG(a->M < (1ll << 31) && a->N < (1ll << 31) && a->K < (1ll << 31), "dims exceed int32");
   GemmP p;
   fill_params(a, p);
+  hipStream_t s = (hipStream_t)stream;
+  const long nsteps = ((a->K + 63) / 64) * a->batch;
+  if (!g_force_128 && a->c_is_f32 && a->M % 256 == 0 && a->N % 256 == 0 && nsteps >= 256) {
+    // 256x256 tiles, one workgroup per CU: pick the split-K factor that fills 256 slots in whole waves
+    const long t256 = (a->M / 256) * (a->N / 256);
+    int nsplit = 1;
+    double best = 0.0;
+    for (int sp = 1; sp <= 16; ++sp) {
+      if (sp > 1 && nsteps / sp < 24) break;
+      const double waves = (double)(t256 * sp) / 256.0;
+      const double eff = waves / (double)((long)(waves + 0.999999));
+      if (eff > best + 0.02) { best = eff; nsplit = sp; }
+    }
+    if (nsplit > 1 && !a->accumulate)
+      (void)hipMemset2DAsync(a->C, (size_t)a->ldc * 4, 0, (size_t)a->N * 4, (size_t)a->M, s);
+    static bool done = false;
+    auto kfn = gemm_tn256_kernel<true>;
+    if (!done) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); done = true; }
+    hipLaunchKernelGGL(kfn, dim3((unsigned)t256, (unsigned)nsplit), dim3(512), 131072, s, p);
+    WFT_CHECK_LAUNCH();
+    return WFT_OK;
+  }
   const long tiles = (a->M / 128) * (a->N / 128);
   // split-K factor: fill the 512 resident-block slots (256 CUs x 2) in whole waves
-  const long nsteps = ((a->K + 63) / 64) * a->batch;
   int nsplit = 1;
   if (a->c_is_f32) {
     double best = 0.0;
@@ -394,7 +866,6 @@ extern "C" int wft_gemm_tn_bf16(const wft_gemm_args* a, void* stream) {
       if (eff > best + 0.03) { best = eff; nsplit = sp; }
     }
   }
-  hipStream_t s = (hipStream_t)stream;
   if (nsplit > 1 && !a->accumulate)
     (void)hipMemset2DAsync(a->C, (size_t)a->ldc * 4, 0, (size_t)a->N * 4, (size_t)a->M, s);
   dim3 grid((unsigned)tiles, (unsigned)nsplit), block(256);
