@@ -92,4 +92,17 @@ __device__ __forceinline__ s16x4 lds_read_tr16(const void* lds_addr) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((WFT_LDS s16x4*)lds_addr);
 }
 
+// Same read issued from inline asm: hipcc (ROCm 7.2) cannot disambiguate the builtin from pending LDS-DMA
+// writes and drains them with s_waitcnt vmcnt(0) in front of every read.  The caller owns the wait:
+// asm volatile("s_waitcnt lgkmcnt(0)") followed by __builtin_amdgcn_sched_barrier(0) before the first use
+// (cdna_hip_programming.md §5.7 item 1 form (iii), rule 18).
+__device__ __forceinline__ s16x4 lds_read_tr16_asm(unsigned lds_byte_addr) {
+  s16x4 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(lds_byte_addr));
+  return r;
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+  return (unsigned)(size_t)(const WFT_LDS char*)p;
+}
+
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -562,15 +562,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmP p) {
 
 // ---------------------------------------------------------------------------------- TN 256x256
 // Weight-gradient GEMM, large-shape variant: 256(p) x 256(q) output tile, 8 waves as 2(q) x 4(p)
-// (128 q x 64 p per wave), LDS tiles [64 r][256 cols] (512-byte rows) for A and B, double buffered
-// (128 KiB).  Same transposed-read fragments and pair swizzle as the 128 kernel; split-K partials are
-// added to C with fp32 atomics as contiguous 256-byte half rows staged through LDS.
+// (128 q x 64 p per wave), same ping-pong as gemm_nt256_kernel: ring of four 32-row reduction slabs
+// ({A [32 r][256 p], B [32 r][256 q]} = 32 KiB each), waves 0-3 / 4-7 half a period apart, group A stages
+// the A part, group B the B part, counted vmcnt(8).  Fragments are transposed LDS reads
+// (ds_read_b64_tr_b16) with the pair swizzle of the 128 kernel.  Split-K partials are added to C with
+// fp32 atomics issued as contiguous 256-byte half rows staged through LDS.
 template <bool C_F32>
 __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char dsmem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wq = wave >> 2, wp = wave & 3;
+  const bool grp_b = wave >= 4;
   const int P = p.M, Q = p.N, R = p.K;
   const int tiles_q = Q >> 8;
   const int tiles_p = P >> 8;
@@ -578,46 +581,40 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmP p) {
   const int tp = sid / tiles_q, tq = sid - tp * tiles_q;
   const int p0 = tp << 8, q0 = tq << 8;
 
-  const int tpb = (R + 63) >> 6;
-  const int nsteps_all = tpb * p.batch;
+  const int spb = (R + 31) >> 5;  // 32-row slabs per batch item
+  const int nslab_all = spb * p.batch;
   const int nsplit = gridDim.y;
-  const int per = (nsteps_all + nsplit - 1) / nsplit;
+  const int per = (nslab_all + nsplit - 1) / nsplit;
   const int s_begin = blockIdx.y * per;
-  const int s_end = (s_begin + per) < nsteps_all ? (s_begin + per) : nsteps_all;
-  const int nsteps = s_end - s_begin;
-  if (nsteps <= 0) return;
+  const int s_end = (s_begin + per) < nslab_all ? (s_begin + per) : nslab_all;
+  const int nslab = s_end - s_begin;
+  if (nslab <= 0) return;
 
-  // staging: one wave-instruction = 2 rows of 512 B; tile = 32 instructions; wave w issues 4w..4w+3
+  // staging share: one wave-instruction = 2 rows of 512 B; a part = 16 instructions; wave (w & 3) of the
+  // group owns instructions 4(w&3) .. +3 = rows 8(w&3) .. +7 of its part
   const int rr = lane >> 5, cp = lane & 31;
-  auto stage = [&](int buf, int step) {
-    const int b = step / tpb, t = step - b * tpb;
-    const unsigned short* Ab = p.A + (long)b * p.sA;
-    const unsigned short* Bb = p.B + (long)b * p.sB;
-    char* sa = dsmem + buf * 65536 + wave * 4096;
-    char* sb = sa + 32768;
+  const unsigned short* const gbase = grp_b ? p.B : p.A;
+  const long gld = grp_b ? p.ldb : p.lda;
+  const long gbs = grp_b ? p.sB : p.sA;
+  const int col0 = grp_b ? q0 : p0;
+  char* const stage_dst = dsmem + (grp_b ? 16384 : 0) + (wave & 3) * 4096;
+  // (batch item, slab-in-item) of the next slab to stage / to read, advanced incrementally (no division in the loop)
+  int ld_b = s_begin / spb, ld_t = s_begin - ld_b * spb;
+  int rd_t = ld_t;
+  auto stage = [&](int u) {  // local slab index u -> ring slot u & 3; rows past R are clamped (masked at read time)
+    const unsigned short* base = gbase + (long)ld_b * gbs + col0;
+    char* dst = stage_dst + (u & 3) * 32768;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int r = (wave * 4 + j) * 2 + rr;
-      int gr = t * 64 + r;
+      const int r = (wave & 3) * 8 + j * 2 + rr;
+      int gr = ld_t * 32 + r;
       gr = gr < R ? gr : R - 1;
       const int c = cp ^ (tn_f(r) << 1);
-      glds16(Ab + (long)gr * p.lda + p0 + (c << 3), sa + j * 1024);
-      glds16(Bb + (long)gr * p.ldb + q0 + (c << 3), sb + j * 1024);
+      glds16(base + (long)gr * gld + (c << 3), dst + j * 1024);
     }
+    if (++ld_t == spb) { ld_t = 0; ++ld_b; }
   };
-  auto zero_tail = [&](int buf, int step) {
-    const int t = step % tpb;
-    const int rem = R - t * 64;
-    if (rem >= 64) return false;
-    char* base = dsmem + buf * 65536;
-    const int nchunk = (64 - rem) * 32;  // 16-byte chunks per operand
-    for (int c = tid; c < nchunk; c += 512) {
-      const int off = (rem * 32 + c) * 16;
-      *(u32x4*)(base + off) = u32x4{0, 0, 0, 0};
-      *(u32x4*)(base + 32768 + off) = u32x4{0, 0, 0, 0};
-    }
-    return true;
-  };
+  const int rem_last = R - (spb - 1) * 32;  // valid rows of the last slab of a batch item (32 = full)
 
   f32x4 acc[8][4];  // [q tile][p tile]
 #pragma unroll
@@ -625,81 +622,89 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmP p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  stage(0, s_begin);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  if (zero_tail(0, s_begin)) __syncthreads();
-
   const int g = lane >> 4, li = lane & 15;
   const int r_in = li >> 2;
   const int fsw = (r_in | ((g & 1) << 2)) << 1;
   const int colq = wq * 128 + 4 * (li & 3);  // + i*16
   const int colp = wp * 64 + 4 * (li & 3);   // + j*16
-  // fragment = two transposed reads (rows 8g+4t+r_in of the 32-row k-step s)
-  auto frag = [&](const char* tile, int s, int col) -> bf16x8 {
-    s16x8 o;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int r = 32 * s + 8 * g + 4 * t + r_in;
-      const s16x4 x = lds_read_tr16(tile + r * 512 + (((col >> 3) ^ fsw) << 4) + ((col & 7) << 1));
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[4 * t + e] = x[e];
-    }
-    return __builtin_bit_cast(bf16x8, o);
+  const unsigned lds0 = lds_addr_of(dsmem);
+  // per-lane byte offsets (within a slab part) of the two transposed reads of a fragment at column `col`
+  auto frag_off = [&](int col, int t) -> unsigned {
+    const int r = 8 * g + 4 * t + r_in;
+    return (unsigned)(r * 512 + (((col >> 3) ^ fsw) << 4) + ((col & 7) << 1));
   };
+  s16x4 qh[8][2], ph[4][2];  // raw halves of the fragments (inline-asm reads: waited for by hand below)
 
-  for (int step = 0; step < nsteps; ++step) {
-    const int cur = step & 1;
-    if (step + 1 < nsteps) stage(cur ^ 1, s_begin + step + 1);
-    const char* sa = dsmem + cur * 65536;
-    const char* sb = sa + 32768;
-    bf16x8 qf[4][2], pf[4][2];
-    // phase 1: q tiles 0..3, p tiles 0..1
+  stage(0);
+  if (nslab > 1) stage(1);
+  if (nslab > 2) stage(2);
+  if (nslab > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (nslab > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (grp_b) __builtin_amdgcn_s_barrier();
+
+  bf16x8 qf[8], pf[4];
+  for (int u = 0; u < nslab; ++u) {
+    // ---------------- L-unit
+    if (u + 3 < nslab) stage(u + 3);
+    {
+      const unsigned sa = lds0 + (u & 3) * 32768;
+      const unsigned sb = sa + 16384;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) { pf[j][0] = frag(sa, 0, colp + j * 16); pf[j][1] = frag(sa, 1, colp + j * 16); }
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { qf[i][0] = frag(sb, 0, colq + i * 16); qf[i][1] = frag(sb, 1, colq + i * 16); }
+        for (int t = 0; t < 2; ++t) ph[j][t] = lds_read_tr16_asm(sa + frag_off(colp + j * 16, t));
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+      for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[i][s], pf[j][s], acc[i][j], 0, 0, 0);
-    // phase 2: p tiles 2..3
-#pragma unroll
-    for (int j = 2; j < 4; ++j) { pf[j][0] = frag(sa, 0, colp + j * 16); pf[j][1] = frag(sa, 1, colp + j * 16); }
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 2; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[i][s], pf[j][s], acc[i][j], 0, 0, 0);
-    // phase 3: q tiles 4..7
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { qf[i][0] = frag(sb, 0, colq + (i + 4) * 16); qf[i][1] = frag(sb, 1, colq + (i + 4) * 16); }
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 2; j < 4; ++j)
-          acc[i + 4][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[i][s], pf[j][s], acc[i + 4][j], 0, 0, 0);
-    // phase 4
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i + 4][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[i][s], pf[j][s], acc[i + 4][j], 0, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (step + 1 < nsteps) {
-      if (zero_tail(cur ^ 1, s_begin + step + 1)) __syncthreads();
+        for (int t = 0; t < 2; ++t) qh[i][t] = lds_read_tr16_asm(sb + frag_off(colq + i * 16, t));
     }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s16x8 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { o[e] = ph[j][0][e]; o[4 + e] = ph[j][1][e]; }
+      pf[j] = __builtin_bit_cast(bf16x8, o);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      s16x8 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { o[e] = qh[i][0][e]; o[4 + e] = qh[i][1][e]; }
+      qf[i] = __builtin_bit_cast(bf16x8, o);
+    }
+    if (rd_t == spb - 1 && rem_last < 32) {
+      // ragged end of the reduction: rows >= rem_last of this slab hold clamped duplicates; zero them in
+      // ONE operand (element 4t+e of the fragment is row 8g + 4t + e)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (8 * g + e >= rem_last) pf[j][e] = (__bf16)0.0f;
+    }
+    if (++rd_t == spb) rd_t = 0;
+    const int ahead = nslab - 1 - u;
+    if (ahead >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (ahead == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---------------- C-unit
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[i], pf[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
   }
+  if (!grp_b) __builtin_amdgcn_s_barrier();
 
   // D[q][p]: lane (li, g) holds acc[i][j][e] = C[p = j*16 + li][q = i*16 + 4g + e] of the wave tile
   if (nsplit > 1) {
@@ -835,12 +840,13 @@ extern "C" int wft_gemm_tn_bf16(const wft_gemm_args* a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const long nsteps = ((a->K + 63) / 64) * a->batch;
   if (!g_force_128 && a->c_is_f32 && a->M % 256 == 0 && a->N % 256 == 0 && nsteps >= 256) {
+    const long nslabs = ((a->K + 31) / 32) * a->batch;
     // 256x256 tiles, one workgroup per CU: pick the split-K factor that fills 256 slots in whole waves
     const long t256 = (a->M / 256) * (a->N / 256);
     int nsplit = 1;
     double best = 0.0;
     for (int sp = 1; sp <= 16; ++sp) {
-      if (sp > 1 && nsteps / sp < 24) break;
+      if (sp > 1 && nslabs / sp < 48) break;
       const double waves = (double)(t256 * sp) / 256.0;
       const double eff = waves / (double)((long)(waves + 0.999999));
       if (eff > best + 0.02) { best = eff; nsplit = sp; }
