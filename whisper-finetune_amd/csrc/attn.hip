@@ -138,29 +138,28 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
           sacc[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_row_frag(kt_l, kb2, s, lane), qf[s],
                                                               sacc[kb2], 0, 0, 0);
       }
-      // mask + tile max
-      float tmax = ATT_NEG;
-      const bool need_mask = (key0 + 64 > p.Tk) || (p.causal && key0 + 63 > qw0);
+      // mask (only tiles that touch the ragged end / the causal diagonal: wave-uniform branch, selects inside)
+      if ((key0 + 64 > p.Tk) || (p.causal && key0 + 63 > qw0)) {
+        const int lim = (p.causal ? (qi + 1 < p.Tk ? qi + 1 : p.Tk) : p.Tk) - key0 - 4 * h;  // valid iff key offset < lim
 #pragma unroll
-      for (int kb2 = 0; kb2 < 2; ++kb2)
+        for (int kb2 = 0; kb2 < 2; ++kb2)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          if (need_mask) {
-            const int key = key0 + 32 * kb2 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (key >= p.Tk || (p.causal && key > qi)) sacc[kb2][e] = ATT_NEG;
-          }
-          tmax = fmaxf(tmax, sacc[kb2][e]);
-        }
+          for (int e = 0; e < 16; ++e)
+            sacc[kb2][e] = (32 * kb2 + (e & 3) + 8 * (e >> 2)) < lim ? sacc[kb2][e] : ATT_NEG;
+      }
+      float tmax = fmaxf(sacc[0][0], sacc[1][0]);
+#pragma unroll
+      for (int e = 1; e < 16; ++e) tmax = fmaxf(tmax, fmaxf(sacc[0][e], sacc[1][e]));
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
       const float mnew = fmaxf(m, tmax);
-      const float alpha = exp2f((m - mnew) * c);
+      const float alpha = __builtin_amdgcn_exp2f((m - mnew) * c);
       const float mc = mnew * c;
       float ls = 0.f;
 #pragma unroll
       for (int kb2 = 0; kb2 < 2; ++kb2)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const float pv = exp2f(sacc[kb2][e] * c - mc);
+          const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kb2][e], c, -mc));
           sacc[kb2][e] = pv;
           ls += pv;
         }
@@ -284,15 +283,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
                                                               pacc[kb2], 0, 0, 0);
         }
       }
+      if ((key0 + 64 > p.Tk) || (p.causal && key0 + 63 > qw0)) {
+        const int lim = (p.causal ? (qi + 1 < p.Tk ? qi + 1 : p.Tk) : p.Tk) - key0 - 4 * h;
 #pragma unroll
-      for (int kb2 = 0; kb2 < 2; ++kb2)
+        for (int kb2 = 0; kb2 < 2; ++kb2)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int key = key0 + 32 * kb2 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          const bool ok = key < p.Tk && !(p.causal && key > qi);
-          const float pv = ok ? exp2f(sacc[kb2][e] * c - lse2) : 0.f;
-          sacc[kb2][e] = pv * (pacc[kb2][e] - dlt);  // dS^T (unscaled)
-        }
+          for (int e = 0; e < 16; ++e) {
+            const bool ok = (32 * kb2 + (e & 3) + 8 * (e >> 2)) < lim;
+            const float pv = ok ? __builtin_amdgcn_exp2f(fmaf(sacc[kb2][e], c, -lse2)) : 0.f;
+            sacc[kb2][e] = pv * (pacc[kb2][e] - dlt);
+          }
+      } else {
+#pragma unroll
+        for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            sacc[kb2][e] = __builtin_amdgcn_exp2f(fmaf(sacc[kb2][e], c, -lse2)) * (pacc[kb2][e] - dlt);  // dS^T (unscaled)
+      }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const bf16x8 dsf = att_pack8(sacc[ks >> 1], ks & 1);
@@ -383,18 +390,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
           pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_row_frag(do_l, qb2, s, lane), vf[s], pacc, 0, 0, 0);
         }
         f32x16 dsacc;
+        const bool need_mask = (qq0 + 32 * qb2 + 32 > p.Tq) || (kw0 + 32 > p.Tk) || (p.causal && kw0 + 31 > qq0 + 32 * qb2);
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
           const int qoff = 32 * qb2 + 8 * a + 4 * h;
           const f32x4 l4 = *(const f32x4*)(lse_l + qoff);
           const f32x4 d4 = *(const f32x4*)(dlt_l + qoff);
+          if (need_mask) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int qg = qq0 + qoff + e;
-            const bool ok = qg < p.Tq && ki < p.Tk && !(p.causal && ki > qg);
-            const float pv = ok ? exp2f(sacc[4 * a + e] * c - l4[e]) : 0.f;
-            sacc[4 * a + e] = pv;
-            dsacc[4 * a + e] = pv * (pacc[4 * a + e] - d4[e]);
+            for (int e = 0; e < 4; ++e) {
+              const int qg = qq0 + qoff + e;
+              const bool ok = qg < p.Tq && ki < p.Tk && !(p.causal && ki > qg);
+              const float pv = ok ? __builtin_amdgcn_exp2f(fmaf(sacc[4 * a + e], c, -l4[e])) : 0.f;
+              sacc[4 * a + e] = pv;
+              dsacc[4 * a + e] = pv * (pacc[4 * a + e] - d4[e]);
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[4 * a + e], c, -l4[e]));
+              sacc[4 * a + e] = pv;
+              dsacc[4 * a + e] = pv * (pacc[4 * a + e] - d4[e]);
+            }
           }
         }
 #pragma unroll
