@@ -188,6 +188,15 @@ int wft_ce_bwd(const wft_bf16* logits, int64_t ld, const int64_t* targets,
                const float* row_lse, const float* stats, const float* gscale,
                wft_bf16* dlogits, void* stream);
 
+/* Teacher-forced evaluation reductions (eval/evaluator.py:70-73 argmax;
+ * eval/metrics.py:106-137 log_softmax / softmax / CE / entropy / max-prob) in ONE
+ * pass over the logits: out4[row] = {lse, max logit, E_p[logit], target logit (0 if
+ * the target is -100)}, argmax[row] = lowest index of the maximum.  targets may be
+ * NULL.  nll = lse - x_t; log p(pred) = max - lse; confidence = exp(max - lse);
+ * entropy = lse - E_p[logit].                                                  */
+int wft_token_stats(const wft_bf16* logits, int64_t ld, const int64_t* targets,
+                    int64_t rows, int64_t V, float* out4, int64_t* argmax, void* stream);
+
 /* ------------------------------------------------- Log-mel + SpecAugment */
 /* whisper.audio.log_mel_spectrogram (data/data_loader.py:278; SURVEY.md App.
  * A.2): reflect-pad 200, Hann-400 STFT hop 160, |.|^2, mel filterbank,

@@ -265,7 +265,38 @@ def gen_ref_host():
     print("ref_host.npz written", {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
 
 
+def gen_ref_eval():
+    """eval/utils.py normaliser, eval/metrics.py ECE / token metrics / aggregation from the reference's own code."""
+    import json
+    tmp = Path(tempfile.mkdtemp())
+    _install_stubs(tmp)
+    sys.path.insert(0, str(tmp))
+    sys.path.insert(0, str(REF / "src"))
+    from whisper_finetune.eval import metrics as rm
+    from whisper_finetune.eval import utils as ru
+
+    out = {}
+    texts = ["Grüß Gott, wie geht's? Über-Straße 12/3 – ÇA VA", "  Hello\tWORLD  ñandú şah Ș ", "a-b–c/d ÄÖÜ äöü ß",
+             "1,234.5 test: ok; yes!", "", "   "]
+    out["normalize"] = {v: [[t, ru.normalize_text(t, **ru.VOCAB_SPECS[v])] for t in texts] for v in ("v0", "v1", "v2", "v3")}
+    g = torch.Generator().manual_seed(3)
+    conf = torch.rand(500, generator=g).tolist()
+    ok = (torch.rand(500, generator=g) < torch.tensor(conf)).tolist()
+    out["ece"] = {"conf": conf, "ok": ok, "value": float(rm.compute_ece(conf, ok)), "value10": float(rm.compute_ece(conf, ok, n_bins=10))}
+    logits = torch.randn(9, 50, generator=g) * 2
+    tgt = torch.randint(0, 50, (9,), generator=g); tgt[[2, 7]] = -100
+    pred = logits.argmax(-1)
+    nll, lp, ent, cf, cr = rm.compute_token_metrics(logits, tgt, pred)
+    out["token_metrics"] = {"logits": logits.tolist(), "targets": tgt.tolist(), "nll": nll, "avg_log_prob": lp, "entropy": ent,
+                            "confidences": cf, "correct": cr}
+    nll0 = rm.compute_token_metrics(logits, torch.full((9,), -100), pred)
+    out["token_metrics_all_pad"] = list(nll0)
+    (HERE / "ref_eval.json").write_text(json.dumps(out, indent=0))
+    print("ref_eval.json written")
+
+
 if __name__ == "__main__":
+    gen_ref_eval()
     gen_arch()
     gen_logmel()
     gen_ref_host()

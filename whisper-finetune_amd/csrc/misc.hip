@@ -407,6 +407,72 @@ extern "C" int wft_ce_bwd(const wft_bf16* logits, int64_t ld, const int64_t* tar
   return WFT_OK;
 }
 
+// ----------------------------------------------------------------------------- eval token statistics
+// One pass over the V logits of every token (eval/metrics.py:106-137 computes log_softmax, softmax, CE,
+// entropy and max-prob as five separate [S, V] passes): per row
+//   out[row] = { lse, max logit, sum_c p_c * x_c, x_target (0 if ignored) },  argmax[row] (lowest index on ties)
+// from which nll = lse - x_t, log p(pred) = max - lse, confidence = exp(max - lse), entropy = lse - E_p[x].
+__global__ __launch_bounds__(256) void token_stats_kernel(const unsigned short* logits, long ld, const long* targets, long V,
+                                                           float* out4, long* argmax) {
+  __shared__ float sm[4], ss[4], sw[4], sbv[4];
+  __shared__ int sbi[4];
+  const long row = blockIdx.x;
+  const unsigned short* x = logits + row * ld;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  float m = -3.0e38f, s = 0.f, w = 0.f, bv = -3.0e38f;  // w = sum exp(x - m) * x
+  int bi = 0x7fffffff;
+  auto push = [&](float v, int idx) {
+    if (v > bv) { bv = v; bi = idx; }
+    if (v > m) { const float f = __expf(m - v); s *= f; w *= f; m = v; }
+    const float e = __expf(v - m);
+    s += e;
+    w += e * v;
+  };
+  const long nv = V >> 3;
+  for (long i = tid; i < nv; i += 256) {
+    const u32x4 r = *(const u32x4*)(x + i * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      push(bf2f((unsigned short)(r[e] & 0xffff)), (int)(i * 8 + 2 * e));
+      push(bf2f((unsigned short)(r[e] >> 16)), (int)(i * 8 + 2 * e + 1));
+    }
+  }
+  for (long c = (nv << 3) + tid; c < V; c += 256) push(bf2f(x[c]), (int)c);
+  auto merge = [&](float om, float os, float ow, float obv, int obi) {
+    const float nm = fmaxf(m, om);
+    const float f0 = __expf(m - nm), f1 = __expf(om - nm);
+    s = s * f0 + os * f1;
+    w = w * f0 + ow * f1;
+    m = nm;
+    if (obv > bv || (obv == bv && obi < bi)) { bv = obv; bi = obi; }
+  };
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    merge(__shfl_xor(m, o, 64), __shfl_xor(s, o, 64), __shfl_xor(w, o, 64), __shfl_xor(bv, o, 64), __shfl_xor(bi, o, 64));
+  if (lane == 0) { sm[wv] = m; ss[wv] = s; sw[wv] = w; sbv[wv] = bv; sbi[wv] = bi; }
+  __syncthreads();
+  if (tid == 0) {
+    m = sm[0]; s = ss[0]; w = sw[0]; bv = sbv[0]; bi = sbi[0];
+    for (int k = 1; k < 4; ++k) merge(sm[k], ss[k], sw[k], sbv[k], sbi[k]);
+    const long t = targets ? targets[row] : -100;
+    out4[row * 4 + 0] = m + __logf(s);
+    out4[row * 4 + 1] = bv;
+    out4[row * 4 + 2] = w / s;
+    out4[row * 4 + 3] = (t >= 0 && t < V) ? bf2f(x[t]) : 0.f;
+    argmax[row] = bi;
+  }
+}
+extern "C" int wft_token_stats(const wft_bf16* logits, int64_t ld, const int64_t* targets, int64_t rows, int64_t V,
+                               float* out4, int64_t* argmax, void* stream) {
+  WFT_CHECK_ARG(logits && out4 && argmax, "null pointer");
+  WFT_CHECK_ARG(rows >= 1 && V >= 1 && ld >= V && ld % 8 == 0, "bad shape (ld must be a multiple of 8, >= V)");
+  WFT_CHECK_ARG((((uintptr_t)logits) & 15) == 0, "16-byte alignment");
+  hipLaunchKernelGGL(token_stats_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, (long)ld,
+                     (const long*)targets, (long)V, out4, (long*)argmax);
+  WFT_CHECK_LAUNCH();
+  return WFT_OK;
+}
+
 // ----------------------------------------------------------------------------- AdamW
 __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, unsigned short* pb,
                                                      long n, float lr, float b1, float b2, float eps, float wd, float bc1,

@@ -327,6 +327,18 @@ def ce_bwd(logits, targets, V: int, label_smoothing: float, row_lse, stats, gsca
     return dl
 
 
+def token_stats(logits, targets, V: int):
+    """logits bf16 [rows, ld>=V]; targets i64 [rows] or None -> (stats f32 [rows, 4] = lse, max, E_p[x], x_target; argmax i64)."""
+    _chk(logits, BF16, "logits")
+    assert logits.dim() == 2 and logits.stride(1) == 1
+    rows, ld = logits.shape[0], logits.stride(0)
+    out4 = torch.empty((rows, 4), dtype=F32, device=logits.device)
+    am = torch.empty(rows, dtype=torch.int64, device=logits.device)
+    tg = None if targets is None else targets.contiguous()
+    L.check(L.load().wft_token_stats(_p(logits), ld, _p(tg), rows, V, _p(out4), _p(am), L.stream_ptr()), "wft_token_stats")
+    return out4, am
+
+
 # --------------------------------------------------------------------------- audio
 def logmel(audio, filters, n_frames: int = 3000):
     """audio f32 [B, 160*n_frames], filters f32 [n_mels, 201] -> f32 [B, n_mels, n_frames]."""

@@ -77,6 +77,7 @@ SIGNATURES = {
     "wft_embed_bwd": [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, C.c_int, c_i64, c_vp],
     "wft_ce_fwd": [c_vp, c_i64, c_vp, c_i64, c_i64, C.c_float, c_vp, c_vp, c_vp, c_vp, c_vp],
     "wft_ce_bwd": [c_vp, c_i64, c_vp, c_i64, c_i64, C.c_float, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "wft_token_stats": [c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp],
     "wft_logmel": [c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, c_vp],
     "wft_specaug": [c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp],
     "wft_mel_to_tmajor_bf16": [c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, c_vp],
