@@ -124,6 +124,10 @@ typedef struct {
   int residual_first;  /* != 0: add the residual BEFORE the epilogue op (gelu / dgelu) instead of after */
 } wft_gemm_args;
 int wft_gemm_nt_bf16(const wft_gemm_args* args, void* stream);
+/* Which kernel wft_gemm_nt_bf16 dispatches these arguments to: 256 (gemm_nt256_kernel, 256x256
+ * ping-pong tiles) or 128 (gemm_nt_kernel).  Pure host function (used by bench.py to attribute
+ * HIP-event timings to the kernel names rocprofv3 reports).                              */
+int wft_gemm_nt_variant(const wft_gemm_args* args);
 /* C[p, q] (+)= alpha * sum_r A[r, p] * B[r, q]   (weight gradients dW = dY^T X:
  * what autograd's mm-backward computes for whisper.model.Linear).
  *  A bf16 [R, P] (row r at A + r*lda, P contiguous), B bf16 [R, Q];

@@ -766,6 +766,15 @@ static int fill_params(const wft_gemm_args* a, GemmP& p) {
   return 0;
 }
 
+static bool nt_uses_256(const wft_gemm_args* a) {
+  const bool wide_ok = a->c_is_f32 || (a->ldc % 8 == 0 && (!a->residual || (a->ldr % 8 == 0 && ((uintptr_t)a->residual & 15) == 0)) &&
+                                       (!a->aux || (a->ldaux % 8 == 0 && ((uintptr_t)a->aux & 15) == 0)) &&
+                                       (!a->bias || ((uintptr_t)a->bias & 15) == 0));
+  return !g_force_128 && wide_ok && a->N % 256 == 0 && a->M >= 1024 &&
+         ((a->M + 255) / 256) * (a->N / 256) * a->batch >= 192;
+}
+extern "C" int wft_gemm_nt_variant(const wft_gemm_args* a) { return a && nt_uses_256(a) ? 256 : 128; }
+
 extern "C" int wft_gemm_nt_bf16(const wft_gemm_args* a, void* stream) {
   WFT_CHECK_ARG(a && a->A && a->B && a->C, "null pointer");
   WFT_CHECK_ARG(a->M >= 1 && a->N >= 128 && a->K >= 64 && a->batch >= 1, "bad shape");
@@ -781,11 +790,13 @@ extern "C" int wft_gemm_nt_bf16(const wft_gemm_args* a, void* stream) {
   fill_params(a, p);
   hipStream_t s = (hipStream_t)stream;
   // big, 256-aligned-N problems go to the 256x256 kernel (one workgroup per CU, 128 KiB LDS)
+  const bool big = nt_uses_256(a);
+#if 0
   const bool wide_ok = a->c_is_f32 || (a->ldc % 8 == 0 && (!a->residual || (a->ldr % 8 == 0 && ((uintptr_t)a->residual & 15) == 0)) &&
                                        (!a->aux || (a->ldaux % 8 == 0 && ((uintptr_t)a->aux & 15) == 0)) &&
                                        (!a->bias || ((uintptr_t)a->bias & 15) == 0));
-  const bool big = !g_force_128 && wide_ok && a->N % 256 == 0 && a->M >= 1024 &&
-                   ((a->M + 255) / 256) * (a->N / 256) * a->batch >= 192;
+  const bool big_unused = false;
+#endif
   if (big) {
     static bool attr_done = false;
     const long t256 = ((a->M + 255) / 256) * (a->N / 256);

@@ -189,7 +189,7 @@ def gemm_nt(a, b, *, M=None, N=None, K=None, lda=None, ldb=None, out=None, out_f
         ev0.record()
         L.check(L.load().wft_gemm_nt_bf16(C.byref(args), L.stream_ptr()), "wft_gemm_nt_bf16")
         ev1.record()
-        PROFILE_NT.append((ev0, ev1, 2.0 * M * N * K * batch))
+        PROFILE_NT.append((ev0, ev1, 2.0 * M * N * K * batch, L.load().wft_gemm_nt_variant(C.byref(args))))
         return out
     L.check(L.load().wft_gemm_nt_bf16(C.byref(args), L.stream_ptr()), "wft_gemm_nt_bf16")
     return out

@@ -70,6 +70,7 @@ SIGNATURES = {
     "wft_layernorm_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int,
                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp],
     "wft_gemm_nt_bf16": [C.POINTER(GemmArgs), c_vp],
+    "wft_gemm_nt_variant": [C.POINTER(GemmArgs)],
     "wft_gemm_tn_bf16": [C.POINTER(GemmArgs), c_vp],
     "wft_attn_fwd_bf16": [C.POINTER(AttnArgs), c_vp],
     "wft_attn_bwd_bf16": [C.POINTER(AttnArgs), c_vp],
