@@ -52,25 +52,40 @@ __device__ __forceinline__ void att_stage(const unsigned short* base, long ld, i
   }
 }
 
-// 32x32x16 A-operand row read: lane (r = lane&31, h = lane>>5) gets tile[blk*32 + r][16s + 8h .. +8]
-__device__ __forceinline__ bf16x8 att_row_frag(const char* tile, int blk, int s, int lane) {
-  const int row = blk * 32 + (lane & 31);
-  const int chunk = 2 * s + (lane >> 5);
-  return *(const bf16x8*)(tile + row * 128 + ((chunk ^ att_F(row)) << 4));
+// Per-lane LDS byte offsets of every fragment read, computed ONCE per kernel: with the tile base a
+// compile-time constant (loops are unrolled by two over the LDS buffers) every ds_read in the tile loop is
+// base-VGPR + immediate — the address arithmetic that used to be ~1/3 of the VALU stream is gone.
+//   row[s]      : 32x32x16 A-operand row read, lane (r = lane&31, h = lane>>5) gets tile[blk*32 + r][16s + 8h .. +8]
+//                 (+ blk*4096 immediate)
+//   tr[db][t]   : transposed read t (rows 8t + 4h + (i>>2)) of the "accumulator as B operand" k-order:
+//                 element j of lane (r, h) = tile[16*ks + 8*(j>>2) + 4h + (j&3)][32*db + r]   (+ ks*2048 immediate)
+struct AttOffs {
+  int row[4];
+  int tr[2][2];
+};
+__device__ __forceinline__ AttOffs att_offsets(int lane) {
+  AttOffs o;
+  const int r = lane & 31, h = lane >> 5, g = lane >> 4, i = lane & 15;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) o.row[s] = r * 128 + (((2 * s + h) ^ att_F(r)) << 4);
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int rowt = 8 * t + 4 * h + (i >> 2);
+      const int col = 32 * db + 16 * (g & 1) + 4 * (i & 3);
+      o.tr[db][t] = rowt * 128 + (((col >> 3) ^ att_F(rowt)) << 4) + ((col & 7) << 1);
+    }
+  return o;
 }
-
-// 32x32x16 A-operand TRANSPOSED read for the "accumulator as B operand" k-order:
-// element j of lane (r, h) = tile[R0 + 8*(j>>2) + 4h + (j&3)][32*db + r], R0 = 16*ks.
-__device__ __forceinline__ bf16x8 att_tr_frag(const char* tile, int ks, int db, int lane) {
-  const int g = lane >> 4, i = lane & 15, h = g >> 1;
-  const int col = 32 * db + 16 * (g & 1) + 4 * (i & 3);
-  const int chunk = col >> 3;
-  const int inner = (col & 7) << 1;
+__device__ __forceinline__ bf16x8 att_row_frag(const char* tile, const AttOffs& o, int blk, int s) {
+  return *(const bf16x8*)(tile + blk * 4096 + o.row[s]);
+}
+__device__ __forceinline__ bf16x8 att_tr_frag(const char* tile, const AttOffs& o, int ks, int db) {
   s16x8 out;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    const int row = 16 * ks + 8 * t + 4 * h + (i >> 2);
-    const s16x4 x = lds_read_tr16(tile + row * 128 + ((chunk ^ att_F(row)) << 4) + inner);
+    const s16x4 x = lds_read_tr16(tile + ks * 2048 + o.tr[db][t]);
 #pragma unroll
     for (int e = 0; e < 4; ++e) out[4 * t + e] = x[e];
   }
@@ -88,6 +103,9 @@ __device__ __forceinline__ bf16x8 att_load_reg_frag(const unsigned short* rowptr
   return *(const bf16x8*)(rowptr + 16 * s + 8 * h);
 }
 
+template <int V>
+struct IntC { static constexpr int value = V; };
+
 // ------------------------------------------------------------------------------ forward
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   __shared__ __attribute__((aligned(16))) char smem[32768];  // [buf 2][K 8K | V 8K]
@@ -103,6 +121,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   bf16x8 qf[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) qf[s] = att_load_reg_frag(qrow, s, h);
+  const AttOffs offs = att_offsets(lane);
 
   int nkt = (p.Tk + 63) >> 6;
   if (p.causal) {
@@ -110,33 +129,33 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
     nkt = nkt < last ? nkt : last;
   }
   const float c = p.scale * LOG2E;
+  const f32x16 zero16 = f32x16{0};
   f32x16 oacc[2];
-  oacc[0] = f32x16{0};
-  oacc[1] = f32x16{0};
+  oacc[0] = zero16;
+  oacc[1] = zero16;
   float m = ATT_NEG, l = 0.f;
 
   att_stage(kb, p.ldk, 0, p.Tk, smem, wave, lane);
   att_stage(vb, p.ldv, 0, p.Tk, smem + 8192, wave, lane);
   __syncthreads();
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
+
+  auto tile = [&](auto cur_tag, int kt) {
+    constexpr int CUR = decltype(cur_tag)::value;
     const int key0 = kt * 64;
     if (kt + 1 < nkt) {
-      att_stage(kb, p.ldk, key0 + 64, p.Tk, smem + (cur ^ 1) * 16384, wave, lane);
-      att_stage(vb, p.ldv, key0 + 64, p.Tk, smem + (cur ^ 1) * 16384 + 8192, wave, lane);
+      att_stage(kb, p.ldk, key0 + 64, p.Tk, smem + (CUR ^ 1) * 16384, wave, lane);
+      att_stage(vb, p.ldv, key0 + 64, p.Tk, smem + (CUR ^ 1) * 16384 + 8192, wave, lane);
     }
-    const char* kt_l = smem + cur * 16384;
+    const char* kt_l = smem + CUR * 16384;
     const char* vt_l = kt_l + 8192;
-    const bool active = !(p.causal && key0 > qw0 + 31);
-    if (active) {
+    if (!(p.causal && key0 > qw0 + 31)) {
       f32x16 sacc[2];
 #pragma unroll
       for (int kb2 = 0; kb2 < 2; ++kb2) {
-        sacc[kb2] = f32x16{0};
+        sacc[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_row_frag(kt_l, offs, kb2, 0), qf[0], zero16, 0, 0, 0);
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-          sacc[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_row_frag(kt_l, kb2, s, lane), qf[s],
-                                                              sacc[kb2], 0, 0, 0);
+        for (int s = 1; s < 4; ++s)
+          sacc[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_row_frag(kt_l, offs, kb2, s), qf[s], sacc[kb2], 0, 0, 0);
       }
       // mask (only tiles that touch the ragged end / the causal diagonal: wave-uniform branch, selects inside)
       if ((key0 + 64 > p.Tk) || (p.causal && key0 + 63 > qw0)) {
@@ -149,20 +168,25 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
       }
       float tmax = fmaxf(sacc[0][0], sacc[1][0]);
 #pragma unroll
-      for (int e = 1; e < 16; ++e) tmax = fmaxf(tmax, fmaxf(sacc[0][e], sacc[1][e]));
+      for (int e = 1; e < 16; ++e) tmax = fmaxf(tmax, fmaxf(sacc[0][e], sacc[1][e]));  // v_max3_f32
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
       const float mnew = fmaxf(m, tmax);
       const float alpha = __builtin_amdgcn_exp2f((m - mnew) * c);
-      const float mc = mnew * c;
-      float ls = 0.f;
+      // packed fp32 math (v_pk_fma_f32 / v_pk_add_f32): this kernel is VALU-bound (SQ_ACTIVE_INST_VALU ~82 %)
+      const f32x2 c2 = {c, c}, mc2 = {mnew * c, mnew * c};
+      f32x2 ls2 = {0.f, 0.f};
 #pragma unroll
       for (int kb2 = 0; kb2 < 2; ++kb2)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kb2][e], c, -mc));
-          sacc[kb2][e] = pv;
-          ls += pv;
+        for (int e = 0; e < 8; ++e) {
+          f32x2 t2 = {sacc[kb2][2 * e], sacc[kb2][2 * e + 1]};
+          t2 = t2 * c2 - mc2;
+          f32x2 p2 = {__builtin_amdgcn_exp2f(t2[0]), __builtin_amdgcn_exp2f(t2[1])};
+          ls2 += p2;
+          sacc[kb2][2 * e] = p2[0];
+          sacc[kb2][2 * e + 1] = p2[1];
         }
+      float ls = ls2[0] + ls2[1];
       ls += __shfl_xor(ls, 32, 64);
       l = l * alpha + ls;
       m = mnew;
@@ -175,12 +199,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
         const bf16x8 pf = att_pack8(sacc[ks >> 1], ks & 1);
 #pragma unroll
         for (int db = 0; db < 2; ++db)
-          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_tr_frag(vt_l, ks, db, lane), pf, oacc[db],
-                                                             0, 0, 0);
+          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_tr_frag(vt_l, offs, ks, db), pf, oacc[db], 0, 0, 0);
       }
     }
     __syncthreads();
+  };
+  int kt = 0;
+  for (; kt + 1 < nkt; kt += 2) {
+    tile(IntC<0>{}, kt);
+    tile(IntC<1>{}, kt + 1);
   }
+  if (kt < nkt) tile(IntC<0>{}, kt);
+
   if (qi < p.Tq) {
     const float inv = 1.0f / l;
     unsigned short* orow = p.o + (long)b * p.o_bs + (long)qi * p.ldo + hd * 64;
@@ -242,6 +272,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
     qf[s] = att_load_reg_frag(qrow, s, h);
     dof[s] = att_load_reg_frag(dorow, s, h);
   }
+  const AttOffs offs = att_offsets(lane);
   const long sidx = ((long)b * p.H + hd) * p.Tq + qc;
   const float lse2 = p.lse[sidx] * LOG2E;
   const float dlt = p.delta[sidx];
@@ -252,35 +283,34 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
     nkt = nkt < last ? nkt : last;
   }
   const float c = p.scale * LOG2E;
+  const f32x16 zero16 = f32x16{0};
   f32x16 dqacc[2];
-  dqacc[0] = f32x16{0};
-  dqacc[1] = f32x16{0};
+  dqacc[0] = zero16;
+  dqacc[1] = zero16;
 
   att_stage(kb, p.ldk, 0, p.Tk, smem, wave, lane);
   att_stage(vb, p.ldv, 0, p.Tk, smem + 8192, wave, lane);
   __syncthreads();
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
+
+  auto tile = [&](auto cur_tag, int kt) {
+    constexpr int CUR = decltype(cur_tag)::value;
     const int key0 = kt * 64;
     if (kt + 1 < nkt) {
-      att_stage(kb, p.ldk, key0 + 64, p.Tk, smem + (cur ^ 1) * 16384, wave, lane);
-      att_stage(vb, p.ldv, key0 + 64, p.Tk, smem + (cur ^ 1) * 16384 + 8192, wave, lane);
+      att_stage(kb, p.ldk, key0 + 64, p.Tk, smem + (CUR ^ 1) * 16384, wave, lane);
+      att_stage(vb, p.ldv, key0 + 64, p.Tk, smem + (CUR ^ 1) * 16384 + 8192, wave, lane);
     }
-    const char* kt_l = smem + cur * 16384;
+    const char* kt_l = smem + CUR * 16384;
     const char* vt_l = kt_l + 8192;
-    const bool active = !(p.causal && key0 > qw0 + 31);
-    if (active) {
+    if (!(p.causal && key0 > qw0 + 31)) {
       f32x16 sacc[2], pacc[2];
 #pragma unroll
       for (int kb2 = 0; kb2 < 2; ++kb2) {
-        sacc[kb2] = f32x16{0};
-        pacc[kb2] = f32x16{0};
+        sacc[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_row_frag(kt_l, offs, kb2, 0), qf[0], zero16, 0, 0, 0);
+        pacc[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_row_frag(vt_l, offs, kb2, 0), dof[0], zero16, 0, 0, 0);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          sacc[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_row_frag(kt_l, kb2, s, lane), qf[s],
-                                                              sacc[kb2], 0, 0, 0);
-          pacc[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_row_frag(vt_l, kb2, s, lane), dof[s],
-                                                              pacc[kb2], 0, 0, 0);
+        for (int s = 1; s < 4; ++s) {
+          sacc[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_row_frag(kt_l, offs, kb2, s), qf[s], sacc[kb2], 0, 0, 0);
+          pacc[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_row_frag(vt_l, offs, kb2, s), dof[s], pacc[kb2], 0, 0, 0);
         }
       }
       if ((key0 + 64 > p.Tk) || (p.causal && key0 + 63 > qw0)) {
@@ -305,12 +335,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
         const bf16x8 dsf = att_pack8(sacc[ks >> 1], ks & 1);
 #pragma unroll
         for (int db = 0; db < 2; ++db)
-          dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_tr_frag(kt_l, ks, db, lane), dsf,
-                                                              dqacc[db], 0, 0, 0);
+          dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_tr_frag(kt_l, offs, ks, db), dsf, dqacc[db], 0, 0, 0);
       }
     }
     __syncthreads();
+  };
+  int kt = 0;
+  for (; kt + 1 < nkt; kt += 2) {
+    tile(IntC<0>{}, kt);
+    tile(IntC<1>{}, kt + 1);
   }
+  if (kt < nkt) tile(IntC<0>{}, kt);
+
   if (qi < p.Tq) {
     unsigned short* drow = p.dq + (long)b * p.dq_bs + (long)qi * p.lddq + hd * 64;
 #pragma unroll
@@ -326,9 +362,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
 }
 
 // ------------------------------------------------------------------------------ dK, dV
+#define DKDV_BUF (16384 + 512)
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
   // [buf 2][Q 8K | dO 8K | lse 256 B | delta 256 B]
-  __shared__ __attribute__((aligned(16))) char smem[2 * (16384 + 512)];
+  __shared__ __attribute__((aligned(16))) char smem[2 * DKDV_BUF];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int k0 = blockIdx.x * 128, hd = blockIdx.y, b = blockIdx.z;
@@ -347,15 +384,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
     kf[s] = att_load_reg_frag(krow, s, h);
     vf[s] = att_load_reg_frag(vrow, s, h);
   }
+  const AttOffs offs = att_offsets(lane);
   const float c = p.scale * LOG2E;
   const int nqt = (p.Tq + 63) >> 6;
   const int qt0 = p.causal ? (k0 >> 6) : 0;  // first query tile that can see key k0
+  const f32x16 zero16 = f32x16{0};
   f32x16 dkacc[2], dvacc[2];
-  dkacc[0] = f32x16{0}; dkacc[1] = f32x16{0};
-  dvacc[0] = f32x16{0}; dvacc[1] = f32x16{0};
+  dkacc[0] = zero16; dkacc[1] = zero16;
+  dvacc[0] = zero16; dvacc[1] = zero16;
 
-  auto stage_q = [&](int buf, int qt) {
-    char* base = smem + buf * (16384 + 512);
+  auto stage_q = [&](char* base, int qt) {
     att_stage(qb, p.ldq, qt * 64, p.Tq, base, wave, lane);
     att_stage(dob, p.lddo, qt * 64, p.Tq, base + 8192, wave, lane);
     if (tid < 64) {
@@ -368,26 +406,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
   };
 
   if (qt0 < nqt) {
-    stage_q(0, qt0);
+    stage_q(smem, qt0);
     __syncthreads();
   }
-  for (int qt = qt0; qt < nqt; ++qt) {
-    const int cur = (qt - qt0) & 1;
+  auto tile = [&](auto cur_tag, int qt) {
+    constexpr int CUR = decltype(cur_tag)::value;
     const int qq0 = qt * 64;
-    if (qt + 1 < nqt) stage_q(cur ^ 1, qt + 1);
-    const char* q_l = smem + cur * (16384 + 512);
+    if (qt + 1 < nqt) stage_q(smem + (CUR ^ 1) * DKDV_BUF, qt + 1);
+    const char* q_l = smem + CUR * DKDV_BUF;
     const char* do_l = q_l + 8192;
     const float* lse_l = (const float*)(q_l + 16384);
     const float* dlt_l = lse_l + 64;
-    const bool active = !(p.causal && kw0 > qq0 + 63);
-    if (active) {
+    if (!(p.causal && kw0 > qq0 + 63)) {
 #pragma unroll
       for (int qb2 = 0; qb2 < 2; ++qb2) {
-        f32x16 sacc = f32x16{0}, pacc = f32x16{0};
+        f32x16 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_row_frag(q_l, offs, qb2, 0), kf[0], zero16, 0, 0, 0);
+        f32x16 pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_row_frag(do_l, offs, qb2, 0), vf[0], zero16, 0, 0, 0);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_row_frag(q_l, qb2, s, lane), kf[s], sacc, 0, 0, 0);
-          pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_row_frag(do_l, qb2, s, lane), vf[s], pacc, 0, 0, 0);
+        for (int s = 1; s < 4; ++s) {
+          sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_row_frag(q_l, offs, qb2, s), kf[s], sacc, 0, 0, 0);
+          pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_row_frag(do_l, offs, qb2, s), vf[s], pacc, 0, 0, 0);
         }
         f32x16 dsacc;
         const bool need_mask = (qq0 + 32 * qb2 + 32 > p.Tq) || (kw0 + 32 > p.Tk) || (p.causal && kw0 + 31 > qq0 + 32 * qb2);
@@ -420,16 +458,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
           const bf16x8 dsf = att_pack8(dsacc, ks);
 #pragma unroll
           for (int db = 0; db < 2; ++db) {
-            dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_tr_frag(do_l, 2 * qb2 + ks, db, lane), pf,
-                                                                dvacc[db], 0, 0, 0);
-            dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_tr_frag(q_l, 2 * qb2 + ks, db, lane), dsf,
-                                                                dkacc[db], 0, 0, 0);
+            dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_tr_frag(do_l, offs, 2 * qb2 + ks, db), pf, dvacc[db], 0, 0, 0);
+            dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_tr_frag(q_l, offs, 2 * qb2 + ks, db), dsf, dkacc[db], 0, 0, 0);
           }
         }
       }
     }
     __syncthreads();
+  };
+  int qt = qt0;
+  for (; qt + 1 < nqt; qt += 2) {
+    tile(IntC<0>{}, qt);
+    tile(IntC<1>{}, qt + 1);
   }
+  if (qt < nqt) tile(IntC<0>{}, qt);
+
   if (ki < p.Tk) {
     unsigned short* dkrow = p.dk + (long)b * p.dk_bs + (long)ki * p.lddk + hd * 64;
     unsigned short* dvrow = p.dv + (long)b * p.dv_bs + (long)ki * p.lddv + hd * 64;
