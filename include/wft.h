@@ -122,6 +122,11 @@ typedef struct {
   int64_t M; int64_t N; int64_t K; int batch;
   int valid_rows_period; int valid_rows;
   int residual_first;  /* != 0: add the residual BEFORE the epilogue op (gelu / dgelu) instead of after */
+  /* wft_gemm_tn_bf16 only: optional caller-owned scratch for split-K partial tiles.  With at least
+   * wft_gemm_tn_workspace_bytes(args) bytes the partials are written with plain stores and summed in a
+   * fixed order by a second kernel (bitwise reproducible); with NULL / too small they are added to C
+   * with fp32 atomics (order-dependent in the last bits).                                            */
+  void* workspace; int64_t workspace_bytes;
 } wft_gemm_args;
 int wft_gemm_nt_bf16(const wft_gemm_args* args, void* stream);
 /* Which kernel wft_gemm_nt_bf16 dispatches these arguments to: 256 (gemm_nt256_kernel, 256x256
@@ -135,6 +140,7 @@ int wft_gemm_nt_variant(const wft_gemm_args* args);
  *  Uses the same wft_gemm_args: M:=P, N:=Q, K:=R; bias/residual/aux ignored.
  *  batch > 1 sums over the batch as extra reduction (conv weight grads).     */
 int wft_gemm_tn_bf16(const wft_gemm_args* args, void* stream);
+int64_t wft_gemm_tn_workspace_bytes(const wft_gemm_args* args);
 
 /* -------------------------------------------------------------- Attention */
 /* whisper.model.MultiHeadAttention.qkv_attention:

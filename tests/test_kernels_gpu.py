@@ -296,3 +296,17 @@ def test_full_size_ce_gradient_rows_sum_to_zero():
     assert torch.equal(am, logits[:, :V].float().argmax(-1))
     dl = K.ce_bwd(logits, tgt, V, 0.1, lse, stats, torch.ones(1, device=DEV), inplace=False)
     assert dl[:, :V].float().sum(-1).abs().max().item() < 1e-4
+
+
+def test_gemm_tn_split_k_is_bitwise_reproducible():
+    """Weight-gradient GEMM at the BASELINE size: the split-K partials go through the workspace and are summed in a
+    fixed order, so two launches agree bit for bit (the fp32-atomic fallback does not)."""
+    g = torch.Generator(device=DEV).manual_seed(5)
+    a = bf(torch.randn(48000, 1280, device=DEV, generator=g)); b = bf(torch.randn(48000, 1280, device=DEV, generator=g))
+    c1 = K.gemm_tn(a, b); c2 = K.gemm_tn(a, b)
+    assert torch.equal(c1, c2)
+    ref = a[:6000].float().t() @ b[:6000].float()
+    close(K.gemm_tn(a[:6000], b[:6000]), ref, 2e-5)
+    acc = torch.ones(1280, 1280, device=DEV)
+    K.gemm_tn(a, b, out=acc, accumulate=True)
+    close(acc, c1 + 1, 1e-6)

@@ -26,6 +26,7 @@ struct GemmP {
   int accumulate;
   int period, valid;
   int res_first;
+  float* ws;  // split-K partial tiles [nsplit][P][Q] fp32 (TN, optional)
   int diag;  // timing-only diagnostic builds of the 256 kernel (WFT_GEMM_DIAG): 1 no vmcnt wait, 2 no staging loads, 3 = 2 + no barrier
 };
 
@@ -726,6 +727,23 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmP p) {
   // D[q][p]: lane (li, g) holds acc[i][j][e] = C[p = j*16 + li][q = i*16 + 4g + e] of the wave tile
   if (nsplit > 1) {
     float* lds = (float*)(dsmem + wave * 8448);  // [16 p][132] fp32 per pass
+    if (p.ws) {
+      // deterministic split-K: this split's partial tile goes to the workspace with plain 16-byte stores
+      // (rows of 128 fp32 = 512 B per wave: 32 lanes x 16 B), summed later in split order
+      float* wbase = p.ws + ((long)blockIdx.y * P + p0 + wp * 64) * Q + q0 + wq * 128;
+      const int hr = lane >> 5, c4 = (lane & 31) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *(f32x4*)(lds + li * 132 + i * 16 + 4 * g) = acc[i][j] * p.alpha;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 16; r += 2)
+          *(f32x4*)(wbase + (long)(j * 16 + r + hr) * Q + c4) = *(const f32x4*)(lds + (r + hr) * 132 + c4);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      return;
+    }
     float* cbase = (float*)p.C + (long)(p0 + wp * 64) * p.ldc + q0 + wq * 128 + lane;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -762,6 +780,20 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmP p) {
   }
 }
 
+// split-K reduction: C[p][q] (+)= sum_s ws[s][p][q], splits added in index order (reproducible)
+__global__ __launch_bounds__(256) void tn_splitk_reduce_kernel(const float* ws, float* C, long ldc, int P, int Q, int nsplit,
+                                                                int accumulate) {
+  const long nq4 = Q >> 2;
+  const long total = (long)P * nq4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long pp = i / nq4, q4 = (i - pp * nq4) * 4;
+    float* cp = C + pp * ldc + q4;
+    f32x4 s = accumulate ? *(const f32x4*)cp : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < nsplit; ++k) s += *(const f32x4*)(ws + ((long)k * P + pp) * Q + q4);
+    *(f32x4*)cp = s;
+  }
+}
+
 // ---------------------------------------------------------------------------------- host
 static int g_diag = 0;
 static bool g_force_128 = false;  // debugging / A-B switch: WFT_GEMM_FORCE_128=1
@@ -780,6 +812,7 @@ static int fill_params(const wft_gemm_args* a, GemmP& p) {
   p.period = a->valid_rows_period; p.valid = a->valid_rows;
   p.res_first = a->residual_first;
   p.diag = g_diag;
+  p.ws = nullptr;
   return 0;
 }
 
@@ -865,6 +898,30 @@ extern "C" int wft_gemm_nt_bf16(const wft_gemm_args* a, void* stream) {
   return WFT_OK;
 }
 
+static bool tn_uses_256(const wft_gemm_args* a) {
+  const long nsteps = ((a->K + 63) / 64) * a->batch;
+  return !g_force_128 && a->c_is_f32 && a->M % 256 == 0 && a->N % 256 == 0 && nsteps >= 256;
+}
+static int tn256_nsplit(const wft_gemm_args* a) {
+  const long t256 = (a->M / 256) * (a->N / 256);
+  const long nslabs = ((a->K + 31) / 32) * a->batch;
+  const int ncu = wft_num_cus();
+  int nsplit = 1;
+  double best = 0.0;
+  for (int sp = 1; sp <= 16; ++sp) {
+    if (sp > 1 && nslabs / sp < 48) break;
+    const double waves = (double)(t256 * sp) / (double)ncu;
+    const double eff = waves / (double)((long)(waves + 0.999999));
+    if (eff > best + 0.02) { best = eff; nsplit = sp; }
+  }
+  return nsplit;
+}
+extern "C" int64_t wft_gemm_tn_workspace_bytes(const wft_gemm_args* a) {
+  if (!a || !tn_uses_256(a)) return 0;
+  const int nsplit = tn256_nsplit(a);
+  return nsplit > 1 ? (int64_t)nsplit * a->M * a->N * 4 : 0;
+}
+
 extern "C" int wft_gemm_tn_bf16(const wft_gemm_args* a, void* stream) {
   WFT_CHECK_ARG(a && a->A && a->B && a->C, "null pointer");
   WFT_CHECK_ARG(a->M >= 128 && a->N >= 128 && a->K >= 1 && a->batch >= 1, "bad shape");
@@ -878,24 +935,26 @@ extern "C" int wft_gemm_tn_bf16(const wft_gemm_args* a, void* stream) {
   fill_params(a, p);
   hipStream_t s = (hipStream_t)stream;
   const long nsteps = ((a->K + 63) / 64) * a->batch;
-  if (!g_force_128 && a->c_is_f32 && a->M % 256 == 0 && a->N % 256 == 0 && nsteps >= 256) {
-    const long nslabs = ((a->K + 31) / 32) * a->batch;
+  if (tn_uses_256(a)) {
     // 256x256 tiles, one workgroup per CU: pick the split-K factor that fills 256 slots in whole waves
     const long t256 = (a->M / 256) * (a->N / 256);
-    int nsplit = 1;
-    double best = 0.0;
-    for (int sp = 1; sp <= 16; ++sp) {
-      if (sp > 1 && nslabs / sp < 48) break;
-      const double waves = (double)(t256 * sp) / 256.0;
-      const double eff = waves / (double)((long)(waves + 0.999999));
-      if (eff > best + 0.02) { best = eff; nsplit = sp; }
-    }
-    if (nsplit > 1 && !a->accumulate)
+    const int nsplit = tn256_nsplit(a);
+    const bool use_ws = nsplit > 1 && a->workspace && a->workspace_bytes >= (int64_t)nsplit * a->M * a->N * 4 &&
+                        (((uintptr_t)a->workspace) & 15) == 0;
+    if (use_ws) p.ws = (float*)a->workspace;
+    if (nsplit > 1 && !use_ws && !a->accumulate)
       (void)hipMemset2DAsync(a->C, (size_t)a->ldc * 4, 0, (size_t)a->N * 4, (size_t)a->M, s);
     static bool done = false;
     auto kfn = gemm_tn256_kernel<true>;
     if (!done) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); done = true; }
     hipLaunchKernelGGL(kfn, dim3((unsigned)t256, (unsigned)nsplit), dim3(512), 131072, s, p);
+    if (use_ws) {
+      const long total = a->M * (a->N / 4);
+      long g = (total + 255) / 256;
+      if (g > 2048) g = 2048;
+      hipLaunchKernelGGL(tn_splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, (const float*)a->workspace, (float*)a->C,
+                         (long)a->ldc, (int)a->M, (int)a->N, nsplit, a->accumulate);
+    }
     WFT_CHECK_LAUNCH();
     return WFT_OK;
   }

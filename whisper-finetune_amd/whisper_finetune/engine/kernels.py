@@ -219,8 +219,27 @@ def gemm_tn(a, b, *, P=None, Q=None, R=None, lda=None, ldb=None, out=None, out_f
     args.c_is_f32, args.accumulate = int(out.dtype == F32), int(accumulate)
     args.epilogue, args.alpha = L.EPI_NONE, alpha
     args.M, args.N, args.K, args.batch = P, Q, R, batch
-    L.check(L.load().wft_gemm_tn_bf16(C.byref(args), L.stream_ptr()), "wft_gemm_tn_bf16")
+    lib = L.load()
+    need = lib.wft_gemm_tn_workspace_bytes(C.byref(args))
+    if need > 0:
+        ws = _tn_workspace(a.device, need)
+        args.workspace, args.workspace_bytes = ws.data_ptr(), ws.numel()
+    L.check(lib.wft_gemm_tn_bf16(C.byref(args), L.stream_ptr()), "wft_gemm_tn_bf16")
     return out
+
+
+_TN_WS = {}
+
+
+def _tn_workspace(device, nbytes: int) -> torch.Tensor:
+    """Per-device scratch for deterministic split-K weight-gradient GEMMs (grown on demand, reused: all
+    launches are ordered on one stream)."""
+    key = (device.type, device.index)
+    ws = _TN_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+        _TN_WS[key] = ws
+    return ws
 
 
 # --------------------------------------------------------------------------- attention

@@ -32,6 +32,7 @@ class GemmArgs(C.Structure):
         ("M", c_i64), ("N", c_i64), ("K", c_i64), ("batch", C.c_int),
         ("valid_rows_period", C.c_int), ("valid_rows", C.c_int),
         ("residual_first", C.c_int),
+        ("workspace", c_vp), ("workspace_bytes", c_i64),
     ]
 
 
@@ -72,6 +73,7 @@ SIGNATURES = {
     "wft_gemm_nt_bf16": [C.POINTER(GemmArgs), c_vp],
     "wft_gemm_nt_variant": [C.POINTER(GemmArgs)],
     "wft_gemm_tn_bf16": [C.POINTER(GemmArgs), c_vp],
+    "wft_gemm_tn_workspace_bytes": [C.POINTER(GemmArgs)],
     "wft_attn_fwd_bf16": [C.POINTER(AttnArgs), c_vp],
     "wft_attn_bwd_bf16": [C.POINTER(AttnArgs), c_vp],
     "wft_embed_fwd": [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, C.c_int, c_i64, c_vp],
@@ -88,7 +90,8 @@ SIGNATURES = {
     "wft_last_error": [],
     "wft_version": [],
 }
-_RESTYPES = {"wft_last_error": C.c_char_p, "wft_version": C.c_char_p, "wft_layernorm_bwd_workspace": c_i64}
+_RESTYPES = {"wft_last_error": C.c_char_p, "wft_version": C.c_char_p, "wft_layernorm_bwd_workspace": c_i64,
+             "wft_gemm_tn_workspace_bytes": c_i64}
 
 _lib = None
 
