@@ -30,6 +30,20 @@ struct GemmP {
   int diag;  // timing-only diagnostic builds of the 256 kernel (WFT_GEMM_DIAG): 1 no vmcnt wait, 2 no staging loads, 3 = 2 + no barrier
 };
 
+// sid -> (row tile, column tile) in column BANDS of 5 tiles, row-major inside a band: the 32 workgroups an XCD
+// runs at a time (consecutive sids) then cover a ~6 x 5 patch = 11 operand panels instead of 2 x 20 = 22 for a
+// wide N.  Measured before: FETCH_SIZE of the 48000x5120x1280 GEMM was 8x its algorithmic A+B bytes (every XCD
+// re-streamed all of B every round).
+__device__ __forceinline__ void band_coords(int sid, int tiles_r, int tiles_c, int& tr, int& tc) {
+  const int W = 5;
+  const int band = sid / (tiles_r * W);
+  const int c0 = band * W;
+  const int w = (tiles_c - c0) < W ? (tiles_c - c0) : W;
+  const int r = sid - band * tiles_r * W;
+  tr = r / w;
+  tc = c0 + r - tr * w;
+}
+
 __device__ __forceinline__ int xcd_remap(int bid, int ntile) {
   const int q = ntile >> 3, r = ntile & 7, xcd = bid & 7;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
@@ -200,7 +214,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
   const unsigned short* src[4];
   auto set_src = [&](int t) {  // PERSISTENT: tile t of this workgroup's sequence
     const int bz = t / tiles, sid = xcd_remap(t - bz * tiles, tiles);
-    const int tm = sid / tiles_n, tn = sid - tm * tiles_n;
+    int tm, tn;
+    band_coords(sid, tiles_m, tiles_n, tm, tn);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int row = (wave & 3) * 64 + j * 16 + rr;
@@ -239,7 +254,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
 
   for (; t < total; t += gridDim.x) {
     const int bz = t / tiles, sid = xcd_remap(t - bz * tiles, tiles);
-    const int tm = sid / tiles_n, tn = sid - tm * tiles_n;
+    int tm, tn;
+    band_coords(sid, tiles_m, tiles_n, tm, tn);
     const int m0 = tm << 8, n0 = tn << 8;
 
     f32x4 acc[8][4];
@@ -596,7 +612,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmP p) {
   const int tiles_q = Q >> 8;
   const int tiles_p = P >> 8;
   const int sid = xcd_remap(blockIdx.x, tiles_p * tiles_q);
-  const int tp = sid / tiles_q, tq = sid - tp * tiles_q;
+  int tp, tq;
+  band_coords(sid, tiles_p, tiles_q, tp, tq);
   const int p0 = tp << 8, q0 = tq << 8;
 
   const int spb = (R + 31) >> 5;  // 32-row slabs per batch item
