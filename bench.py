@@ -103,7 +103,7 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--model", default="large-v3")
-    ap.add_argument("--batch", type=int, default=32, help="clips per GPU per step")
+    ap.add_argument("--batch", type=int, default=68, help="clips per GPU per step")
     ap.add_argument("--seq", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -211,6 +211,7 @@ def main():
             "step_tflops_per_gpu": round(step_flops / world / (dt / args.steps) / 1e12, 1),
             "step_frac_of_bf16_peak": round(step_flops / world / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
             "final_loss": round(final_loss, 4),
+            "hbm_peak_gib": round(torch.cuda.max_memory_allocated() / 2**30, 1),
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

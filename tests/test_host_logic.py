@@ -250,3 +250,16 @@ def test_product_path_refuses_cpu_tensors():
     m = _tiny()
     with pytest.raises(L.WftError):
         m(torch.zeros(1, 80, 3000), torch.zeros(1, 4, dtype=torch.long))
+
+
+def test_any_torch_optimizer_step_invalidates_bf16_shadows():
+    """torch's fused optimizers do not bump tensor._version, so the shadow cache keys on an epoch that every
+    Optimizer.step() advances (engine/ops.py post-hook)."""
+    from whisper_finetune.engine import ops
+
+    p = torch.nn.Parameter(torch.randn(4, 4))
+    p.grad = torch.randn(4, 4)
+    for opt in (torch.optim.AdamW([p], lr=1e-3), torch.optim.SGD([p], lr=1e-3)):
+        before = ops._SHADOW_EPOCH[0]
+        opt.step()
+        assert ops._SHADOW_EPOCH[0] == before + 1

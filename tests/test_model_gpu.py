@@ -226,3 +226,23 @@ def test_save_model_round_trip(tmp_path):
     assert set(ck) == {"model_state_dict", "dims"} and ck["dims"]["n_audio_state"] == 384
     assert all(v.dtype == torch.float16 for k, v in ck["model_state_dict"].items() if v.is_floating_point())
     assert set(ck["model_state_dict"]) == set(params)
+
+
+def test_fused_adamw_update_reaches_the_bf16_weight_shadows():
+    """Regression: torch.optim.AdamW(fused=True) leaves tensor._version untouched; the forward after a step
+    must nevertheless run on the UPDATED weights (bf16 shadows rebuilt), as the reference's autocast does."""
+    dims, params, audio, y_in, y_out = _tiny_case()
+    m = _engine(dims, params).train()
+    mel = O.log_mel_spectrogram(audio, dims.n_mels).to(DEV)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-2, fused=True)
+    w = m.encoder.blocks[0].mlp[0].weight
+    m(mel, y_in.to(DEV), targets=y_out.to(DEV), label_smoothing=0.0).backward()
+    opt.step()
+    opt.zero_grad(set_to_none=True)
+    m.eval()
+    with torch.no_grad():
+        after = m(mel, y_in.to(DEV))
+        fresh = _engine(dims, {k: v.detach().cpu() for k, v in m.state_dict().items()}).eval()
+        want = fresh(mel, y_in.to(DEV))
+    assert (w.detach().cpu() - params["encoder.blocks.0.mlp.0.weight"]).abs().max() > 1e-3  # the step moved the weights
+    assert torch.equal(after, want)  # same kernels, same fp32 masters -> identical logits

@@ -10,6 +10,7 @@ from __future__ import annotations
 from typing import List, Optional, Sequence, Tuple
 
 import torch
+from torch.optim.optimizer import register_optimizer_step_post_hook
 
 from . import kernels as K
 from . import lib as L
@@ -24,6 +25,16 @@ _SHADOW_EPOCH = [0]
 
 def bump_shadow_epoch():
     _SHADOW_EPOCH[0] += 1
+
+
+# torch's fused / foreach optimizers update parameters WITHOUT bumping `_version` (observed with
+# AdamW(fused=True): p._version stays 0 across steps), so the version part of the key cannot see them.
+# Every torch.optim.Optimizer.step() therefore invalidates the shadows through a global post-hook.
+def _optimizer_post_hook(optimizer, args, kwargs):
+    bump_shadow_epoch()
+
+
+register_optimizer_step_post_hook(_optimizer_post_hook)
 
 
 def _ver(t: Optional[torch.Tensor]):
