@@ -16,6 +16,9 @@
 // ds_read_b128 operand reads and the 4-row transposed reads.
 #include "common.h"
 
+#ifndef ATT_PK
+#define ATT_PK 1
+#endif
 #define ATT_NEG (-1.0e30f)
 #define LOG2E 1.4426950408889634f
 
@@ -38,18 +41,73 @@ __device__ __forceinline__ int att_F(int row) { return (((row >> 1) & 1) << 2) |
 
 // Stage one [64][64] bf16 tile (rows row0.. of a [nrows, ld] matrix, 64 columns at `base`).
 // 8 wave-instructions of 8 rows x 128 B; wave w issues instructions 2w, 2w+1.
-__device__ __forceinline__ void att_stage(const unsigned short* base, long ld, int row0, int nrows,
-                                          char* tile, int wave, int lane) {
+// The per-lane part of the source address (row-in-tile * ld + swizzled chunk) is computed ONCE per kernel
+// (AttStage); a full tile then costs no vector arithmetic at all: the tile origin is a wave-uniform 64-bit
+// base (SALU) and the load uses the saddr + 32-bit-voffset form.  (Before: 16 v_mul_lo_u32 + 8 v_mad_u64_u32
+// per tile, ~25 % of the forward kernel's VALU cycles.)  Only the ragged last tile clamps rows per lane.
+struct AttStage {
+  unsigned off[2];  // byte offset of this lane's 16 bytes inside a tile whose row 0 is the base
+  int row[2];
+};
+__device__ __forceinline__ AttStage att_stage_init(long ld, int wave, int lane) {
+  AttStage st;
   const int rr = lane >> 3, cp = lane & 7;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int i = wave * 2 + j;
-    const int row = 8 * i + rr;
-    int gr = row0 + row;
-    gr = gr < nrows ? gr : nrows - 1;
-    const int c = cp ^ att_F(row);
-    glds16(base + (long)gr * ld + c * 8, tile + i * 1024);
+    const int row = 8 * (wave * 2 + j) + rr;
+    st.row[j] = row;
+    st.off[j] = (unsigned)(row * (int)ld + ((cp ^ att_F(row)) << 3)) * 2u;
   }
+  return st;
+}
+template <bool RAGGED>
+__device__ __forceinline__ void att_stage1(const AttStage& st, const unsigned short* base, long ld, int row0, int nrows,
+                                           char* tile, int wave, int lane) {
+  const char* tb = (const char*)base + (long)row0 * ld * 2;  // wave-uniform
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    unsigned off = st.off[j];
+    if (RAGGED) {
+      int rl = st.row[j];
+      rl = row0 + rl < nrows ? rl : nrows - 1 - row0;
+      off = (unsigned)(rl * (int)ld + (((lane & 7) ^ att_F(st.row[j])) << 3)) * 2u;
+    }
+    glds16(tb + off, tile + (wave * 2 + j) * 1024);
+  }
+}
+__device__ __forceinline__ void att_stage(const AttStage& st, const unsigned short* base, long ld, int row0, int nrows,
+                                          char* tile, int wave, int lane) {
+  if (row0 + 64 <= nrows) att_stage1<false>(st, base, ld, row0, nrows, tile, wave, lane);
+  else att_stage1<true>(st, base, ld, row0, nrows, tile, wave, lane);
+}
+// two tiles that share row0 / nrows (K and V, or Q and dO): ONE wave-uniform branch for both
+__device__ __forceinline__ void att_stage2(const AttStage& sa, const unsigned short* a, long lda, char* ta,
+                                           const AttStage& sb, const unsigned short* b, long ldb, char* tb,
+                                           int row0, int nrows, int wave, int lane) {
+  if (row0 + 64 <= nrows) {
+    att_stage1<false>(sa, a, lda, row0, nrows, ta, wave, lane);
+    att_stage1<false>(sb, b, ldb, row0, nrows, tb, wave, lane);
+  } else {
+    att_stage1<true>(sa, a, lda, row0, nrows, ta, wave, lane);
+    att_stage1<true>(sb, b, ldb, row0, nrows, tb, wave, lane);
+  }
+}
+
+// attn.hip is compiled with -ffinite-math-only (Makefile): without it hipcc canonicalises (v_max_f32 x,x,x) every MFMA
+// result in front of fmaxf, ~25 extra VALU instructions per tile.  Scores are finite by construction (masked entries
+// are -1e30, never -inf).  Plain builtins (not inline asm) so the compiler's MFMA->VALU hazard handling still applies.
+__device__ __forceinline__ float att_max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+__device__ __forceinline__ float att_max2(float a, float b) { return __builtin_fmaxf(a, b); }
+// max over the 32 scores a lane holds for its query (two 32x32 accumulator blocks)
+__device__ __forceinline__ float att_max32(const f32x16& a, const f32x16& b) {
+  float t0 = att_max3(a[0], a[1], a[2]), t1 = att_max3(a[3], a[4], a[5]);
+  float t2 = att_max3(b[0], b[1], b[2]), t3 = att_max3(b[3], b[4], b[5]);
+  t0 = att_max3(t0, a[6], a[7]);   t1 = att_max3(t1, a[8], a[9]);
+  t2 = att_max3(t2, b[6], b[7]);   t3 = att_max3(t3, b[8], b[9]);
+  t0 = att_max3(t0, a[10], a[11]); t1 = att_max3(t1, a[12], a[13]);
+  t2 = att_max3(t2, b[10], b[11]); t3 = att_max3(t3, b[12], b[13]);
+  t0 = att_max3(t0, a[14], a[15]); t2 = att_max3(t2, b[14], b[15]);
+  return att_max3(att_max2(t0, t1), t2, t3);
 }
 
 // Per-lane LDS byte offsets of every fragment read, computed ONCE per kernel: with the tile base a
@@ -103,12 +161,50 @@ __device__ __forceinline__ bf16x8 att_load_reg_frag(const unsigned short* rowptr
   return *(const bf16x8*)(rowptr + 16 * s + 8 * h);
 }
 
+// ds_read_b64_tr_b16 from inline asm (the caller owns s_waitcnt lgkmcnt + sched_barrier before first use; see
+// common.h lds_read_tr16_asm) with the slot / fragment offset in the instruction's immediate field
+template <int IMM>
+__device__ __forceinline__ s16x4 att_tr_asm(unsigned lds_byte_addr) {
+  s16x4 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(lds_byte_addr), "n"(IMM));
+  return r;
+}
+__device__ __forceinline__ bf16x8 att_join(s16x4 a, s16x4 b) {
+  s16x8 out;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { out[e] = a[e]; out[4 + e] = b[e]; }
+  return __builtin_bit_cast(bf16x8, out);
+}
+// lanes l and l^32 hold the two halves of one query's row: combine them with v_permlane32_swap (VALU) instead of
+// a ds_bpermute round trip through the LDS pipe.  (Inline asm: hipcc folds the builtin's two results into one value
+// when both inputs are the same variable.  s_nop 1 covers the VALU-write -> permlane-read hazard.)
+__device__ __forceinline__ void att_xhalf(float v, float& a, float& b) {
+  a = v;
+  b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float att_xhalf_max(float v) {
+  float a, b;
+  att_xhalf(v, a, b);
+  return att_max2(a, b);
+}
+__device__ __forceinline__ float att_xhalf_sum(float v) {
+  float a, b;
+  att_xhalf(v, a, b);
+  return a + b;
+}
+
 template <int V>
 struct IntC { static constexpr int value = V; };
 
 // ------------------------------------------------------------------------------ forward
+// K/V tiles travel through a THREE-slot LDS ring, staged two tiles ahead of their use, and the end-of-tile
+// wait is a counted s_waitcnt vmcnt(4) (this wave's 4 LDS-DMA instructions of tile kt+2 may stay in flight).
+// The transposed V reads are inline asm: with the builtin, hipcc drains every outstanding LDS-DMA
+// (s_waitcnt vmcnt(0)) in front of the first ds_read_b64_tr of each tile, which cut the prefetch distance to
+// half a tile and left the kernel latency-bound (no-load experiment: +27 %).
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
-  __shared__ __attribute__((aligned(16))) char smem[32768];  // [buf 2][K 8K | V 8K]
+  __shared__ __attribute__((aligned(16))) char smem[3 * 16384];  // [slot 3][K 8K | V 8K]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int q0 = blockIdx.x * 128, hd = blockIdx.y, b = blockIdx.z;
@@ -122,6 +218,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
 #pragma unroll
   for (int s = 0; s < 4; ++s) qf[s] = att_load_reg_frag(qrow, s, h);
   const AttOffs offs = att_offsets(lane);
+  const AttStage stK = att_stage_init(p.ldk, wave, lane), stV = att_stage_init(p.ldv, wave, lane);
+  const unsigned lds0 = lds_addr_of(smem);
+  unsigned tra[2][2];  // absolute LDS byte addresses of the transposed reads in slot 0's K tile
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) tra[db][t] = lds0 + offs.tr[db][t];
 
   int nkt = (p.Tk + 63) >> 6;
   if (p.causal) {
@@ -135,27 +238,45 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   oacc[1] = zero16;
   float m = ATT_NEG, l = 0.f;
 
-  att_stage(kb, p.ldk, 0, p.Tk, smem, wave, lane);
-  att_stage(vb, p.ldv, 0, p.Tk, smem + 8192, wave, lane);
-  __syncthreads();
+  att_stage2(stK, kb, p.ldk, smem, stV, vb, p.ldv, smem + 8192, 0, p.Tk, wave, lane);
+  if (nkt > 1) {
+    att_stage2(stK, kb, p.ldk, smem + 16384, stV, vb, p.ldv, smem + 16384 + 8192, 64, p.Tk, wave, lane);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  bf16x8 kf[2][4];  // K row fragments of the CURRENT tile; refilled for the next tile behind the mid-tile barrier
+#pragma unroll
+  for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) kf[kb2][s] = att_row_frag(smem, offs, kb2, s);
 
+  // One tile = [stage kt+2 | V^T reads | S MFMAs | softmax | wait + barrier | K reads of kt+1 | PV MFMAs]: every LDS
+  // read is issued a phase ahead of its use, and the only barrier sits where tile kt+1 must have landed.
   auto tile = [&](auto cur_tag, int kt) {
     constexpr int CUR = decltype(cur_tag)::value;
+    constexpr int NXT = (CUR + 1) % 3, NXT2 = (CUR + 2) % 3;
     const int key0 = kt * 64;
-    if (kt + 1 < nkt) {
-      att_stage(kb, p.ldk, key0 + 64, p.Tk, smem + (CUR ^ 1) * 16384, wave, lane);
-      att_stage(vb, p.ldv, key0 + 64, p.Tk, smem + (CUR ^ 1) * 16384 + 8192, wave, lane);
-    }
-    const char* kt_l = smem + CUR * 16384;
-    const char* vt_l = kt_l + 8192;
-    if (!(p.causal && key0 > qw0 + 31)) {
+    const bool more = kt + 2 < nkt;
+    if (more)
+      att_stage2(stK, kb, p.ldk, smem + NXT2 * 16384, stV, vb, p.ldv, smem + NXT2 * 16384 + 8192, key0 + 128, p.Tk, wave, lane);
+    const bool active = !(p.causal && key0 > qw0 + 31);
+    s16x4 vt[4][2][2];
+    bf16x8 pf[4];
+    if (active) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) vt[ks][db][t] = att_tr_asm<CUR * 16384 + 8192>(tra[db][t] + ks * 2048);
       f32x16 sacc[2];
 #pragma unroll
       for (int kb2 = 0; kb2 < 2; ++kb2) {
-        sacc[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_row_frag(kt_l, offs, kb2, 0), qf[0], zero16, 0, 0, 0);
+        sacc[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb2][0], qf[0], zero16, 0, 0, 0);
 #pragma unroll
-        for (int s = 1; s < 4; ++s)
-          sacc[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_row_frag(kt_l, offs, kb2, s), qf[s], sacc[kb2], 0, 0, 0);
+        for (int s = 1; s < 4; ++s) sacc[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb2][s], qf[s], sacc[kb2], 0, 0, 0);
       }
       // mask (only tiles that touch the ragged end / the causal diagonal: wave-uniform branch, selects inside)
       if ((key0 + 64 > p.Tk) || (p.causal && key0 + 63 > qw0)) {
@@ -166,13 +287,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
           for (int e = 0; e < 16; ++e)
             sacc[kb2][e] = (32 * kb2 + (e & 3) + 8 * (e >> 2)) < lim ? sacc[kb2][e] : ATT_NEG;
       }
-      float tmax = fmaxf(sacc[0][0], sacc[1][0]);
-#pragma unroll
-      for (int e = 1; e < 16; ++e) tmax = fmaxf(tmax, fmaxf(sacc[0][e], sacc[1][e]));  // v_max3_f32
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-      const float mnew = fmaxf(m, tmax);
+      const float mnew = att_max2(m, att_xhalf_max(att_max32(sacc[0], sacc[1])));
       const float alpha = __builtin_amdgcn_exp2f((m - mnew) * c);
-      // packed fp32 math (v_pk_fma_f32 / v_pk_add_f32): this kernel is VALU-bound (SQ_ACTIVE_INST_VALU ~82 %)
+      // packed fp32 math (v_pk_fma_f32 / v_pk_add_f32): the softmax is the VALU-heavy part of this kernel
+#if ATT_PK
       const f32x2 c2 = {c, c}, mc2 = {mnew * c, mnew * c};
       f32x2 ls2 = {0.f, 0.f};
 #pragma unroll
@@ -186,30 +304,58 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
           sacc[kb2][2 * e] = p2[0];
           sacc[kb2][2 * e + 1] = p2[1];
         }
-      float ls = ls2[0] + ls2[1];
-      ls += __shfl_xor(ls, 32, 64);
-      l = l * alpha + ls;
+      l = l * alpha + att_xhalf_sum(ls2[0] + ls2[1]);
+#else
+      const float mc = mnew * c;
+      float ls0 = 0.f, ls1 = 0.f;
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+          const float p0 = __builtin_amdgcn_exp2f(fmaf(sacc[kb2][e], c, -mc));
+          const float p1 = __builtin_amdgcn_exp2f(fmaf(sacc[kb2][e + 1], c, -mc));
+          ls0 += p0;
+          ls1 += p1;
+          sacc[kb2][e] = p0;
+          sacc[kb2][e + 1] = p1;
+        }
+      l = l * alpha + att_xhalf_sum(ls0 + ls1);
+#endif
       m = mnew;
 #pragma unroll
       for (int db = 0; db < 2; ++db)
 #pragma unroll
         for (int e = 0; e < 16; ++e) oacc[db][e] *= alpha;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 pf = att_pack8(sacc[ks >> 1], ks & 1);
+      for (int ks = 0; ks < 4; ++ks) pf[ks] = att_pack8(sacc[ks >> 1], ks & 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 1 < nkt) {
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) kf[kb2][s] = att_row_frag(smem + NXT * 16384, offs, kb2, s);
+    }
+    if (active) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int db = 0; db < 2; ++db)
-          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_tr_frag(vt_l, offs, ks, db), pf, oacc[db], 0, 0, 0);
-      }
+          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_join(vt[ks][db][0], vt[ks][db][1]), pf[ks], oacc[db], 0, 0, 0);
     }
-    __syncthreads();
   };
   int kt = 0;
-  for (; kt + 1 < nkt; kt += 2) {
+  for (; kt + 2 < nkt; kt += 3) {
     tile(IntC<0>{}, kt);
     tile(IntC<1>{}, kt + 1);
+    tile(IntC<2>{}, kt + 2);
   }
   if (kt < nkt) tile(IntC<0>{}, kt);
+  if (kt + 1 < nkt) tile(IntC<1>{}, kt + 1);
 
   if (qi < p.Tq) {
     const float inv = 1.0f / l;
@@ -273,6 +419,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
     dof[s] = att_load_reg_frag(dorow, s, h);
   }
   const AttOffs offs = att_offsets(lane);
+  const AttStage stK = att_stage_init(p.ldk, wave, lane), stV = att_stage_init(p.ldv, wave, lane);
   const long sidx = ((long)b * p.H + hd) * p.Tq + qc;
   const float lse2 = p.lse[sidx] * LOG2E;
   const float dlt = p.delta[sidx];
@@ -288,16 +435,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
   dqacc[0] = zero16;
   dqacc[1] = zero16;
 
-  att_stage(kb, p.ldk, 0, p.Tk, smem, wave, lane);
-  att_stage(vb, p.ldv, 0, p.Tk, smem + 8192, wave, lane);
+  att_stage2(stK, kb, p.ldk, smem, stV, vb, p.ldv, smem + 8192, 0, p.Tk, wave, lane);
   __syncthreads();
 
   auto tile = [&](auto cur_tag, int kt) {
     constexpr int CUR = decltype(cur_tag)::value;
     const int key0 = kt * 64;
     if (kt + 1 < nkt) {
-      att_stage(kb, p.ldk, key0 + 64, p.Tk, smem + (CUR ^ 1) * 16384, wave, lane);
-      att_stage(vb, p.ldv, key0 + 64, p.Tk, smem + (CUR ^ 1) * 16384 + 8192, wave, lane);
+      att_stage2(stK, kb, p.ldk, smem + (CUR ^ 1) * 16384, stV, vb, p.ldv, smem + (CUR ^ 1) * 16384 + 8192, key0 + 64, p.Tk,
+                 wave, lane);
     }
     const char* kt_l = smem + CUR * 16384;
     const char* vt_l = kt_l + 8192;
@@ -324,11 +470,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
             sacc[kb2][e] = pv * (pacc[kb2][e] - dlt);
           }
       } else {
+        // packed fp32 (v_pk_fma / v_pk_add / v_pk_mul): half the VALU issue slots of the scalar form
+        const f32x2 c2 = {c, c}, l2 = {lse2, lse2}, d2 = {dlt, dlt};
 #pragma unroll
         for (int kb2 = 0; kb2 < 2; ++kb2)
 #pragma unroll
-          for (int e = 0; e < 16; ++e)
-            sacc[kb2][e] = __builtin_amdgcn_exp2f(fmaf(sacc[kb2][e], c, -lse2)) * (pacc[kb2][e] - dlt);  // dS^T (unscaled)
+          for (int e = 0; e < 8; ++e) {
+            f32x2 t2 = {sacc[kb2][2 * e], sacc[kb2][2 * e + 1]};
+            t2 = t2 * c2 - l2;
+            const f32x2 p2 = {__builtin_amdgcn_exp2f(t2[0]), __builtin_amdgcn_exp2f(t2[1])};
+            f32x2 g2 = {pacc[kb2][2 * e], pacc[kb2][2 * e + 1]};
+            g2 = (g2 - d2) * p2;  // dS^T (unscaled)
+            sacc[kb2][2 * e] = g2[0];
+            sacc[kb2][2 * e + 1] = g2[1];
+          }
       }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -385,7 +540,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
     vf[s] = att_load_reg_frag(vrow, s, h);
   }
   const AttOffs offs = att_offsets(lane);
+  const AttStage stQ = att_stage_init(p.ldq, wave, lane), stDO = att_stage_init(p.lddo, wave, lane);
   const float c = p.scale * LOG2E;
+  const f32x2 c2 = {c, c};
   const int nqt = (p.Tq + 63) >> 6;
   const int qt0 = p.causal ? (k0 >> 6) : 0;  // first query tile that can see key k0
   const f32x16 zero16 = f32x16{0};
@@ -394,8 +551,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
   dvacc[0] = zero16; dvacc[1] = zero16;
 
   auto stage_q = [&](char* base, int qt) {
-    att_stage(qb, p.ldq, qt * 64, p.Tq, base, wave, lane);
-    att_stage(dob, p.lddo, qt * 64, p.Tq, base + 8192, wave, lane);
+    att_stage2(stQ, qb, p.ldq, base, stDO, dob, p.lddo, base + 8192, qt * 64, p.Tq, wave, lane);
     if (tid < 64) {
       const int qq = qt * 64 + tid;
       ((float*)(base + 16384))[tid] = qq < p.Tq ? lse_b[qq] * LOG2E : 0.f;
@@ -445,10 +601,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
             }
           } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[4 * a + e], c, -l4[e]));
-              sacc[4 * a + e] = pv;
-              dsacc[4 * a + e] = pv * (pacc[4 * a + e] - d4[e]);
+            for (int e = 0; e < 4; e += 2) {  // packed fp32 pairs
+              f32x2 t2 = {sacc[4 * a + e], sacc[4 * a + e + 1]};
+              const f32x2 l2 = {l4[e], l4[e + 1]}, d2 = {d4[e], d4[e + 1]};
+              t2 = t2 * c2 - l2;
+              const f32x2 p2 = {__builtin_amdgcn_exp2f(t2[0]), __builtin_amdgcn_exp2f(t2[1])};
+              f32x2 g2 = {pacc[4 * a + e], pacc[4 * a + e + 1]};
+              g2 = (g2 - d2) * p2;
+              sacc[4 * a + e] = p2[0];
+              sacc[4 * a + e + 1] = p2[1];
+              dsacc[4 * a + e] = g2[0];
+              dsacc[4 * a + e + 1] = g2[1];
             }
           }
         }
