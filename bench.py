@@ -43,13 +43,35 @@ def fwd_flops_per_clip(d, S: int) -> float:
     return conv + enc + dec + 2 * S * dm * V
 
 
-def build_model(name: str, device):
+def attn_core_flops_per_clip(d, S: int) -> float:
+    T, dm = d.n_audio_ctx, d.n_audio_state
+    return d.n_audio_layer * 4 * T * T * dm + d.n_text_layer * (4 * S * S * dm + 4 * S * T * dm)
+
+
+def lora_flops_per_clip(d, S: int, r: int) -> float:
+    """F_lora = sum over adapted Linears of 2*M*r*(in+out)  (SURVEY.md §8d)."""
+    T, dm = d.n_audio_ctx, d.n_audio_state
+    per_row_attn = 4 * 2 * r * (dm + dm)            # q, k, v, out
+    per_row_mlp = 2 * r * (dm + 4 * dm) * 2         # mlp.0, mlp.2
+    enc = d.n_audio_layer * T * (per_row_attn + per_row_mlp)
+    dec = d.n_text_layer * (S * (per_row_attn + per_row_mlp) + S * 2 * 2 * r * 2 * dm + T * 2 * 2 * r * 2 * dm)  # cross q,out on S; k,v on T
+    return enc + dec
+
+
+def build_model(name: str, device, sd_p: float = 0.0):
     from whisper_finetune.engine.whisper_model import MODEL_DIMS, Whisper, sinusoids
 
     dims = MODEL_DIMS[name]
     torch.manual_seed(0)
     with torch.device(device):
         model = Whisper(dims)
+        if sd_p > 0:
+            from whisper_finetune.model.model_utils import CheckpointedStochasticAudioEncoder, CheckpointedStochasticTextDecoder
+
+            model.encoder = CheckpointedStochasticAudioEncoder(dims.n_mels, dims.n_audio_ctx, dims.n_audio_state, dims.n_audio_head,
+                                                               dims.n_audio_layer, sd_p)
+            model.decoder = CheckpointedStochasticTextDecoder(dims.n_vocab, dims.n_text_ctx, dims.n_text_state, dims.n_text_head,
+                                                              dims.n_text_layer, sd_p)
     with torch.no_grad():
         for n, p in model.named_parameters():
             if p.dim() >= 2:
@@ -105,6 +127,10 @@ def main():
     ap.add_argument("--model", default="large-v3")
     ap.add_argument("--batch", type=int, default=68, help="clips per GPU per step")
     ap.add_argument("--seq", type=int, default=128)
+    ap.add_argument("--lora", action="store_true", help="BASELINE configs[2]: LoRA r=16 alpha=32 dropout 0.1 on every Linear")
+    ap.add_argument("--muon", action="store_true", help="Muon + auxiliary Adam param groups (config_large_v3_best_muon.yaml)")
+    ap.add_argument("--stochastic-depth", type=float, default=0.0)
+    ap.add_argument("--deep-spec-augment", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -127,7 +153,15 @@ def main():
     from whisper_finetune.engine import lib as L
 
     L.load()
-    model, dims = build_model(args.model, device)
+    model, dims = build_model(args.model, device, args.stochastic_depth)
+    if args.lora:
+        from whisper_finetune.model.lora import apply_lora
+
+        apply_lora(model, {"rank": 16, "lora_alpha": 32, "lora_dropout": 0.1})
+    if args.deep_spec_augment:
+        from whisper_finetune.model.model_utils import register_deep_spec_augment_hooks
+
+        register_deep_spec_augment_hooks(model, 100, 43)
     model.train()
     B, S = args.batch, args.seq
     torch.manual_seed(1234 + rank)  # per-rank host RNG (finetune.py:325)
@@ -136,19 +170,26 @@ def main():
     y_in, y_out = synthetic_tokens(B, S, device, rank)
     frontend = GpuFrontend(dims.n_mels, device, spec_augment=True,
                            spec_augment_params={"time_mask_param": 100, "freq_mask_param": 43, "time_warp_w": 80, "p": 1.0})
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-5, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.1, fused=True)
+    from whisper_finetune.model.optimizer import WftAdamW, get_optimizer
+
+    if args.muon:
+        opt = get_optimizer(model, {"type": "adamw", "muon": True, "8bit": False, "muon_params": {"lr": 2e-5, "momentum": 0.95, "weight_decay": 0.01},
+                                    "params": {"lr": 2e-5, "weight_decay": 0.01, "betas": [0.9, 0.98], "eps": 1e-6}}, is_lora_run=args.lora)
+    else:
+        # one wft_mt_sumsq + one wft_mt_adamw launch per step: clip_grad_norm_(1.0) folded into the AdamW pass
+        opt = WftAdamW([p for p in model.parameters() if p.requires_grad], lr=1e-5, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.1)
     net = model
     if world > 1:
         from torch.nn.parallel import DistributedDataParallel as DDP
 
         net = DDP(model, device_ids=[local_rank], output_device=local_rank, broadcast_buffers=False,
-                  gradient_as_bucket_view=True, bucket_cap_mb=64)
+                  gradient_as_bucket_view=True, bucket_cap_mb=64, find_unused_parameters=args.stochastic_depth > 0)
 
     def step():
         mel = frontend(audio, training=True)
         loss = net(mel, y_in, targets=y_out, label_smoothing=0.1)
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.fuse_clip_grad_norm(1.0)
         opt.step()
         opt.zero_grad(set_to_none=True)
         return loss
@@ -196,15 +237,21 @@ def main():
     if rank == 0:
         clips = B * world * args.steps
         value = clips * 30.0 / dt
-        step_flops = 3.0 * fwd_flops_per_clip(dims, S) * B * world
+        f_fwd, f_att = fwd_flops_per_clip(dims, S), attn_core_flops_per_clip(dims, S)
+        if args.lora:  # frozen base weights: no dW GEMMs
+            step_flops = (2.0 * (f_fwd - f_att) + 3.0 * f_att + 3.0 * lora_flops_per_clip(dims, S, 16)) * B * world
+        else:
+            step_flops = 3.0 * f_fwd * B * world
+        mode = ("LoRA r=16 alpha=32 p=0.1" if args.lora else "full fine-tune") + (", Muon+AuxAdam" if args.muon else ", AdamW") + \
+               (f", stochastic depth {args.stochastic_depth}" if args.stochastic_depth > 0 else "") + (", deep SpecAugment" if args.deep_spec_augment else "")
         out = {
             "metric": "audio-seconds/sec training throughput, whisper-large-v3 bf16",
             "value": round(value, 1), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {
-                "workload": f"whisper-{args.model} full fine-tune, bf16 MFMA / fp32 master weights, {B} synthetic 30 s clips per GPU "
-                            f"per step, decoder S={S}, log-mel + SpecAugment on GPU, label smoothing 0.1, clip 1.0, AdamW, "
+                "workload": f"whisper-{args.model} {mode}, bf16 MFMA / fp32 master weights, {B} synthetic 30 s clips per GPU "
+                            f"per step, decoder S={S}, log-mel + SpecAugment on GPU, label smoothing 0.1, clip 1.0, "
                             f"local accumulation 1 (global window = {world})",
                 "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world}",
             },

@@ -60,6 +60,9 @@ int wft_cast_pad_transpose_f32_bf16(const float* src, int64_t rows, int64_t cols
                                     int64_t ld_dst, int64_t ld_dst_t, void* stream);
 /* y[i] = a[i] + b[i] (bf16) — gradient accumulation on the residual stream. */
 int wft_add_bf16(const wft_bf16* a, const wft_bf16* b, wft_bf16* y, int64_t n, void* stream);
+/* out = a*x + b*y over n bf16 elements (y may be NULL).  StochasticDepthMixin's train-time rescale
+ * x + (block(x) - x)/(1-p) (model/model_utils.py:241-250) and its backward in one pass each.   */
+int wft_axpby_bf16(float a, const wft_bf16* x, float b, const wft_bf16* y, wft_bf16* out, int64_t n, void* stream);
 /* out[i] = dy[i] * gelu'(pre[i]) (exact-erf GELU) — backward through F.gelu in the
  * conv stem (model/model_utils.py:276-277).                                  */
 int wft_dgelu_mul_bf16(const wft_bf16* dy, const wft_bf16* pre, wft_bf16* out, int64_t n, void* stream);
@@ -127,6 +130,10 @@ typedef struct {
    * fixed order by a second kernel (bitwise reproducible); with NULL / too small they are added to C
    * with fp32 atomics (order-dependent in the last bits).                                            */
   void* workspace; int64_t workspace_bytes;
+  /* wft_gemm_nt_bf16 only: scale of the residual term, C = alpha*acc (+bias)(epilogue) + beta*residual.
+   * 0 is read as 1 so that zero-initialised structs keep the plain residual add.  (Newton-Schulz steps of the
+   * Muon optimizer: B = b*A + c*A@A, X' = a*X + B@X — muon.py zeropower_via_newtonschulz5.)            */
+  float beta; int reserved0;
 } wft_gemm_args;
 int wft_gemm_nt_bf16(const wft_gemm_args* args, void* stream);
 /* Which kernel wft_gemm_nt_bf16 dispatches these arguments to: 256 (gemm_nt256_kernel, 256x256
@@ -242,6 +249,52 @@ int wft_adamw_step(float* p, const float* g, float* m, float* v, wft_bf16* p_bf1
                    const float* gscale, void* stream);
 /* out[0] += sum(g^2) over n elements (for the global grad norm).             */
 int wft_sumsq_f32(const float* g, int64_t n, float* out, void* stream);
+
+/* ------------------------------------------------ multi-tensor optimizer step */
+/* One launch for a whole parameter list (model/optimizer.py:240-262, optimizer.step() at
+ * model_utils.py:122, torch.nn.utils.clip_grad_norm_ at model_utils.py:107).
+ * The tensor list is a caller-owned table in DEVICE memory:
+ *   tab[row * n + t]  int64  address of tensor t's row-th array (row meaning per function)
+ *   numel[t]          int64  elements of tensor t
+ *   chunk_start[t]    int32  index of tensor t's first WFT_MT_CHUNK-element chunk; chunk_start[n] =
+ *                            total_chunks = sum_t ceil(numel[t] / WFT_MT_CHUNK)                        */
+#define WFT_MT_CHUNK 65536
+/* out[0] = sum over all tensors of g^2 (tab row 0 = g, f32).  partial: f32 [total_chunks] scratch.
+ * Two fixed-order stages: bitwise reproducible.                                                */
+int wft_mt_sumsq_f32(const void* tab, const int64_t* numel, const int32_t* chunk_start, int n,
+                     int total_chunks, float* partial, float* out, void* stream);
+/* torch.optim.AdamW step for every tensor (tab rows: 0 p, 1 g, 2 exp_avg, 3 exp_avg_sq; all f32).
+ * If sumsq != NULL, g is first scaled by min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)): clip_grad_norm_
+ * folded into the same pass (28 B/parameter of HBM traffic in total).                           */
+int wft_mt_adamw(const void* tab, const int64_t* numel, const int32_t* chunk_start, int n,
+                 int total_chunks, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, float bias_corr1, float bias_corr2, const float* sumsq,
+                 float max_norm, void* stream);
+
+/* --------------------------------------------------------------------- Muon */
+/* The reference builds `muon.MuonWithAuxAdam` (third-party package `muon`, git HEAD, not vendored:
+ * pyproject.toml:29, model/optimizer.py:171-237).  Its update for a 2-D parameter is
+ *   buf = lerp(buf, g, 1-beta);  u = lerp(g, buf, beta) (nesterov);
+ *   X = bf16(u) (transposed if rows > cols);  X /= ||X||_F + 1e-7;
+ *   5 x { A = X X^T;  B = b A + c A A;  X = a X + B X }   (a, b, c) = (3.4445, -4.7750, 2.0315);
+ *   p = p (1 - lr wd) - lr sqrt(max(1, rows/cols)) X.
+ * The three products per iteration are wft_gemm_nt_bf16 launches (beta = residual scale) batched over all
+ * parameters of one shape; the functions below are the element-wise / layout steps around them.
+ * Tables as above with n = n_mats same-shape [rows, cols] matrices (tab rows: 0 p, 1 g, 2 momentum).   */
+/* Step 1: momentum + nesterov; g is overwritten with u (as grad.lerp_ does); U [n][rows][cols] = bf16(u);
+ * partial [n][ceil(rows*cols / WFT_MT_CHUNK)] = per-chunk sum of bf16(u)^2.  sumsq/max_norm as above.   */
+int wft_muon_momentum_mt(const void* tab, int n_mats, int64_t numel, float beta, int nesterov,
+                         wft_bf16* U, float* partial, const float* sumsq, float max_norm, void* stream);
+/* Step 2: normalise (norm rounded to bf16 like torch's bf16 .norm()) and lay out for the GEMMs:
+ * X [n][rows_pad][cols_pad] with rows <= cols (U^T when the parameter is tall), Xt its transpose
+ * [n][cols_pad][rows_pad]; pads are written as zeros.                                            */
+int wft_muon_prepare(const wft_bf16* U, int rows, int cols, const float* partial, int chunks,
+                     wft_bf16* X, wft_bf16* Xt, int rows_pad, int cols_pad, int n_mats, void* stream);
+/* dst[b][c][r] = src[b][r][c] (keeps X and X^T in step between Newton-Schulz iterations).          */
+int wft_transpose_bf16(const wft_bf16* src, int rows, int cols, wft_bf16* dst, int batch, void* stream);
+/* Step 4: p = p (1 - lr wd) - lr * scale * O[t][r][c]; O bf16, row stride ldo, matrix stride stride_o. */
+int wft_muon_apply_mt(const void* tab, int n_mats, int rows, int cols, const wft_bf16* O, int64_t ldo,
+                      int64_t stride_o, float lr, float weight_decay, float scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -441,3 +441,74 @@ def synthetic_batch(dims: ModelDimensions, B: int, S: int, seed: int = 1234, n_s
     y_in = torch.cat([specials.expand(B, -1), body], dim=1)
     y_out = torch.cat([y_in[:, 1:], torch.full((B, 1), 50257)], dim=1)
     return audio, y_in, y_out
+
+
+# ----------------------------------------------------------------------------------------------
+# §8f-1 — optimizer step.  The reference builds `muon.MuonWithAuxAdam` / `SingleDeviceMuonWithAuxAdam`
+# (model/optimizer.py:171-237) from the third-party package `muon` (github.com/KellerJordan/Muon, git HEAD, pinned by
+# nothing: pyproject.toml:29) — NOT present in /root/reference and not installed, so its published algorithm is
+# restated here (PARITY UNPINNED for this part: no golden vectors exist in the reference's tests beyond the
+# param-group keys, tests/test_optimizer.py:22-60).  torch.optim.AdamW is the oracle for the AdamW path.
+NS_COEFFS = (3.4445, -4.7750, 2.0315)
+
+
+def zeropower_via_newtonschulz5(G: Tensor, steps: int = 5) -> Tensor:
+    """Quintic Newton-Schulz iteration towards the orthogonal polar factor of G, in bf16 (muon.py)."""
+    assert G.ndim >= 2
+    a, b, c = NS_COEFFS
+    X = G.bfloat16()
+    if G.size(-2) > G.size(-1):
+        X = X.mT
+    X = X / (X.norm(dim=(-2, -1), keepdim=True) + 1e-7)
+    for _ in range(steps):
+        A = X @ X.mT
+        B = b * A + c * A @ A
+        X = a * X + B @ X
+    if G.size(-2) > G.size(-1):
+        X = X.mT
+    return X
+
+
+def muon_update(grad: Tensor, momentum: Tensor, beta: float = 0.95, ns_steps: int = 5, nesterov: bool = True) -> Tensor:
+    """In place on grad and momentum, as the package does (muon.py muon_update)."""
+    momentum.lerp_(grad, 1 - beta)
+    update = grad.lerp_(momentum, beta) if nesterov else momentum
+    if update.ndim == 4:
+        update = update.view(len(update), -1)
+    update = zeropower_via_newtonschulz5(update, steps=ns_steps)
+    update *= max(1, grad.size(-2) / grad.size(-1)) ** 0.5
+    return update
+
+
+def adam_update(grad: Tensor, buf1: Tensor, buf2: Tensor, step: int, betas, eps: float) -> Tensor:
+    buf1.lerp_(grad, 1 - betas[0])
+    buf2.lerp_(grad.square(), 1 - betas[1])
+    buf1c = buf1 / (1 - betas[0] ** step)
+    buf2c = buf2 / (1 - betas[1] ** step)
+    return buf1c / (buf2c.sqrt() + eps)
+
+
+def muon_with_aux_adam_step(param_groups, state: dict) -> None:
+    """One SingleDeviceMuonWithAuxAdam.step() over plain tensors: param_groups are the reference's dicts (use_muon, lr,
+    momentum | betas/eps, weight_decay) whose "params" are (p, grad) pairs; `state` maps id(p) -> dict."""
+    with torch.no_grad():
+        for group in param_groups:
+            for p, g in group["params"]:
+                st = state.setdefault(id(p), {})
+                if group["use_muon"]:
+                    if g is None:
+                        g = torch.zeros_like(p)
+                    if not st:
+                        st["momentum_buffer"] = torch.zeros_like(p)
+                    update = muon_update(g, st["momentum_buffer"], beta=group["momentum"])
+                    p.mul_(1 - group["lr"] * group["weight_decay"])
+                    p.add_(update.reshape(p.shape).to(p.dtype), alpha=-group["lr"])
+                else:
+                    if g is None:
+                        g = torch.zeros_like(p)
+                    if not st:
+                        st["exp_avg"], st["exp_avg_sq"], st["step"] = torch.zeros_like(p), torch.zeros_like(p), 0
+                    st["step"] += 1
+                    update = adam_update(g, st["exp_avg"], st["exp_avg_sq"], st["step"], group["betas"], group["eps"])
+                    p.mul_(1 - group["lr"] * group["weight_decay"])
+                    p.add_(update, alpha=-group["lr"])

@@ -295,7 +295,71 @@ def gen_ref_eval():
     print("ref_eval.json written")
 
 
+def fake_muon_model():
+    """A whisper-shaped toy (encoder/decoder block stacks with 2-D Linear weights of two widths, biases, norms; a conv
+    stem, embeddings and a final norm outside the blocks) for the optimizer-factory parity case."""
+    torch.manual_seed(0)
+
+    class Block(torch.nn.Module):
+        def __init__(self, d):
+            super().__init__()
+            self.attn_ln = torch.nn.LayerNorm(d)
+            self.query = torch.nn.Linear(d, d)
+            self.key = torch.nn.Linear(d, d, bias=False)
+            self.mlp = torch.nn.Sequential(torch.nn.Linear(d, 4 * d), torch.nn.GELU(), torch.nn.Linear(4 * d, d))
+
+    class Stack(torch.nn.Module):
+        def __init__(self, d, n, conv):
+            super().__init__()
+            if conv:
+                self.conv1 = torch.nn.Conv1d(8, d, 3, padding=1)
+            else:
+                self.token_embedding = torch.nn.Embedding(32, d)
+            self.blocks = torch.nn.ModuleList([Block(d) for _ in range(n)])
+            self.ln_post = torch.nn.LayerNorm(d)
+
+    class Fake(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.encoder = Stack(16, 2, True)
+            self.decoder = Stack(16, 1, False)
+
+    m = Fake()
+    m.encoder.blocks[0].key.weight.requires_grad = False  # frozen parameters are left out of every group
+    return m
+
+
+MUON_CONF = {"type": "adamw", "muon": True, "8bit": False, "muon_ndim_threshold": 2,
+             "muon_params": {"lr": 2e-4, "momentum": 0.95, "weight_decay": 0.01},
+             "params": {"lr": 2e-5, "weight_decay": 0.01, "betas": [0.9, 0.98], "eps": 1e-6, "amsgrad": False}}
+
+
+def gen_ref_optim():
+    """Param-group construction of the reference's get_optimizer Muon branch (model/optimizer.py:9-128), from the reference's
+    own helper functions (the `muon` package itself is not installed, so the optimizer object is not built)."""
+    import json
+    tmp = Path(tempfile.mkdtemp())
+    _install_stubs(tmp)
+    sys.path.insert(0, str(tmp))
+    sys.path.insert(0, str(REF / "src"))
+    from whisper_finetune.model import optimizer as ro
+
+    m = fake_muon_model()
+    names = {id(p): n for n, p in m.named_parameters()}
+    muon, aux = ro._partition_muon_params(m, ndim_threshold=2)
+    out = {"muon_names": [names[id(p)] for p in muon], "aux_names": [names[id(p)] for p in aux], "groups": {}}
+    for match in (True, False):
+        groups = ro._build_muon_param_groups(muon, base_lr=2e-4, base_weight_decay=0.01, momentum=0.95,
+                                             match_adamw_update_rms=match, match_factor=0.2)
+        out["groups"][str(match)] = [{"names": [names[id(p)] for p in g["params"]], "lr": g["lr"], "momentum": g["momentum"],
+                                      "weight_decay": g["weight_decay"], "use_muon": g["use_muon"]} for g in groups]
+    out["use_muon"] = [[c, ro._use_muon_optimizer(c)] for c in ({"muon": True}, {"muon": False, "type": "muon"}, {"type": "muon"}, {"type": "adamw"})]
+    (HERE / "ref_optim.json").write_text(json.dumps(out, indent=0))
+    print("ref_optim.json written", len(muon), len(aux))
+
+
 if __name__ == "__main__":
+    gen_ref_optim()
     gen_ref_eval()
     gen_arch()
     gen_logmel()

@@ -21,7 +21,7 @@ struct GemmP {
   const float* bias;
   const unsigned short* res; long ldr; long sR;
   unsigned short* aux; long ldaux; long sAux;
-  float alpha;
+  float alpha, beta;
   int M, N, K, batch;
   int accumulate;
   int period, valid;
@@ -138,10 +138,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
       }
       if (p.res && p.res_first) {
         const u32x2 r2 = *(const u32x2*)(p.res + (long)bz * p.sR + (long)m * p.ldr + n);
-        v[0] += bf2f((unsigned short)(r2[0] & 0xffff));
-        v[1] += bf2f((unsigned short)(r2[0] >> 16));
-        v[2] += bf2f((unsigned short)(r2[1] & 0xffff));
-        v[3] += bf2f((unsigned short)(r2[1] >> 16));
+        v[0] += p.beta * bf2f((unsigned short)(r2[0] & 0xffff));
+        v[1] += p.beta * bf2f((unsigned short)(r2[0] >> 16));
+        v[2] += p.beta * bf2f((unsigned short)(r2[1] & 0xffff));
+        v[3] += p.beta * bf2f((unsigned short)(r2[1] >> 16));
       }
       if (EPI == WFT_EPI_GELU) {
         if (p.aux) {
@@ -159,10 +159,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
       }
       if (p.res && !p.res_first) {
         const u32x2 r2 = *(const u32x2*)(p.res + (long)bz * p.sR + (long)m * p.ldr + n);
-        v[0] += bf2f((unsigned short)(r2[0] & 0xffff));
-        v[1] += bf2f((unsigned short)(r2[0] >> 16));
-        v[2] += bf2f((unsigned short)(r2[1] & 0xffff));
-        v[3] += bf2f((unsigned short)(r2[1] >> 16));
+        v[0] += p.beta * bf2f((unsigned short)(r2[0] & 0xffff));
+        v[1] += p.beta * bf2f((unsigned short)(r2[0] >> 16));
+        v[2] += p.beta * bf2f((unsigned short)(r2[1] & 0xffff));
+        v[3] += p.beta * bf2f((unsigned short)(r2[1] >> 16));
       }
       if (zero_row) { v[0] = v[1] = v[2] = v[3] = 0.f; }
       if (C_F32) {
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
             if (p.res && p.res_first) {
               const u32x4 r4 = *(const u32x4*)(p.res + (long)bz * p.sR + roff * p.ldr + ncol);
 #pragma unroll
-              for (int e = 0; e < 4; ++e) { v[2 * e] += bf2f((unsigned short)(r4[e] & 0xffff)); v[2 * e + 1] += bf2f((unsigned short)(r4[e] >> 16)); }
+              for (int e = 0; e < 4; ++e) { v[2 * e] += p.beta * bf2f((unsigned short)(r4[e] & 0xffff)); v[2 * e + 1] += p.beta * bf2f((unsigned short)(r4[e] >> 16)); }
             }
             if (EPI == WFT_EPI_GELU) {
               if (p.aux) {
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
             if (p.res && !p.res_first) {
               const u32x4 r4 = *(const u32x4*)(p.res + (long)bz * p.sR + roff * p.ldr + ncol);
 #pragma unroll
-              for (int e = 0; e < 4; ++e) { v[2 * e] += bf2f((unsigned short)(r4[e] & 0xffff)); v[2 * e + 1] += bf2f((unsigned short)(r4[e] >> 16)); }
+              for (int e = 0; e < 4; ++e) { v[2 * e] += p.beta * bf2f((unsigned short)(r4[e] & 0xffff)); v[2 * e + 1] += p.beta * bf2f((unsigned short)(r4[e] >> 16)); }
             }
             if (p.period > 0 && (m % p.period) >= p.valid) {
 #pragma unroll
@@ -401,8 +401,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
         }
         if (p.res && p.res_first) {
           const u32x2 r2 = *(const u32x2*)(p.res + (long)bz * p.sR + (long)m * p.ldr + n);
-          v[0] += bf2f((unsigned short)(r2[0] & 0xffff)); v[1] += bf2f((unsigned short)(r2[0] >> 16));
-          v[2] += bf2f((unsigned short)(r2[1] & 0xffff)); v[3] += bf2f((unsigned short)(r2[1] >> 16));
+          v[0] += p.beta * bf2f((unsigned short)(r2[0] & 0xffff)); v[1] += p.beta * bf2f((unsigned short)(r2[0] >> 16));
+          v[2] += p.beta * bf2f((unsigned short)(r2[1] & 0xffff)); v[3] += p.beta * bf2f((unsigned short)(r2[1] >> 16));
         }
         if (EPI == WFT_EPI_GELU) {
           if (p.aux) {
@@ -418,8 +418,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
         }
         if (p.res && !p.res_first) {
           const u32x2 r2 = *(const u32x2*)(p.res + (long)bz * p.sR + (long)m * p.ldr + n);
-          v[0] += bf2f((unsigned short)(r2[0] & 0xffff)); v[1] += bf2f((unsigned short)(r2[0] >> 16));
-          v[2] += bf2f((unsigned short)(r2[1] & 0xffff)); v[3] += bf2f((unsigned short)(r2[1] >> 16));
+          v[0] += p.beta * bf2f((unsigned short)(r2[0] & 0xffff)); v[1] += p.beta * bf2f((unsigned short)(r2[0] >> 16));
+          v[2] += p.beta * bf2f((unsigned short)(r2[1] & 0xffff)); v[3] += p.beta * bf2f((unsigned short)(r2[1] >> 16));
         }
         if (zero_row) { v[0] = v[1] = v[2] = v[3] = 0.f; }
         if (C_F32) {
@@ -824,6 +824,7 @@ static int fill_params(const wft_gemm_args* a, GemmP& p) {
   p.res = a->residual; p.ldr = a->ldr; p.sR = a->strideR;
   p.aux = a->aux; p.ldaux = a->ldaux; p.sAux = a->strideAux;
   p.alpha = a->alpha;
+  p.beta = a->beta == 0.f ? 1.f : a->beta;
   p.M = (int)a->M; p.N = (int)a->N; p.K = (int)a->K; p.batch = a->batch;
   p.accumulate = a->accumulate;
   p.period = a->valid_rows_period; p.valid = a->valid_rows;

@@ -117,6 +117,39 @@ extern "C" int wft_add_bf16(const wft_bf16* a, const wft_bf16* b, wft_bf16* y, i
 }
 
 
+// ----------------------------------------------------------------------------- stochastic-depth rescale
+// out = a*x + b*y (y may be NULL: out = a*x).  Forward of StochasticDepthMixin's train-time rescale
+// x + (block(x) - x) / (1 - p) = (1 - s) x + s block(x), s = 1/(1-p)  (model/model_utils.py:241-250) in ONE pass instead
+// of three element-wise kernels; its backward is two scaled copies.
+__global__ __launch_bounds__(256) void axpby_bf16_kernel(float a, const unsigned short* x, float b, const unsigned short* y,
+                                                          unsigned short* out, long n) {
+  const long nv = n >> 3;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+    const u32x4 xv = *(const u32x4*)(x + i * 8);
+    u32x4 yv = {0u, 0u, 0u, 0u};
+    if (y) yv = *(const u32x4*)(y + i * 8);
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      o[e] = pack2bf(a * bf2f((unsigned short)(xv[e] & 0xffff)) + b * bf2f((unsigned short)(yv[e] & 0xffff)),
+                     a * bf2f((unsigned short)(xv[e] >> 16)) + b * bf2f((unsigned short)(yv[e] >> 16)));
+    *(u32x4*)(out + i * 8) = o;
+  }
+  if (blockIdx.x == 0) {
+    const long t = (nv << 3) + threadIdx.x;
+    if (t < n) out[t] = f2bf(a * bf2f(x[t]) + (y ? b * bf2f(y[t]) : 0.f));
+  }
+}
+extern "C" int wft_axpby_bf16(float a, const wft_bf16* x, float b, const wft_bf16* y, wft_bf16* out, int64_t n, void* stream) {
+  WFT_CHECK_ARG(x && out && n >= 0, "bad args");
+  WFT_CHECK_ARG((((uintptr_t)x) & 15) == 0 && (((uintptr_t)y) & 15) == 0 && (((uintptr_t)out) & 15) == 0, "16-byte alignment");
+  if (n == 0) return WFT_OK;
+  hipLaunchKernelGGL(axpby_bf16_kernel, dim3(ew_grid(n / 8 + 1)), dim3(256), 0, (hipStream_t)stream, a, x, b, y, out, (long)n);
+  WFT_CHECK_LAUNCH();
+  return WFT_OK;
+}
+
+
 // ----------------------------------------------------------------------------- dGELU
 // out = dy * gelu'(pre)   (conv stem backward; the Linear path fuses this in the GEMM epilogue)
 __global__ __launch_bounds__(256) void dgelu_mul_kernel(const unsigned short* dy, const unsigned short* pre,

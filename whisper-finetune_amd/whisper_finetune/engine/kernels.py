@@ -78,6 +78,18 @@ def add_bf16(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def axpby_bf16(a: float, x: torch.Tensor, b: float = 0.0, y: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """a*x + b*y (bf16, same shape; y optional)."""
+    _chk(x, BF16, "x")
+    x = x.contiguous()
+    if y is not None:
+        _chk(y, BF16, "y")
+        y = y.contiguous()
+    out = torch.empty_like(x)
+    L.check(L.load().wft_axpby_bf16(float(a), _p(x), float(b), _p(y), _p(out), x.numel(), L.stream_ptr()), "wft_axpby_bf16")
+    return out
+
+
 def dgelu_mul(dy: torch.Tensor, pre: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _chk(dy, BF16, "dy"); _chk(pre, BF16, "pre")
     assert dy.is_contiguous() and pre.is_contiguous()
@@ -144,7 +156,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, mask=None):
 def gemm_nt(a, b, *, M=None, N=None, K=None, lda=None, ldb=None, out=None, out_f32=False, accumulate=False,
             bias=None, residual=None, aux=None, epilogue=L.EPI_NONE, alpha=1.0, batch=1,
             strideA=0, strideB=0, strideC=0, strideR=0, strideAux=0, ldc=None,
-            valid_rows_period=0, valid_rows=0, residual_first=False, ldaux=None, ldr=None):
+            valid_rows_period=0, valid_rows=0, residual_first=False, ldaux=None, ldr=None, beta=1.0):
     """C[M,N] = alpha * A[M,K] @ B[N,K]^T (+bias) (epilogue) (+residual).
 
     a: bf16, row m at a.data_ptr() + m*lda; b: bf16 [N, K] (ldb).  Defaults take the shapes
@@ -180,7 +192,7 @@ def gemm_nt(a, b, *, M=None, N=None, K=None, lda=None, ldb=None, out=None, out_f
     if aux is not None:
         _chk(aux, BF16, "aux")
         args.aux, args.ldaux, args.strideAux = aux.data_ptr(), (aux.stride(-2) if ldaux is None else ldaux), strideAux
-    args.epilogue, args.alpha = epilogue, alpha
+    args.epilogue, args.alpha, args.beta = epilogue, alpha, beta
     args.M, args.N, args.K, args.batch = M, N, K, batch
     args.valid_rows_period, args.valid_rows = valid_rows_period, valid_rows
     args.residual_first = int(residual_first)
@@ -404,3 +416,117 @@ def adamw_step(p, g, m, v, p_bf16, lr, beta1, beta2, eps, wd, bc1, bc2, gscale=N
 
 def sumsq(g, out):
     L.check(L.load().wft_sumsq_f32(_p(g), g.numel(), _p(out), L.stream_ptr()), "wft_sumsq_f32")
+
+
+# --------------------------------------------------------------------------- multi-tensor optimizer steps
+MT_CHUNK = 65536  # include/wft.h WFT_MT_CHUNK
+
+
+class TensorTable:
+    """Device-side pointer table for the wft_mt_* / wft_muon_*_mt entry points: `rows` lists of equally long tensor
+    lists (row r of tensor t at tab[r * n + t]).  numel / chunk_start depend only on the shapes and are cached by
+    the caller; the pointer rows are rebuilt every step because gradient tensors are re-allocated."""
+
+    def __init__(self, tensors):
+        self.n = len(tensors)
+        self.device = tensors[0].device
+        numel = [t.numel() for t in tensors]
+        starts, tot = [], 0
+        for ne in numel:
+            starts.append(tot)
+            tot += (ne + MT_CHUNK - 1) // MT_CHUNK
+        starts.append(tot)
+        self.total_chunks = tot
+        self.numel = torch.tensor(numel, dtype=torch.int64, device=self.device)
+        self.chunk_start = torch.tensor(starts, dtype=torch.int32, device=self.device)
+
+    def pointers(self, *rows):
+        flat = []
+        for r in rows:
+            assert len(r) == self.n
+            for t in r:
+                if t.dtype != F32 or not t.is_contiguous() or not t.is_cuda:
+                    raise L.WftError("multi-tensor optimizer kernels need contiguous f32 HIP tensors")
+                flat.append(t.data_ptr())
+        return torch.tensor(flat, dtype=torch.int64, device=self.device)
+
+
+def mt_sumsq(table: TensorTable, grads, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """sum over all tensors of g^2 -> f32 [1] on the device (fixed-order reduction)."""
+    tab = table.pointers(grads)
+    partial = torch.empty(table.total_chunks, dtype=F32, device=table.device)
+    out = torch.empty(1, dtype=F32, device=table.device) if out is None else out
+    L.check(L.load().wft_mt_sumsq_f32(_p(tab), _p(table.numel), _p(table.chunk_start), table.n, table.total_chunks,
+                                      _p(partial), _p(out), L.stream_ptr()), "wft_mt_sumsq_f32")
+    return out
+
+
+def mt_adamw(table: TensorTable, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, wd, bc1, bc2, sumsq=None,
+             max_norm=0.0):
+    tab = table.pointers(params, grads, exp_avg, exp_avg_sq)
+    L.check(L.load().wft_mt_adamw(_p(tab), _p(table.numel), _p(table.chunk_start), table.n, table.total_chunks, lr, beta1,
+                                  beta2, eps, wd, bc1, bc2, _p(sumsq), float(max_norm), L.stream_ptr()), "wft_mt_adamw")
+
+
+def transpose_bf16(src: torch.Tensor, dst: torch.Tensor):
+    """src bf16 [batch, rows, cols] contiguous -> dst [batch, cols, rows]."""
+    _chk(src, BF16, "src"); _chk(dst, BF16, "dst")
+    b, r, c = src.shape
+    assert src.is_contiguous() and dst.is_contiguous() and dst.shape == (b, c, r)
+    L.check(L.load().wft_transpose_bf16(_p(src), r, c, _p(dst), b, L.stream_ptr()), "wft_transpose_bf16")
+    return dst
+
+
+NS_COEFFS = (3.4445, -4.7750, 2.0315)  # muon.py zeropower_via_newtonschulz5
+
+
+def muon_group_step(params, grads, bufs, lr, wd, momentum, nesterov=True, ns_steps=5, sumsq=None, max_norm=0.0,
+                    return_update=False):
+    """One Muon step for a list of same-shape 2-D f32 parameters (muon.py muon_update + the p update of
+    SingleDeviceMuonWithAuxAdam.step): momentum/nesterov -> bf16 -> Frobenius normalisation -> 5 Newton-Schulz
+    iterations as batched MFMA GEMMs -> p = p(1 - lr wd) - lr sqrt(max(1, rows/cols)) X."""
+    lib = L.load()
+    n = len(params)
+    rows, cols = params[0].shape
+    dev = params[0].device
+    tall = rows > cols
+    R, Cc = (cols, rows) if tall else (rows, cols)
+    Rp, Cp = round_up(R, 128), round_up(Cc, 128)
+    numel = rows * cols
+    chunks = (numel + MT_CHUNK - 1) // MT_CHUNK
+    flat = []
+    for row in (params, grads, bufs):
+        for t in row:
+            if t.dtype != F32 or not t.is_contiguous() or t.shape != (rows, cols):
+                raise L.WftError("muon_group_step needs contiguous f32 tensors of one shape")
+            flat.append(t.data_ptr())
+    tab = torch.tensor(flat, dtype=torch.int64, device=dev)
+    U = torch.empty((n, rows, cols), dtype=BF16, device=dev)
+    partial = torch.empty((n, chunks), dtype=F32, device=dev)
+    L.check(lib.wft_muon_momentum_mt(_p(tab), n, numel, momentum, int(nesterov), _p(U), _p(partial), _p(sumsq),
+                                     float(max_norm), L.stream_ptr()), "wft_muon_momentum_mt")
+    X = torch.empty((n, Rp, Cp), dtype=BF16, device=dev)
+    Xt = torch.empty((n, Cp, Rp), dtype=BF16, device=dev)
+    L.check(lib.wft_muon_prepare(_p(U), rows, cols, _p(partial), chunks, _p(X), _p(Xt), Rp, Cp, n, L.stream_ptr()),
+            "wft_muon_prepare")
+    del U
+    A = torch.empty((n, Rp, Rp), dtype=BF16, device=dev)
+    Bm = torch.empty((n, Rp, Rp), dtype=BF16, device=dev)
+    Xt2 = torch.empty((n, Cp, Rp), dtype=BF16, device=dev)
+    a, b, c = NS_COEFFS
+    for it in range(ns_steps):
+        gemm_nt(X, X, M=Rp, N=Rp, K=Cp, lda=Cp, ldb=Cp, out=A, ldc=Rp, batch=n, strideA=Rp * Cp, strideB=Rp * Cp,
+                strideC=Rp * Rp)                                                        # A = X X^T
+        gemm_nt(A, A, M=Rp, N=Rp, K=Rp, lda=Rp, ldb=Rp, out=Bm, ldc=Rp, batch=n, strideA=Rp * Rp, strideB=Rp * Rp,
+                strideC=Rp * Rp, alpha=c, residual=A, ldr=Rp, strideR=Rp * Rp, beta=b)  # B = b A + c A A   (A = A^T)
+        gemm_nt(Xt, Bm, M=Cp, N=Rp, K=Rp, lda=Rp, ldb=Rp, out=Xt2, ldc=Rp, batch=n, strideA=Cp * Rp, strideB=Rp * Rp,
+                strideC=Cp * Rp, residual=Xt, ldr=Rp, strideR=Cp * Rp, beta=a)          # X'^T = a X^T + X^T B (B = B^T)
+        Xt, Xt2 = Xt2, Xt
+        if it + 1 < ns_steps or not tall:
+            transpose_bf16(Xt, X)
+    O, ldo, so = (Xt, Rp, Cp * Rp) if tall else (X, Cp, Rp * Cp)
+    scale = max(1.0, rows / cols) ** 0.5
+    L.check(lib.wft_muon_apply_mt(_p(tab), n, rows, cols, _p(O), ldo, so, lr, wd, scale, L.stream_ptr()), "wft_muon_apply_mt")
+    if return_update:
+        return O[:, :rows, :cols].float() * scale
+    return None

@@ -33,6 +33,7 @@ class GemmArgs(C.Structure):
         ("valid_rows_period", C.c_int), ("valid_rows", C.c_int),
         ("residual_first", C.c_int),
         ("workspace", c_vp), ("workspace_bytes", c_i64),
+        ("beta", C.c_float), ("reserved0", C.c_int),
     ]
 
 
@@ -63,6 +64,7 @@ SIGNATURES = {
     "wft_cast_bf16_f32": [c_vp, c_vp, c_i64, c_vp],
     "wft_cast_pad_transpose_f32_bf16": [c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp],
     "wft_add_bf16": [c_vp, c_vp, c_vp, c_i64, c_vp],
+    "wft_axpby_bf16": [C.c_float, c_vp, C.c_float, c_vp, c_vp, c_i64, c_vp],
     "wft_dgelu_mul_bf16": [c_vp, c_vp, c_vp, c_i64, c_vp],
     "wft_colsum_bf16": [c_vp, c_i64, c_i64, c_i64, c_vp, C.c_int, c_vp],
     "wft_layernorm_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_float,
@@ -87,6 +89,12 @@ SIGNATURES = {
     "wft_adamw_step": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_float, C.c_float, C.c_float, C.c_float,
                        C.c_float, C.c_float, C.c_float, c_vp, c_vp],
     "wft_sumsq_f32": [c_vp, c_i64, c_vp, c_vp],
+    "wft_mt_sumsq_f32": [c_vp, c_vp, c_vp, C.c_int, C.c_int, c_vp, c_vp, c_vp],
+    "wft_mt_adamw": [c_vp, c_vp, c_vp, C.c_int, C.c_int] + [C.c_float] * 7 + [c_vp, C.c_float, c_vp],
+    "wft_muon_momentum_mt": [c_vp, C.c_int, c_i64, C.c_float, C.c_int, c_vp, c_vp, c_vp, C.c_float, c_vp],
+    "wft_muon_prepare": [c_vp, C.c_int, C.c_int, c_vp, C.c_int, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp],
+    "wft_transpose_bf16": [c_vp, C.c_int, C.c_int, c_vp, C.c_int, c_vp],
+    "wft_muon_apply_mt": [c_vp, C.c_int, C.c_int, C.c_int, c_vp, c_i64, c_i64, C.c_float, C.c_float, C.c_float, c_vp],
     "wft_last_error": [],
     "wft_version": [],
 }

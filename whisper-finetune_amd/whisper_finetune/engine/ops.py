@@ -293,6 +293,22 @@ def linear(x, group: LinearGroup, weights, biases, loras=None, residual=None, ge
     return LinearFn.apply(x, residual, gelu_pre, cfg, *params)
 
 
+# --------------------------------------------------------------------------- stochastic depth
+class SdRescaleFn(torch.autograd.Function):
+    """x + (out - x) / keep in one kernel (StochasticDepthMixin.stochastic_depth, model/model_utils.py:241-250)."""
+
+    @staticmethod
+    def forward(ctx, x, out, keep: float):
+        s = 1.0 / keep
+        ctx.s = s
+        return K.axpby_bf16(1.0 - s, x, s, out)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.to(BF16)
+        return K.axpby_bf16(1.0 - ctx.s, g), K.axpby_bf16(ctx.s, g), None
+
+
 # --------------------------------------------------------------------------- LayerNorm
 class LayerNormFn(torch.autograd.Function):
     """whisper.model.LayerNorm (fp32 statistics, bf16 in/out) + optional deep-SpecAugment mask

@@ -100,7 +100,11 @@ def train_step(
 
         log_lora_debug_info(rt.unwrap_model(model), step=step, tracker=lora_tracker, log_to_wandb=rt.IS_MAIN)
 
-    torch.nn.utils.clip_grad_norm_(model.parameters(), max_grad_norm)
+    if scaler is None and hasattr(optimizer, "fuse_clip_grad_norm"):
+        # libwft optimizers compute the global norm and apply the clip coefficient inside their update kernels
+        optimizer.fuse_clip_grad_norm(max_grad_norm)
+    else:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_grad_norm)
 
     if is_lora_run and lora_tracker is not None:
         lora_tracker.snapshot()
@@ -175,17 +179,27 @@ def infinite_iter(data_loader) -> Iterator:
 
 
 class StochasticDepthMixin:
-    """Stochastic depth with per-block gradient checkpointing (https://arxiv.org/abs/1603.09382)."""
+    """Stochastic depth (https://arxiv.org/abs/1603.09382) — model/model_utils.py:220-250.
+
+    The reference wraps every kept block in `checkpoint` (recompute in backward) to fit 24-80 GB cards.  An MI355X holds
+    288 GB, so by default the activations simply stay resident (`recompute = False`: identical numbers, one forward pass
+    less per step); set `.recompute = True` (finetune.py: training.wft_recompute) to get the reference's memory profile."""
+
+    recompute = False
 
     def stochastic_depth(self, x: Tensor, layer: Callable[[Tensor], Tensor], p: float) -> Tensor:
         # the skip decision is a HOST draw from the default CPU generator (RNG parity with the reference)
         if self.training and p > 0.0 and torch.rand(1).item() < p:
             return x
-        out = checkpoint(layer, x, use_reentrant=False)
+        out = checkpoint(layer, x, use_reentrant=False) if self.recompute else layer(x)
         if self.training and p > 0.0:
             keep = 1.0 - p
             if keep <= 0.0:
                 return x
+            if x.is_cuda and x.dtype == torch.bfloat16 and out.dtype == torch.bfloat16:
+                from whisper_finetune.engine.ops import SdRescaleFn
+
+                return SdRescaleFn.apply(x, out, keep)  # one fused pass
             return x + (out - x) / keep  # block(x) already contains the skip connection
         return out
 

@@ -1,9 +1,11 @@
 """`get_optimizer(model, optimizer_conf, is_lora_run)` (model/optimizer.py:131-264) for the MI355X build.
 
 adam / adamw map to torch.optim (fused multi-tensor kernels on the GPU) or, with `optimizer.wft: true`, to
-`WftAdamW`, which steps every parameter with the `wft_adamw_step` kernel and folds the clip_grad_norm_
-coefficient into the same pass.  bitsandbytes 8-bit optimizers and Muon are SURVEY.md §8f-1 ("next") and
-raise a clear error here rather than silently substituting another optimizer."""
+`WftAdamW`: one `wft_mt_adamw` launch for the whole parameter list with the clip_grad_norm_ coefficient folded
+into the same pass.  `optimizer.muon: true` builds the reference's Muon + auxiliary-Adam parameter groups
+(same partition, RMS-matched learning rates and `_lr_group_metadata`) on `WftMuonWithAuxAdam`, whose
+Newton-Schulz iterations are batched bf16 MFMA GEMMs.  bitsandbytes 8-bit optimizers raise ImportError as the
+reference does when the package is missing."""
 from __future__ import annotations
 
 from typing import Dict
@@ -17,49 +19,242 @@ def print_trainable_parameters(model) -> None:
     print(f"trainable params: {train:,} || all params: {total:,} || trainable%: {100 * train / max(total, 1):.4f}")
 
 
-class WftAdamW(torch.optim.Optimizer):
-    """AdamW (decoupled weight decay, bias correction) whose update runs in libwft.  `grad_scale` (a device
-    scalar, e.g. the clipping coefficient) is applied to the gradient inside the kernel."""
+def _global_sumsq(params_with_grad):
+    """device f32 [1] = sum of squares of every gradient (one fixed-order multi-tensor reduction)."""
+    from whisper_finetune.engine import kernels as K
+
+    table = K.TensorTable(params_with_grad)
+    return K.mt_sumsq(table, [p.grad for p in params_with_grad])
+
+
+class _FusedClipMixin:
+    """`fuse_clip_grad_norm(max_norm)`: train_step calls this INSTEAD of torch.nn.utils.clip_grad_norm_
+    (model/model_utils.py:107); the next step() then computes the global gradient norm in one multi-tensor pass
+    and applies min(1, max_norm / (norm + 1e-6)) inside the update kernels — the gradients are never rewritten."""
+
+    _pending_max_norm = None
+    last_grad_norm = None  # device f32 [1] after a fused-clip step (what clip_grad_norm_ would have returned)
+
+    def fuse_clip_grad_norm(self, max_norm: float) -> None:
+        if max_norm is None or max_norm <= 0:
+            raise ValueError(f"max_norm must be > 0, got {max_norm}")
+        self._pending_max_norm = float(max_norm)
+
+    def _take_clip(self, params_with_grad):
+        max_norm, self._pending_max_norm = self._pending_max_norm, None
+        if max_norm is None or not params_with_grad:
+            return None, 0.0
+        sumsq = _global_sumsq(params_with_grad)
+        self.last_grad_norm = sumsq.sqrt()
+        return sumsq, max_norm
+
+
+def _adamw_groups_step(optimizer, groups, sumsq, max_norm):
+    """torch.optim.AdamW semantics for the given param groups, one wft_mt_adamw launch per (group, step count)."""
+    from whisper_finetune.engine import kernels as K
+
+    for group in groups:
+        b1, b2 = group["betas"]
+        by_step = {}
+        for p in group["params"]:
+            if p.grad is None:
+                continue
+            st = optimizer.state[p]
+            if not st:
+                st["step"] = 0
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            st["step"] += 1
+            by_step.setdefault(int(st["step"]), []).append(p)
+        for step, ps in by_step.items():
+            key = tuple(id(p) for p in ps)
+            cache = optimizer.__dict__.setdefault("_tables", {})
+            table = cache.get(key)
+            if table is None:
+                table = cache[key] = K.TensorTable(ps)
+            grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
+            K.mt_adamw(table, [p.data for p in ps], grads, [optimizer.state[p]["exp_avg"] for p in ps],
+                       [optimizer.state[p]["exp_avg_sq"] for p in ps], group["lr"], b1, b2, group["eps"],
+                       group["weight_decay"], 1 - b1 ** step, 1 - b2 ** step, sumsq, max_norm)
+
+
+class WftAdamW(_FusedClipMixin, torch.optim.Optimizer):
+    """AdamW (decoupled weight decay, bias correction; torch.optim.AdamW's state names) whose update is ONE libwft
+    launch for the whole parameter list (wft_mt_adamw, 28 B/parameter), with clip_grad_norm_ folded in."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False):
         if amsgrad:
-            raise NotImplementedError("amsgrad is not built into wft_adamw_step")
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
-        self.grad_scale = None
+            raise NotImplementedError("amsgrad is not built into wft_mt_adamw")
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        with_grad = [p for g in self.param_groups for p in g["params"] if p.grad is not None]
+        sumsq, max_norm = self._take_clip(with_grad)
+        _adamw_groups_step(self, self.param_groups, sumsq, max_norm)
+        return loss  # the bf16 weight shadows are invalidated by the global optimizer post-hook (engine/ops.py)
+
+
+class WftMuonWithAuxAdam(_FusedClipMixin, torch.optim.Optimizer):
+    """`muon.SingleDeviceMuonWithAuxAdam` / `muon.MuonWithAuxAdam` (third-party `muon` package the reference imports at
+    model/optimizer.py:171; published algorithm restated in oracle/whisper_oracle.py) on libwft kernels.
+
+    Param groups are the reference's: {"params", "lr", "momentum", "weight_decay", "use_muon": True} and
+    {"params", "lr", "betas", "eps", "weight_decay", "use_muon": False}.  Muon parameters of one shape are stepped
+    together: momentum/nesterov, bf16 cast, Frobenius normalisation, five Newton-Schulz iterations as BATCHED bf16
+    MFMA GEMMs, update.  Under DDP every rank holds identical (all-reduced) gradients, so every rank computes the
+    identical update locally; the reference's distributed variant shards that work and all-gathers the result,
+    which is numerically the same update."""
+
+    def __init__(self, param_groups):
+        for group in param_groups:
+            assert "use_muon" in group
+            if group["use_muon"]:
+                group["lr"] = group.get("lr", 0.02)
+                group["momentum"] = group.get("momentum", 0.95)
+                group["weight_decay"] = group.get("weight_decay", 0)
+                assert set(group.keys()) == {"params", "lr", "momentum", "weight_decay", "use_muon"}
+            else:
+                group["lr"] = group.get("lr", 3e-4)
+                group["betas"] = group.get("betas", (0.9, 0.95))
+                group["eps"] = group.get("eps", 1e-10)
+                group["weight_decay"] = group.get("weight_decay", 0)
+                assert set(group.keys()) == {"params", "lr", "betas", "eps", "weight_decay", "use_muon"}
+        super().__init__(param_groups, dict())
 
     @torch.no_grad()
     def step(self, closure=None):
         from whisper_finetune.engine import kernels as K
-        from whisper_finetune.engine import ops
 
         loss = closure() if closure is not None else None
         for group in self.param_groups:
-            b1, b2 = group["betas"]
+            if group["use_muon"]:
+                for p in group["params"]:
+                    if p.grad is None:
+                        p.grad = torch.zeros_like(p)  # muon.py: "force synchronization"
+        with_grad = [p for g in self.param_groups for p in g["params"] if p.grad is not None]
+        sumsq, max_norm = self._take_clip(with_grad)
+        for group in self.param_groups:
+            if not group["use_muon"]:
+                continue
+            buckets = {}
             for p in group["params"]:
-                if p.grad is None:
-                    continue
+                if p.ndim < 2:
+                    raise ValueError("Muon parameters must have ndim >= 2")
                 st = self.state[p]
                 if not st:
-                    st["step"] = 0
-                    st["m"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    st["v"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                st["step"] += 1
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                K.adamw_step(p, g, st["m"], st["v"], None, group["lr"], b1, b2, group["eps"], group["weight_decay"],
-                             1 - b1 ** st["step"], 1 - b2 ** st["step"], self.grad_scale)
-        ops.bump_shadow_epoch()  # parameters changed through raw pointers: invalidate the bf16 shadows
+                    st["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                buckets.setdefault((p.shape[0], p[0].numel()), []).append(p)
+            for (rows, cols), ps in buckets.items():
+                grads = [(p.grad if p.grad.is_contiguous() else p.grad.contiguous()).view(rows, cols) for p in ps]
+                K.muon_group_step([p.data.view(rows, cols) for p in ps], grads,
+                                  [self.state[p]["momentum_buffer"].view(rows, cols) for p in ps], group["lr"],
+                                  group["weight_decay"], group["momentum"], sumsq=sumsq, max_norm=max_norm)
+        _adamw_groups_step(self, [g for g in self.param_groups if not g["use_muon"]], sumsq, max_norm)
         return loss
+
+
+def _partition_muon_params(model, ndim_threshold: int = 2):
+    """Muon gets the >= ndim_threshold-D parameters INSIDE encoder.blocks / decoder.blocks; everything else (gains,
+    biases, embeddings, conv stem, final norms) stays on the auxiliary Adam (model/optimizer.py:9-52)."""
+    block_ids = {id(p) for blk in list(model.encoder.blocks) + list(model.decoder.blocks) for p in blk.parameters()}
+    muon, aux, seen = [], [], set()
+    for _, p in model.named_parameters():
+        if not p.requires_grad or id(p) in seen:
+            continue
+        (muon if id(p) in block_ids and p.ndim >= ndim_threshold else aux).append(p)
+        seen.add(id(p))
+    expected = {id(p) for p in model.parameters() if p.requires_grad}
+    if seen != expected:
+        raise RuntimeError(f"Muon parameter partition mismatch: missing={len(expected - seen)}, extra={len(seen - expected)}. "
+                           "This should not happen.")
+    return muon, aux
+
+
+def _use_muon_optimizer(optimizer_conf: Dict) -> bool:
+    if "muon" in optimizer_conf:
+        return bool(optimizer_conf["muon"])
+    return optimizer_conf.get("type") == "muon"
+
+
+def _muon_update_rms_match_scale(param, factor: float = 0.2) -> float:
+    """lr multiplier that turns the package's sqrt(max(1, A/B)) update scaling into the paper's 0.2 sqrt(max(A, B)):
+    factor * sqrt(B_effective), B_effective = last dim after Muon's flattening (model/optimizer.py:61-85)."""
+    if param.ndim < 2:
+        raise ValueError("Muon RMS matching requires parameters with ndim >= 2.")
+    b_eff = param[0].numel() if param.ndim == 4 else param.shape[-1]
+    return float(factor) * (float(b_eff) ** 0.5)
+
+
+def _build_muon_param_groups(muon_params, base_lr, base_weight_decay, momentum, match_adamw_update_rms, match_factor):
+    if not match_adamw_update_rms:
+        return [{"params": muon_params, "use_muon": True, "lr": base_lr, "momentum": momentum,
+                 "weight_decay": base_weight_decay}]
+    grouped = {}
+    for p in muon_params:
+        scale = _muon_update_rms_match_scale(p, factor=match_factor)
+        if scale <= 0:
+            raise ValueError(f"Muon RMS match scale must be > 0, got {scale}")
+        key = (p.ndim, p[0].numel() if p.ndim == 4 else p.shape[-1])
+        if key not in grouped:
+            grouped[key] = {"params": [], "use_muon": True, "lr": base_lr * scale, "momentum": momentum,
+                            "weight_decay": base_weight_decay / scale if base_weight_decay != 0 else 0.0}
+        grouped[key]["params"].append(p)
+    return list(grouped.values())
+
+
+def _get_muon_optimizer(model, optimizer_conf: Dict):
+    """model/optimizer.py:163-237: group construction, warnings and `_lr_group_metadata` identical; the optimizer class is
+    the libwft one on HIP tensors (and only there: there is no CPU Muon in this build)."""
+    if optimizer_conf.get("type") not in (None, "adamw", "muon"):
+        print("WARNING: optimizer.type is ignored when optimizer.muon=True. Using MuonWithAuxAdam.")
+    if optimizer_conf.get("8bit", False):
+        print("WARNING: optimizer.8bit=True is ignored for Muon.")
+    ndim_threshold = int(optimizer_conf.get("muon_ndim_threshold", 2))
+    if ndim_threshold < 1:
+        raise ValueError(f"optimizer.muon_ndim_threshold must be >= 1, got {ndim_threshold}")
+    muon_params, aux_params = _partition_muon_params(model, ndim_threshold=ndim_threshold)
+    muon_conf = optimizer_conf.get("muon_params", {})
+    adamw_conf = optimizer_conf.get("params", {})
+    adamw_lr = adamw_conf.get("lr", 3e-4)
+    adamw_betas = tuple(adamw_conf.get("betas", (0.9, 0.95)))
+    adamw_eps = adamw_conf.get("eps", 1e-10)
+    adamw_wd = adamw_conf.get("weight_decay", 0.0)
+    match = bool(optimizer_conf.get("muon_match_adamw_update_rms", True))
+    factor = float(optimizer_conf.get("muon_match_factor", 0.2))
+    if factor <= 0:
+        raise ValueError(f"optimizer.muon_match_factor must be > 0, got {factor}")
+    if "amsgrad" in adamw_conf:
+        print("WARNING: optimizer.params.amsgrad is not used by Muon auxiliary AdamW.")
+    muon_lr = muon_conf.get("lr", 0.02)
+    muon_momentum = muon_conf.get("momentum", 0.95)
+    muon_wd = muon_conf.get("weight_decay", adamw_wd)
+    groups = _build_muon_param_groups(muon_params, muon_lr, muon_wd, muon_momentum, match, factor)
+    metadata = [{"lr_log_label": "muon", "base_lr_unscaled": muon_lr} for _ in groups]
+    if aux_params:
+        groups.append({"params": aux_params, "use_muon": False, "lr": adamw_lr, "betas": adamw_betas, "eps": adamw_eps,
+                       "weight_decay": adamw_wd})
+        metadata.append({"lr_log_label": "aux_adamw", "base_lr_unscaled": adamw_lr})
+    if match:
+        print(f"Muon RMS matching active: factor={factor}, shared base_lr={muon_lr}, shared weight_decay={muon_wd}")
+    print(f"Using WftMuonWithAuxAdam with {len(muon_params)} Muon params and {len(aux_params)} AuxAdamW params")
+    optimizer = WftMuonWithAuxAdam(groups)
+    optimizer._lr_group_metadata = metadata
+    return optimizer
 
 
 def get_optimizer(model, optimizer_conf: Dict, is_lora_run: bool = False):
     params = [p for p in model.parameters() if p.requires_grad]
     print("---OPTIMIZER----")
     print_trainable_parameters(model)
+    if optimizer_conf.get("8bit", False) and is_lora_run:
+        print("WARNING: Using 8-bit optimizer with LoRA training.")
+    if _use_muon_optimizer(optimizer_conf):
+        return _get_muon_optimizer(model, optimizer_conf)
     if optimizer_conf.get("8bit", False):
-        raise ImportError("8-bit optimizers need bitsandbytes, which has no gfx950 build in this environment "
-                          "(set optimizer.8bit: False)")
-    if optimizer_conf.get("muon", False) or optimizer_conf.get("type") == "muon":
-        raise NotImplementedError("Muon + AuxAdam is not built yet (SURVEY.md §8f-1); use optimizer.type: adamw")
+        raise ImportError("For using Adam 8bit optimizer you need to have bitsandbytes installed. "
+                          "(no gfx950 build in this environment: set optimizer.8bit: False)")
     kind = optimizer_conf["type"]
     kw = dict(optimizer_conf.get("params", {}))
     if "betas" in kw:

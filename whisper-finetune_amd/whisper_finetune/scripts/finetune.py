@@ -87,6 +87,9 @@ def build_model(config: dict) -> Whisper:
         model.decoder = CheckpointedStochasticTextDecoder(dims.n_vocab, dims.n_text_ctx, dims.n_text_state, dims.n_text_head,
                                                           dims.n_text_layer, sd_p)
         model.load_state_dict(saved)
+    for part in (model.encoder, model.decoder):
+        if hasattr(part, "recompute"):
+            part.recompute = bool(t_cfg.get("wft_recompute", False))  # 288 GB HBM: keep activations resident by default
     resize_whisper_layers(model, enc_layers, dec_layers)
     model.is_bfloat = t_cfg.get("mp_dtype", "fp16") != "fp16"
     if t_cfg.get("train_only_decoder", False):
