@@ -58,6 +58,14 @@ int wft_cast_pad_transpose_f32_bf16(const float* src, int64_t rows, int64_t cols
                                     wft_bf16* dst, wft_bf16* dst_t,
                                     int64_t rows_pad, int64_t cols_pad,
                                     int64_t ld_dst, int64_t ld_dst_t, void* stream);
+/* W_eff = W + scaling * B @ (A * mask): the weight minLoRA's parametrization produces for every adapted Linear
+ * (reference call sites model/lora.py:30-71 apply, :83-89 merge).  W f32 [rows, cols], B f32
+ * [rows, rank], A f32 [rank, cols], mask f32 [cols] or NULL (the already-drawn dropout mask), rank <= 64.
+ * Outputs (any subset): dst bf16 [rows_pad, cols_pad] (ld_dst) and dst_t bf16 [cols_pad, rows_pad] (ld_dst_t), zero
+ * padded — the GEMM shadows of the training forward/backward; dst_f32 f32 [rows, cols] (may alias W) — merge_lora. */
+int wft_lora_merge(const float* W, int64_t rows, int64_t cols, const float* B, const float* A, const float* mask,
+                   int rank, float scaling, wft_bf16* dst, wft_bf16* dst_t, int64_t rows_pad, int64_t cols_pad,
+                   int64_t ld_dst, int64_t ld_dst_t, float* dst_f32, void* stream);
 /* y[i] = a[i] + b[i] (bf16) — gradient accumulation on the residual stream. */
 int wft_add_bf16(const wft_bf16* a, const wft_bf16* b, wft_bf16* y, int64_t n, void* stream);
 /* out = a*x + b*y over n bf16 elements (y may be NULL).  StochasticDepthMixin's train-time rescale

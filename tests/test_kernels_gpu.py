@@ -310,3 +310,38 @@ def test_gemm_tn_split_k_is_bitwise_reproducible():
     acc = torch.ones(1280, 1280, device=DEV)
     K.gemm_tn(a, b, out=acc, accumulate=True)
     close(acc, c1 + 1, 1e-6)
+
+
+@pytest.mark.parametrize("rows,cols,r,masked", [(384, 384, 16, True), (1536, 384, 4, False), (100, 200, 64, True)])
+def test_lora_merge_matches_minlora_parametrization(rows, cols, r, masked):
+    """wft_lora_merge: W + s*B@(A*mask) as f32 (merge_lora) and as padded bf16 shadows (+T) for the GEMMs."""
+    g = torch.Generator().manual_seed(rows + r)
+    W = torch.randn(rows, cols, generator=g) * 0.05
+    A = torch.randn(r, cols, generator=g) * 0.1
+    B = torch.randn(rows, r, generator=g) * 0.1
+    mask = (torch.rand(1, cols, generator=g) > 0.2).float() / 0.8 if masked else None
+    want = W + (B @ (A if mask is None else A * mask)) * 2.0
+    rp, cp = K.round_up(rows, 128), K.round_up(cols, 128)
+    out = torch.full((rp, cp), 7.0, dtype=torch.bfloat16, device=DEV)
+    out_t = torch.full((cp, rp), 7.0, dtype=torch.bfloat16, device=DEV)
+    out32 = torch.empty(rows, cols, device=DEV)
+    K.lora_merge(W.to(DEV), B.to(DEV), A.to(DEV), None if mask is None else mask.to(DEV), 2.0, out=out, out_t=out_t, out_f32=out32)
+    assert (out32.cpu() - want).abs().max() < 1e-5
+    assert torch.equal(out[:rows, :cols].cpu(), out32.cpu().to(torch.bfloat16))      # shadow = bf16(f32 result)
+    assert torch.equal(out_t.cpu(), out.cpu().t())
+    assert out[rows:].abs().max() == 0 and out[:, cols:].abs().max() == 0          # pad written as zeros
+    with pytest.raises(L.WftError):
+        K.lora_merge(W.to(DEV), torch.zeros(rows, 65, device=DEV), torch.zeros(65, cols, device=DEV), None, 1.0, out_f32=out32)
+
+
+def test_sd_rescale_kernel_and_transpose():
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 77, 40, generator=g).to(torch.bfloat16).to(DEV)
+    y = torch.randn(3, 77, 40, generator=g).to(torch.bfloat16).to(DEV)
+    s = 1 / 0.9
+    got = K.axpby_bf16(1 - s, x, s, y)
+    want = ((1 - s) * x.float() + s * y.float()).to(torch.bfloat16)
+    assert (got.float() - want.float()).abs().max() <= 2 ** -7 * want.float().abs().max()
+    assert torch.equal(K.axpby_bf16(2.0, x), (2.0 * x.float()).to(torch.bfloat16))
+    t = torch.empty(3, 40, 77, dtype=torch.bfloat16, device=DEV)
+    assert torch.equal(K.transpose_bf16(x, t), x.transpose(1, 2).contiguous())

@@ -90,6 +90,64 @@ extern "C" int wft_cast_pad_transpose_f32_bf16(const float* src, int64_t rows, i
   return WFT_OK;
 }
 
+// W_eff = W + scaling * B (A ⊙ mask): minLoRA's parametrized weight (merge: model/lora.py:83-89).
+// Written as bf16 [rows_pad, cols_pad] (+ transposed) for the GEMMs and/or as f32 [rows, cols] (merge_lora; may alias W).
+// 64x64 tiles; the tile's B rows and (masked, scaled) A columns sit in LDS: r <= 64 FMAs per element, HBM-bound.
+__global__ __launch_bounds__(256) void lora_merge_kernel(const float* W, long rows, long cols, const float* Bm, const float* Am,
+                                                          const float* mask, int r, float scaling, unsigned short* dst,
+                                                          unsigned short* dst_t, long rows_pad, long cols_pad, long ld_dst,
+                                                          long ld_dst_t, float* dst_f32) {
+  __shared__ unsigned short tile[64][66];
+  __shared__ float bs[64][65];  // bs[i][q] = B[r0 + i][q]
+  __shared__ float as[64][65];  // as[q][j] = scaling * A[q][c0 + j] * mask[c0 + j]
+  const long r0 = (long)blockIdx.y * 64, c0 = (long)blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 64 * r; i += 256) {
+    const int a = i / r, q = i - a * r;
+    bs[a][q] = (r0 + a < rows) ? Bm[(r0 + a) * r + q] : 0.f;
+  }
+  for (int i = threadIdx.x; i < 64 * r; i += 256) {
+    const int q = i >> 6, j = i & 63;
+    const long c = c0 + j;
+    as[q][j] = (c < cols) ? scaling * Am[(long)q * cols + c] * (mask ? mask[c] : 1.f) : 0.f;
+  }
+  __syncthreads();
+  for (int rr = ty; rr < 64; rr += 4) {
+    const long rw = r0 + rr, c = c0 + tx;
+    unsigned short v = 0;
+    if (rw < rows && c < cols) {
+      float acc = 0.f;
+      for (int q = 0; q < r; ++q) acc += bs[rr][q] * as[q][tx];
+      const float w = W[rw * cols + c] + acc;
+      if (dst_f32) dst_f32[rw * cols + c] = w;
+      v = f2bf(w);
+    }
+    tile[rr][tx] = v;
+    if (dst && rw < rows_pad && c < cols_pad) dst[rw * ld_dst + c] = v;
+  }
+  if (dst_t) {
+    __syncthreads();
+    for (int cc = ty; cc < 64; cc += 4) {
+      const long c = c0 + cc, rw = r0 + tx;
+      if (c < cols_pad && rw < rows_pad) dst_t[c * ld_dst_t + rw] = tile[tx][cc];
+    }
+  }
+}
+extern "C" int wft_lora_merge(const float* W, int64_t rows, int64_t cols, const float* B, const float* A, const float* mask,
+                              int rank, float scaling, wft_bf16* dst, wft_bf16* dst_t, int64_t rows_pad, int64_t cols_pad,
+                              int64_t ld_dst, int64_t ld_dst_t, float* dst_f32, void* stream) {
+  WFT_CHECK_ARG(W && B && A && (dst || dst_f32), "null pointer");
+  WFT_CHECK_ARG(rows >= 1 && cols >= 1 && rank >= 1 && rank <= 64, "rank must be in 1..64");
+  WFT_CHECK_ARG(!dst || (rows_pad >= rows && cols_pad >= cols && ld_dst >= cols_pad), "bad bf16 destination shape");
+  WFT_CHECK_ARG(!dst_t || (dst && ld_dst_t >= rows_pad), "transposed destination needs dst and ld_dst_t >= rows_pad");
+  if (!dst) { rows_pad = rows; cols_pad = cols; }
+  dim3 grid((unsigned)((cols_pad + 63) / 64), (unsigned)((rows_pad + 63) / 64));
+  hipLaunchKernelGGL(lora_merge_kernel, grid, dim3(256), 0, (hipStream_t)stream, W, (long)rows, (long)cols, B, A, mask, rank,
+                     scaling, dst, dst_t, (long)rows_pad, (long)cols_pad, (long)ld_dst, (long)ld_dst_t, dst_f32);
+  WFT_CHECK_LAUNCH();
+  return WFT_OK;
+}
+
 __global__ __launch_bounds__(256) void add_bf16_kernel(const unsigned short* a, const unsigned short* b,
                                                         unsigned short* y, long n) {
   const long nv = n >> 3;

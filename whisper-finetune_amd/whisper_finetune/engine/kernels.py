@@ -70,6 +70,32 @@ def weight_shadow(w: torch.Tensor, rows_pad: int, cols_pad: int, want_t: bool, o
     return dst, dst_t
 
 
+def lora_merge(w, B, A, mask, scaling: float, rows_pad=None, cols_pad=None, out=None, out_t=None, out_f32=None):
+    """W + scaling * B @ (A * mask) -> bf16 shadow `out` [rows_pad, cols_pad] (+ `out_t`) and/or f32 `out_f32` [rows, cols]."""
+    for n, t in (("w", w), ("B", B), ("A", A)):
+        _chk(t, F32, n)
+    w2 = w.reshape(w.shape[0], -1).contiguous()
+    rows, cols = w2.shape
+    B, A = B.contiguous(), A.contiguous()
+    r = A.shape[0]
+    assert B.shape == (rows, r) and A.shape == (r, cols)
+    if mask is not None:
+        _chk(mask, F32, "mask")
+        mask = mask.reshape(-1).contiguous()
+        assert mask.numel() == cols
+    if out is not None:
+        rows_pad = out.shape[0] if rows_pad is None else rows_pad
+        cols_pad = out.shape[1] if cols_pad is None else cols_pad
+        assert out.stride(1) == 1 and (out_t is None or out_t.stride(1) == 1)
+    L.check(
+        L.load().wft_lora_merge(_p(w2), rows, cols, _p(B), _p(A), _p(mask), r, float(scaling), _p(out), _p(out_t),
+                                rows_pad or rows, cols_pad or cols, 0 if out is None else out.stride(0),
+                                0 if out_t is None else out_t.stride(0), _p(out_f32), L.stream_ptr()),
+        "wft_lora_merge",
+    )
+    return out, out_t, out_f32
+
+
 def add_bf16(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     _chk(a, BF16, "a"); _chk(b, BF16, "b")
     a = a.contiguous(); b = b.contiguous()

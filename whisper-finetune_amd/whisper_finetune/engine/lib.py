@@ -63,6 +63,7 @@ SIGNATURES = {
     "wft_cast_f32_bf16": [c_vp, c_vp, c_i64, c_vp],
     "wft_cast_bf16_f32": [c_vp, c_vp, c_i64, c_vp],
     "wft_cast_pad_transpose_f32_bf16": [c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp],
+    "wft_lora_merge": [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, C.c_int, C.c_float, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp],
     "wft_add_bf16": [c_vp, c_vp, c_vp, c_i64, c_vp],
     "wft_axpby_bf16": [C.c_float, c_vp, C.c_float, c_vp, c_vp, c_i64, c_vp],
     "wft_dgelu_mul_bf16": [c_vp, c_vp, c_vp, c_i64, c_vp],

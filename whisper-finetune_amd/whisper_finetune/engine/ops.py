@@ -60,6 +60,7 @@ class LinearGroup:
         self.W = self.WT = self.bias = None
         self.lkey = None
         self.Am = self.AmT = self.Bb = self.BbT = None
+        self._Am32 = self._Bb32 = None
 
     @staticmethod
     def dims(weights: Sequence[torch.Tensor]):
@@ -70,9 +71,19 @@ class LinearGroup:
             raise L.WftError(f"in_features={k} must be a multiple of 128 (pad the operand)")
         return n, k, K.round_up(n, 128)
 
-    def shadows(self, weights, biases, need_t: bool):
+    def shadows(self, weights, biases, need_t: bool, loras=None):
+        """bf16 [Npad, K] (+ transposed) image of the stacked weights.  With `loras`, every adapted weight is written as
+        W + s*B@(A*mask) by wft_lora_merge — the same effective weight minLoRA's parametrization hands to F.linear — so
+        the forward and backward-data GEMMs of a LoRA run are exactly the plain ones."""
         want_t = need_t or self.WT is not None
-        key = (tuple(_ver(w) for w in weights), tuple(_ver(b) for b in biases), want_t, _SHADOW_EPOCH[0])
+        # torch's fused optimizers do not bump _version: trainable tensors are additionally keyed on the optimizer epoch;
+        # FROZEN ones (LoRA base weights) are not, so their shadows survive optimizer steps
+        live = any(t is not None and t.requires_grad for t in list(weights) + list(biases))
+        lkey = None
+        if loras is not None and any(sp is not None for sp in loras):
+            lkey = tuple(None if sp is None else (_ver(sp.A), _ver(sp.B), _ver(sp.mask), sp.scaling) for sp in loras)
+            live = True
+        key = (tuple(_ver(w) for w in weights), tuple(_ver(b) for b in biases), want_t, _SHADOW_EPOCH[0] if live else -1, lkey)
         if key != self.key:
             n, k, npad = self.dims(weights)
             dev = weights[0].device
@@ -82,13 +93,19 @@ class LinearGroup:
             if want_t and self.WT is None:
                 self.WT = torch.zeros((k, npad), dtype=BF16, device=dev)
             off = 0
-            for w in weights:
+            for i, w in enumerate(weights):
                 o = w.shape[0]
-                K.weight_shadow(w.detach(), o, k, want_t, out=self.W[off:off + o],
-                                out_t=self.WT[:, off:off + o] if want_t else None)
+                sp = loras[i] if lkey is not None else None
+                if sp is None:
+                    K.weight_shadow(w.detach(), o, k, want_t, out=self.W[off:off + o],
+                                    out_t=self.WT[:, off:off + o] if want_t else None)
+                else:
+                    K.lora_merge(w.detach(), sp.B.detach(), sp.A.detach(), None if sp.mask is None else sp.mask.detach(), sp.scaling,
+                                 rows_pad=o, cols_pad=k, out=self.W[off:off + o], out_t=self.WT[:, off:off + o] if want_t else None)
                 off += o
             if any(b is not None for b in biases):
-                self.bias = torch.zeros(npad, dtype=F32, device=dev)
+                if self.bias is None or self.bias.shape[0] != npad:
+                    self.bias = torch.zeros(npad, dtype=F32, device=dev)
                 off = 0
                 for w, b in zip(weights, biases):
                     if b is not None:
@@ -100,27 +117,30 @@ class LinearGroup:
         return self.W, self.WT, self.bias
 
     def lora_shadows(self, weights, loras: Sequence[Optional[LoraSpec]]):
-        """(A*mask) stacked [Rpad, Kpad] (+T) and block-diagonal scaling*B [Npad, Rpad] (+T)."""
+        """(A*mask) stacked [Rpad, K] and block-diagonal scaling*B [Npad, Rpad], both (+T) in bf16: the operands of the
+        rank-r gradient GEMMs (backward only)."""
         key = tuple(None if s is None else (_ver(s.A), _ver(s.B), _ver(s.mask), s.scaling) for s in loras) + (_SHADOW_EPOCH[0],)
         if key != self.lkey:
             n, k, npad = self.dims(weights)
-            kpad = k
             dev = weights[0].device
             rtot = sum(s.A.shape[0] for s in loras if s is not None)
             rpad = K.round_up(rtot, 128)
-            Am = torch.zeros((rpad, k), dtype=F32, device=dev)
-            Bb = torch.zeros((n, rpad), dtype=F32, device=dev)
+            if self._Am32 is None or self._Am32.shape != (rpad, k):
+                self._Am32 = torch.zeros((rpad, k), dtype=F32, device=dev)   # rows >= rtot and the off-diagonal of Bb stay zero
+                self._Bb32 = torch.zeros((n, rpad), dtype=F32, device=dev)
             ro = no = 0
             for w, s in zip(weights, loras):
                 if s is not None:
                     r = s.A.shape[0]
-                    a = s.A.detach() if s.mask is None else s.A.detach() * s.mask
-                    Am[ro:ro + r] = a
-                    Bb[no:no + w.shape[0], ro:ro + r] = s.B.detach() * s.scaling
+                    if s.mask is None:
+                        self._Am32[ro:ro + r].copy_(s.A.detach())
+                    else:
+                        torch.mul(s.A.detach(), s.mask, out=self._Am32[ro:ro + r])
+                    torch.mul(s.B.detach(), s.scaling, out=self._Bb32[no:no + w.shape[0], ro:ro + r])
                     ro += r
                 no += w.shape[0]
-            self.Am, self.AmT = K.weight_shadow(Am, rpad, kpad, True)
-            self.Bb, self.BbT = K.weight_shadow(Bb, npad, rpad, True)
+            self.Am, self.AmT = K.weight_shadow(self._Am32, rpad, k, True, out=self.Am, out_t=self.AmT)
+            self.Bb, self.BbT = K.weight_shadow(self._Bb32, npad, rpad, True, out=self.Bb, out_t=self.BbT)
             self.lkey = key
         return self.Am, self.AmT, self.Bb, self.BbT
 
@@ -154,33 +174,22 @@ class LinearFn(torch.autograd.Function):
             biases.append(bias_list[bi] if hb else None)
             bi += int(hb)
         need_dx = ctx.needs_input_grad[0] or (gelu_pre is not None and ctx.needs_input_grad[2])
-        W, WT, bias = cfg.group.shadows(weights, biases, need_t=need_dx)
+        has_lora = any(s is not None for s in cfg.loras)
+        W, WT, bias = cfg.group.shadows(weights, biases, need_t=need_dx, loras=cfg.loras if has_lora else None)
         n, k, npad = LinearGroup.dims(weights)
         kpad = k
         assert x.dtype == BF16 and x.dim() == 2 and x.is_contiguous() and x.shape[1] == kpad, (x.shape, kpad)
         M = x.shape[0]
-        has_lora = any(s is not None for s in cfg.loras)
-        u = None
         out_pre = None
-        if not has_lora:
-            if cfg.gelu_out:
-                out_pre = torch.empty((M, npad), dtype=BF16, device=x.device)
-                y = K.gemm_nt(x, W, bias=bias, epilogue=L.EPI_GELU, aux=out_pre, residual=residual)
-            else:
-                y = K.gemm_nt(x, W, bias=bias, residual=residual)
+        if cfg.gelu_out:
+            out_pre = torch.empty((M, npad), dtype=BF16, device=x.device)
+            y = K.gemm_nt(x, W, bias=bias, epilogue=L.EPI_GELU, aux=out_pre, residual=residual)
         else:
-            Am, AmT, Bb, BbT = cfg.group.lora_shadows(weights, cfg.loras)
-            u = K.gemm_nt(x, Am)  # [M, Rpad]
-            y0 = K.gemm_nt(x, W, bias=bias, residual=None if cfg.gelu_out else residual)
-            if cfg.gelu_out:
-                out_pre = torch.empty((M, npad), dtype=BF16, device=x.device)
-                y = K.gemm_nt(u, Bb, residual=y0, residual_first=True, epilogue=L.EPI_GELU, aux=out_pre)
-            else:
-                y = K.gemm_nt(u, Bb, residual=y0)
+            y = K.gemm_nt(x, W, bias=bias, residual=residual)
         ctx.cfg = cfg
         ctx.has_res = residual is not None
         ctx.dims = (n, k, npad, kpad)
-        ctx.save_for_backward(x, gelu_pre, out_pre, u, *params)
+        ctx.save_for_backward(x, gelu_pre, out_pre, *params)
         if cfg.gelu_out:
             ctx.mark_non_differentiable(y)
             return out_pre, y
@@ -189,7 +198,7 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         cfg: _LinearCfg = ctx.cfg
-        x, gelu_pre, out_pre, u, *params = ctx.saved_tensors
+        x, gelu_pre, out_pre, *params = ctx.saved_tensors
         n, k, npad, kpad = ctx.dims
         n_w = cfg.n_w
         weights = list(params[:n_w])
@@ -201,27 +210,15 @@ class LinearFn(torch.autograd.Function):
         if dy.dtype != BF16:
             dy = dy.to(BF16)
         dy = dy.contiguous()
-        W, WT, _ = cfg.group.shadows(weights, _bias_list(cfg, params), need_t=True)
+        W, WT, _ = cfg.group.shadows(weights, _bias_list(cfg, params), need_t=True, loras=cfg.loras if has_lora else None)
         # NB: with GELU-out the incoming grad is w.r.t. the pre-activation already (act is non-diff)
         dx = dpre = None
         need_dx = ctx.needs_input_grad[0] or (gelu_pre is not None and ctx.needs_input_grad[2])
-        du = None
-        if has_lora:
-            Am, AmT, Bb, BbT = cfg.group.lora_shadows(weights, cfg.loras)
-            du = K.gemm_nt(dy, BbT)  # [M, Rpad] = dy @ (s*B)
-        if need_dx:
+        if need_dx:  # WT is the EFFECTIVE weight (base + adapters): one GEMM, as without LoRA
             if gelu_pre is not None:
-                if has_lora:
-                    d0 = K.gemm_nt(dy, WT)
-                    dpre = K.gemm_nt(du, AmT, residual=d0, residual_first=True, epilogue=L.EPI_DGELU, aux=gelu_pre)
-                else:
-                    dpre = K.gemm_nt(dy, WT, epilogue=L.EPI_DGELU, aux=gelu_pre)
+                dpre = K.gemm_nt(dy, WT, epilogue=L.EPI_DGELU, aux=gelu_pre)
             else:
-                if has_lora:
-                    d0 = K.gemm_nt(dy, WT)
-                    dx = K.gemm_nt(du, AmT, residual=d0)
-                else:
-                    dx = K.gemm_nt(dy, WT)
+                dx = K.gemm_nt(dy, WT)
         out: List[Optional[torch.Tensor]] = [dx, dy if ctx.has_res else None, dpre, None]
         # parameter grads: weights
         w_need = [ctx.needs_input_grad[4 + i] for i in range(n_w)]
@@ -252,8 +249,14 @@ class LinearFn(torch.autograd.Function):
             base = 4 + n_w + nb
             a_need = [ctx.needs_input_grad[base + i] for i in range(n_l)]
             b2_need = [ctx.needs_input_grad[base + n_l + i] for i in range(n_l)]
-            dA_full = K.gemm_tn(du, x) if any(a_need) else None  # [Rpad, Kpad]
-            dB_full = K.gemm_tn(dy, u) if any(b2_need) else None  # [Npad, Rpad]
+            Am, AmT, Bb, BbT = cfg.group.lora_shadows(weights, cfg.loras)
+            dA_full = dB_full = None
+            if any(a_need):
+                du = K.gemm_nt(dy, BbT)        # [M, Rpad] = dy @ (s*B)
+                dA_full = K.gemm_tn(du, x)     # [Rpad, Kpad]
+            if any(b2_need):
+                u = K.gemm_nt(x, Am)           # [M, Rpad] = x @ (A*mask)^T, recomputed here instead of saved by the forward
+                dB_full = K.gemm_tn(dy, u)     # [Npad, Rpad]
             dAs, dBs = [], []
             ro = no = li = 0
             for w, s in zip(weights, cfg.loras):

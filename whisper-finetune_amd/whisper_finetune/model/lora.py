@@ -3,14 +3,15 @@
 print_lora_info, is_lora_enabled, get_lora_debug_stats, LoRAUpdateTracker,
 log_lora_debug_info), same parameter / state-dict names as minLoRA's weight parametrization
 (`<linear>.parametrizations.weight.original`, `.0.lora_A`, `.0.lora_B`,
-`.0.lora_dropout_mask` — SURVEY.md App. A.3) — but evaluated NATIVELY in low-rank form:
+`.0.lora_dropout_mask` — SURVEY.md App. A.3).  engine/ops.LinearFn evaluates
 
-    y = x W^T + b + (alpha/r) * ((x * m) A^T) B^T        (never materialising W + s*B@A)
+    y = x (W + (alpha/r) B (A * m))^T + b
 
-by engine/ops.LinearFn, so a frozen base Linear costs two rank-r GEMMs in the backward
-instead of the full d_out x d_in weight-gradient GEMM the parametrization form pays
-(SURVEY.md finding 7).  `layer.weight` still returns the effective weight for code that
-reads it (merge / save / debugging).
+with the effective weight written straight into the bf16 GEMM shadow by `wft_lora_merge` (one HBM-bound pass per
+Linear per forward, instead of an fp32 delta + add + cast), so forward and backward-data are the plain GEMMs; the
+adapter gradients stay low-rank (dA = (dy sB)^T x, dB = s dy^T (x (A*m)^T): four rank-r GEMMs) instead of the full
+d_out x d_in weight-gradient GEMM the parametrization form pays (SURVEY.md finding 7).  `layer.weight` still returns
+the effective weight for code that reads it (merge / save / debugging).
 """
 from __future__ import annotations
 
@@ -56,6 +57,12 @@ class LoRAParametrization(nn.Module):
         if not self.enabled:
             return W
         m = self.draw_mask(self.training)
+        if W.is_cuda and W.dtype == torch.float32 and W.dim() == 2 and not torch.is_grad_enabled():
+            from whisper_finetune.engine import kernels as K
+
+            out = torch.empty_like(W)  # native merge kernel W + s*B@(A*mask) (merge_lora, save paths)
+            K.lora_merge(W, self.lora_B, self.lora_A, m, self.scaling, out_f32=out)
+            return out
         A = self.lora_A if m is None else self.lora_A * m
         return W + (self.lora_B @ A).view(W.shape) * self.scaling
 
