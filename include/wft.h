@@ -93,11 +93,14 @@ int wft_layernorm_fwd(const wft_bf16* x, const float* gamma, const float* beta,
                       void* stream);
 /* dx = LN'(dy) (+ dres if dres != NULL); dgamma/dbeta are ACCUMULATED (+=).
  * partial: f32 workspace of wft_layernorm_bwd_workspace(rows, cols) bytes.
- * The same mask arguments zero the masked positions of dy first.            */
+ * The same mask arguments zero the masked positions of dy first.
+ * dx_colsum (f32 [cols] or NULL): column sums of the bf16 dx just written — dx is the gradient of the residual
+ * stream, i.e. dy of the Linear (out / mlp.2) whose output was added to it, so this IS that Linear's bias
+ * gradient and saves a separate pass over [rows, cols].                                          */
 int64_t wft_layernorm_bwd_workspace(int64_t rows, int cols);
 int wft_layernorm_bwd(const wft_bf16* dy, const wft_bf16* x, const float* gamma,
                       const float* mean, const float* rstd, const wft_bf16* dres,
-                      wft_bf16* dx, float* dgamma, float* dbeta, void* partial,
+                      wft_bf16* dx, float* dgamma, float* dbeta, float* dx_colsum, void* partial,
                       int64_t rows, int cols,
                       int rows_per_batch, int t0, int t1, int c0, int c1,
                       void* stream);
@@ -142,12 +145,18 @@ typedef struct {
    * 0 is read as 1 so that zero-initialised structs keep the plain residual add.  (Newton-Schulz steps of the
    * Muon optimizer: B = b*A + c*A@A, X' = a*X + B@X — muon.py zeropower_via_newtonschulz5.)            */
   float beta; int reserved0;
+  /* wft_gemm_nt_bf16 only: if != NULL (bf16 C, batch == 1), colsum[n] = sum over rows of the C just written — the bias
+   * gradient of the Linear that consumes C as its dy (C = d(pre-activation) from the DGELU epilogue).  With `workspace`
+   * of wft_gemm_nt_colsum_workspace_bytes(args) bytes the sums are formed in the epilogue of the 256x256 kernel (no
+   * second pass over C); otherwise the library runs wft_colsum_bf16 over C after the GEMM.                      */
+  float* colsum;
 } wft_gemm_args;
 int wft_gemm_nt_bf16(const wft_gemm_args* args, void* stream);
 /* Which kernel wft_gemm_nt_bf16 dispatches these arguments to: 256 (gemm_nt256_kernel, 256x256
  * ping-pong tiles) or 128 (gemm_nt_kernel).  Pure host function (used by bench.py to attribute
  * HIP-event timings to the kernel names rocprofv3 reports).                              */
 int wft_gemm_nt_variant(const wft_gemm_args* args);
+int64_t wft_gemm_nt_colsum_workspace_bytes(const wft_gemm_args* args);
 /* C[p, q] (+)= alpha * sum_r A[r, p] * B[r, q]   (weight gradients dW = dY^T X:
  * what autograd's mm-backward computes for whisper.model.Linear).
  *  A bf16 [R, P] (row r at A + r*lda, P contiguous), B bf16 [R, Q];

@@ -329,7 +329,7 @@ def test_lora_merge_matches_minlora_parametrization(rows, cols, r, masked):
     assert (out32.cpu() - want).abs().max() < 1e-5
     assert torch.equal(out[:rows, :cols].cpu(), out32.cpu().to(torch.bfloat16))      # shadow = bf16(f32 result)
     assert torch.equal(out_t.cpu(), out.cpu().t())
-    assert out[rows:].abs().max() == 0 and out[:, cols:].abs().max() == 0          # pad written as zeros
+    assert out[rows:].abs().sum() == 0 and out[:, cols:].abs().sum() == 0          # pad written as zeros
     with pytest.raises(L.WftError):
         K.lora_merge(W.to(DEV), torch.zeros(rows, 65, device=DEV), torch.zeros(65, cols, device=DEV), None, 1.0, out_f32=out32)
 
@@ -345,3 +345,30 @@ def test_sd_rescale_kernel_and_transpose():
     assert torch.equal(K.axpby_bf16(2.0, x), (2.0 * x.float()).to(torch.bfloat16))
     t = torch.empty(3, 40, 77, dtype=torch.bfloat16, device=DEV)
     assert torch.equal(K.transpose_bf16(x, t), x.transpose(1, 2).contiguous())
+
+
+def test_fused_bias_gradient_column_sums():
+    """colsum(dx) out of the LayerNorm backward and colsum(C) out of the 256x256 GEMM epilogue (and its fallback)."""
+    g = torch.Generator().manual_seed(9)
+    rows, cols = 3000, 384
+    x = torch.randn(rows, cols, generator=g).to(torch.bfloat16).to(DEV)
+    dy = torch.randn(rows, cols, generator=g).to(torch.bfloat16).to(DEV)
+    dres = torch.randn(rows, cols, generator=g).to(torch.bfloat16).to(DEV)
+    gamma = (1 + 0.1 * torch.randn(cols, generator=g)).to(DEV)
+    _, mean, rstd = K.layernorm_fwd(x, gamma, torch.zeros(cols, device=DEV))
+    dx, dg, db, cs = K.layernorm_bwd(dy, x, gamma, mean, rstd, dres, want_colsum=True)
+    dx2, dg2, db2 = K.layernorm_bwd(dy, x, gamma, mean, rstd, dres)
+    assert torch.equal(dx, dx2) and torch.equal(dg, dg2) and torch.equal(db, db2)
+    want = dx.float().sum(0)
+    assert (cs - want).abs().max() < 1e-3 * want.abs().max() + 1e-3
+    # GEMM epilogue (M >= 1024, N % 256 == 0 -> 256 kernel, fused) and the 128-kernel fallback
+    for M, N, Kd in ((2304, 512, 256), (300, 384, 128)):
+        a = (torch.randn(M, Kd, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+        b = (torch.randn(N, Kd, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+        pre = torch.randn(M, N, generator=g).to(torch.bfloat16).to(DEV)
+        cs = torch.full((N,), 123.0, device=DEV)
+        c = K.gemm_nt(a, b, epilogue=L.EPI_DGELU, aux=pre, colsum=cs)
+        c0 = K.gemm_nt(a, b, epilogue=L.EPI_DGELU, aux=pre)
+        assert torch.equal(c, c0)
+        want = c.float().sum(0)
+        assert (cs - want).abs().max() < 4e-3 * want.abs().max() + 1e-2  # fused sums are of the un-rounded fp32 values

@@ -27,6 +27,7 @@ struct GemmP {
   int period, valid;
   int res_first;
   float* ws;  // split-K partial tiles [nsplit][P][Q] fp32 (TN, optional)
+  float* cs_part;  // NT256: per-(row tile, wave row) column-sum partials [2*tiles_m][N] fp32, or NULL
   int diag;  // timing-only diagnostic builds of the 256 kernel (WFT_GEMM_DIAG): 1 no vmcnt wait, 2 no staging loads, 3 = 2 + no barrier
 };
 
@@ -319,9 +320,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
       char* lds = dsmem + 131072 + wave * 4096;
       const int er = lane >> 3, ec = (lane & 7) * 8;  // row within an 8-row group, first of this lane's 8 columns
       const int ncol = n0 + wn * 64 + ec;
-      float bias8[8];
+      float bias8[8], cs8[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+      for (int e = 0; e < 8; ++e) { bias8[e] = 0.f; cs8[e] = 0.f; }
       if (p.bias) {
         const f32x4 b0 = *(const f32x4*)(p.bias + ncol), b1 = *(const f32x4*)(p.bias + ncol + 4);
 #pragma unroll
@@ -376,9 +377,28 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
             }
             u32x4 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
             *(u32x4*)((unsigned short*)p.C + cb + roff * p.ldc + ncol) = pk;
+            if (p.cs_part) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) cs8[e] += v[e];
+            }
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      if (p.cs_part) {  // column sums of this wave's 128 x 64 block: reduce over the 8 row-lanes, lanes 0-7 store 8 columns each
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float t = cs8[e];
+          t += __shfl_xor(t, 8, 64);
+          t += __shfl_xor(t, 16, 64);
+          t += __shfl_xor(t, 32, 64);
+          cs8[e] = t;
+        }
+        if (lane < 8) {
+          float* dstp = p.cs_part + (long)(tm * 2 + wm) * p.N + ncol;
+          *(f32x4*)dstp = f32x4{cs8[0], cs8[1], cs8[2], cs8[3]};
+          *(f32x4*)(dstp + 4) = f32x4{cs8[4], cs8[5], cs8[6], cs8[7]};
+        }
       }
       continue;
     }
@@ -831,6 +851,7 @@ static int fill_params(const wft_gemm_args* a, GemmP& p) {
   p.res_first = a->residual_first;
   p.diag = g_diag;
   p.ws = nullptr;
+  p.cs_part = nullptr;
   return 0;
 }
 
@@ -844,6 +865,24 @@ static int wft_num_cus() {
   }
   return n;
 }
+// out[col] = sum over `nrows` partial rows (fixed order): finishes the fused bias-gradient column sums of gemm_nt256_kernel
+__global__ __launch_bounds__(256) void nt_colsum_reduce_kernel(const float* partial, int nrows, int n, float* out) {
+  __shared__ float red[8][33];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + cx;
+  float sacc = 0.f;
+  if (col < n)
+    for (int r = ry; r < nrows; r += 8) sacc += partial[(long)r * n + col];
+  red[ry][cx] = sacc;
+  __syncthreads();
+  if (ry == 0 && col < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][cx];
+    out[col] = t;
+  }
+}
+
 static bool nt_uses_256(const wft_gemm_args* a) {
   const bool wide_ok = a->c_is_f32 || (a->ldc % 8 == 0 && (!a->residual || (a->ldr % 8 == 0 && ((uintptr_t)a->residual & 15) == 0)) &&
                                        (!a->aux || (a->ldaux % 8 == 0 && ((uintptr_t)a->aux & 15) == 0)) &&
@@ -852,6 +891,11 @@ static bool nt_uses_256(const wft_gemm_args* a) {
          ((a->M + 255) / 256) * (a->N / 256) * a->batch >= 192;
 }
 extern "C" int wft_gemm_nt_variant(const wft_gemm_args* a) { return a && nt_uses_256(a) ? 256 : 128; }
+
+extern "C" int64_t wft_gemm_nt_colsum_workspace_bytes(const wft_gemm_args* a) {
+  if (!a || !a->colsum || a->c_is_f32 || a->batch != 1 || !nt_uses_256(a)) return 0;
+  return (int64_t)2 * ((a->M + 255) / 256) * a->N * (int64_t)sizeof(float);
+}
 
 extern "C" int wft_gemm_nt_bf16(const wft_gemm_args* a, void* stream) {
   WFT_CHECK_ARG(a && a->A && a->B && a->C, "null pointer");
@@ -875,6 +919,12 @@ extern "C" int wft_gemm_nt_bf16(const wft_gemm_args* a, void* stream) {
                                        (!a->bias || ((uintptr_t)a->bias & 15) == 0));
   const bool big_unused = false;
 #endif
+  const bool cs_fused = a->colsum && big && !a->c_is_f32 && a->batch == 1 && a->workspace &&
+                        a->workspace_bytes >= wft_gemm_nt_colsum_workspace_bytes(a);
+  if (a->colsum) {
+    WFT_CHECK_ARG(!a->c_is_f32 && a->batch == 1, "colsum needs a bf16 C and batch == 1");
+    if (cs_fused) p.cs_part = (float*)a->workspace;
+  }
   if (big) {
     static bool attr_done = false;
     const long t256 = ((a->M + 255) / 256) * (a->N / 256) * a->batch;
@@ -895,7 +945,11 @@ extern "C" int wft_gemm_nt_bf16(const wft_gemm_args* a, void* stream) {
       default: wft_set_error("wft_gemm_nt_bf16: unknown epilogue %d", a->epilogue); return WFT_ERR_ARG;
     }
 #undef LAUNCH_256
+    if (cs_fused)
+      hipLaunchKernelGGL(nt_colsum_reduce_kernel, dim3((unsigned)((a->N + 31) / 32)), dim3(256), 0, s, (const float*)a->workspace,
+                         (int)(2 * ((a->M + 255) / 256)), (int)a->N, a->colsum);
     WFT_CHECK_LAUNCH();
+    if (a->colsum && !cs_fused) return wft_colsum_bf16((const wft_bf16*)a->C, a->M, a->N, a->ldc, a->colsum, 0, stream);
     return WFT_OK;
   }
   const long tiles = ((a->M + 127) / 128) * (a->N / 128);
@@ -913,6 +967,7 @@ extern "C" int wft_gemm_nt_bf16(const wft_gemm_args* a, void* stream) {
   }
 #undef LAUNCH_NT
   WFT_CHECK_LAUNCH();
+  if (a->colsum) return wft_colsum_bf16((const wft_bf16*)a->C, a->M, a->N, a->ldc, a->colsum, 0, stream);
   return WFT_OK;
 }
 

@@ -91,22 +91,25 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const unsigned short* x, co
 // backward: each wave walks rows (grid-stride), keeps per-lane dgamma/dbeta partials for its
 // columns, then the 4 waves of a block are summed through LDS and written to
 // partial[block][2][cols]; ln_bwd_reduce sums the blocks (deterministic, no atomics).
+template <bool DXSUM>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const unsigned short* dy, const unsigned short* x,
                                                       const float* gamma, const float* mean,
                                                       const float* rstd, const unsigned short* dres,
                                                       unsigned short* dx, float* partial, long rows, int cols,
                                                       int rpb, int t0, int t1, int c0, int c1) {
-  __shared__ float red[4][2][LN_MAXC * 64 * 8 / 4];  // reused per chunk pass; sized below
+  __shared__ float red[4][DXSUM ? 3 : 2][LN_MAXC * 64 * 8 / 4];  // reused per chunk pass; sized below
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const long wave_id = (long)blockIdx.x * 4 + wv;
   const long nwaves = (long)gridDim.x * 4;
   const int nch = cols >> 3;
   float dg[LN_MAXC][8], db[LN_MAXC][8], gm[LN_MAXC][8];
+  float dsum[DXSUM ? LN_MAXC : 1][8];  // column sums of the bf16 dx this wave writes (bias grad of the producing Linear)
 #pragma unroll
   for (int c = 0; c < LN_MAXC; ++c) {
     const int ch = lane + c * 64;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
+      if (DXSUM) dsum[c][e] = 0.f;
       dg[c][e] = 0.f;
       db[c][e] = 0.f;
       gm[c][e] = (ch < nch) ? gamma[ch * 8 + e] : 0.f;
@@ -158,13 +161,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const unsigned short* dy, c
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] += rv[e];
         }
+        if (DXSUM) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dsum[c][e] += bf2f(f2bf(o[e]));  // what wft_colsum_bf16 would read back
+        }
         store8(dx + row * cols + ch * 8, o);
       }
     }
   }
   // block reduction of dgamma/dbeta partials, one chunk-slot at a time through LDS
-  float* pg = partial + (long)blockIdx.x * 2 * cols;
+  float* pg = partial + (long)blockIdx.x * (DXSUM ? 3 : 2) * cols;
   float* pb = pg + cols;
+  float* ps = pb + cols;
 #pragma unroll
   for (int c = 0; c < LN_MAXC; ++c) {
     __syncthreads();
@@ -172,6 +180,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const unsigned short* dy, c
     for (int e = 0; e < 8; ++e) {
       red[wv][0][lane * 8 + e] = dg[c][e];
       red[wv][1][lane * 8 + e] = db[c][e];
+      if (DXSUM) red[wv][2][lane * 8 + e] = dsum[c][e];
     }
     __syncthreads();
     // 512 columns of this slot, 256 threads -> 2 each
@@ -180,6 +189,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const unsigned short* dy, c
       if (col < cols) {
         pg[col] = red[0][0][k] + red[1][0][k] + red[2][0][k] + red[3][0][k];
         pb[col] = red[0][1][k] + red[1][1][k] + red[2][1][k] + red[3][1][k];
+        if (DXSUM) ps[col] = red[0][2][k] + red[1][2][k] + red[2][2][k] + red[3][2][k];
       }
     }
   }
@@ -187,29 +197,35 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const unsigned short* dy, c
 
 // sums the per-block partials: block = 32 columns x 8 row-lanes, LDS tree over the row-lanes
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* partial, int nblocks, int cols,
-                                                             float* dgamma, float* dbeta) {
-  __shared__ float red[2][8][33];
+                                                             float* dgamma, float* dbeta, float* dxsum) {
+  __shared__ float red[3][8][33];
   const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
   const int col = blockIdx.x * 32 + cx;
-  float sg = 0.f, sb = 0.f;
+  const int nset = dxsum ? 3 : 2;
+  float sg = 0.f, sb = 0.f, ss = 0.f;
   if (col < cols) {
     for (int b = ry; b < nblocks; b += 8) {
-      sg += partial[(long)b * 2 * cols + col];
-      sb += partial[(long)b * 2 * cols + cols + col];
+      const float* pp = partial + (long)b * nset * cols + col;
+      sg += pp[0];
+      sb += pp[cols];
+      if (dxsum) ss += pp[2 * cols];
     }
   }
   red[0][ry][cx] = sg;
   red[1][ry][cx] = sb;
+  red[2][ry][cx] = ss;
   __syncthreads();
   if (ry == 0 && col < cols) {
-    float tg = 0.f, tb = 0.f;
+    float tg = 0.f, tb = 0.f, ts = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       tg += red[0][k][cx];
       tb += red[1][k][cx];
+      ts += red[2][k][cx];
     }
     dgamma[col] += tg;
     dbeta[col] += tb;
+    if (dxsum) dxsum[col] = ts;
   }
 }
 
@@ -232,20 +248,24 @@ extern "C" int wft_layernorm_fwd(const wft_bf16* x, const float* gamma, const fl
 }
 
 extern "C" int64_t wft_layernorm_bwd_workspace(int64_t rows, int cols) {
-  return (int64_t)ln_grid(rows) * 2 * cols * sizeof(float);
+  return (int64_t)ln_grid(rows) * 3 * cols * sizeof(float);
 }
 
 extern "C" int wft_layernorm_bwd(const wft_bf16* dy, const wft_bf16* x, const float* gamma, const float* mean,
                                  const float* rstd, const wft_bf16* dres, wft_bf16* dx, float* dgamma,
-                                 float* dbeta, void* partial, int64_t rows, int cols, int rows_per_batch,
-                                 int t0, int t1, int c0, int c1, void* stream) {
+                                 float* dbeta, float* dx_colsum, void* partial, int64_t rows, int cols,
+                                 int rows_per_batch, int t0, int t1, int c0, int c1, void* stream) {
   WFT_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && partial, "null pointer");
   WFT_CHECK_ARG(rows >= 1 && cols >= 8 && cols % 8 == 0 && cols <= 2048, "cols must be a multiple of 8, <= 2048");
   const int grid = ln_grid(rows);
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean, rstd,
-                     dres, dx, (float*)partial, (long)rows, cols, rows_per_batch, t0, t1, c0, c1);
+  if (dx_colsum)
+    hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean, rstd,
+                       dres, dx, (float*)partial, (long)rows, cols, rows_per_batch, t0, t1, c0, c1);
+  else
+    hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean, rstd,
+                       dres, dx, (float*)partial, (long)rows, cols, rows_per_batch, t0, t1, c0, c1);
   hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((cols + 31) / 32), dim3(256), 0, (hipStream_t)stream,
-                     (const float*)partial, grid, cols, dgamma, dbeta);
+                     (const float*)partial, grid, cols, dgamma, dbeta, dx_colsum);
   WFT_CHECK_LAUNCH();
   return WFT_OK;
 }

@@ -155,8 +155,8 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, mask=None):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, mask=None):
-    """returns dx bf16, dgamma f32, dbeta f32 (fresh, zero-initialised accumulators)."""
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, mask=None, want_colsum=False):
+    """returns dx bf16, dgamma f32, dbeta f32 (fresh, zero-initialised accumulators) [, colsum(dx) f32 if want_colsum]."""
     _chk(dy, BF16, "dy"); _chk(x, BF16, "x")
     dy = dy.contiguous(); x = x.contiguous()
     if dres is not None:
@@ -167,14 +167,17 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, mask=None):
     lib = L.load()
     ws = torch.empty(lib.wft_layernorm_bwd_workspace(rows, cols), dtype=torch.uint8, device=x.device)
     dx = torch.empty_like(x)
-    dgamma = torch.zeros(cols, dtype=F32, device=x.device)
-    dbeta = torch.zeros(cols, dtype=F32, device=x.device)
+    dgb = torch.zeros((2, cols), dtype=F32, device=x.device)  # one fill for both accumulators
+    dgamma, dbeta = dgb[0], dgb[1]
+    dxs = torch.empty(cols, dtype=F32, device=x.device) if want_colsum else None
     rpb, t0, t1, c0, c1 = mask if mask is not None else (0, 0, 0, 0, 0)
     L.check(
         lib.wft_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), _p(dgamma), _p(dbeta),
-                              _p(ws), rows, cols, rpb, t0, t1, c0, c1, L.stream_ptr()),
+                              _p(dxs), _p(ws), rows, cols, rpb, t0, t1, c0, c1, L.stream_ptr()),
         "wft_layernorm_bwd",
     )
+    if want_colsum:
+        return dx, dgamma, dbeta, dxs
     return dx, dgamma, dbeta
 
 
@@ -182,7 +185,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, mask=None):
 def gemm_nt(a, b, *, M=None, N=None, K=None, lda=None, ldb=None, out=None, out_f32=False, accumulate=False,
             bias=None, residual=None, aux=None, epilogue=L.EPI_NONE, alpha=1.0, batch=1,
             strideA=0, strideB=0, strideC=0, strideR=0, strideAux=0, ldc=None,
-            valid_rows_period=0, valid_rows=0, residual_first=False, ldaux=None, ldr=None, beta=1.0):
+            valid_rows_period=0, valid_rows=0, residual_first=False, ldaux=None, ldr=None, beta=1.0, colsum=None):
     """C[M,N] = alpha * A[M,K] @ B[N,K]^T (+bias) (epilogue) (+residual).
 
     a: bf16, row m at a.data_ptr() + m*lda; b: bf16 [N, K] (ldb).  Defaults take the shapes
@@ -222,6 +225,13 @@ def gemm_nt(a, b, *, M=None, N=None, K=None, lda=None, ldb=None, out=None, out_f
     args.M, args.N, args.K, args.batch = M, N, K, batch
     args.valid_rows_period, args.valid_rows = valid_rows_period, valid_rows
     args.residual_first = int(residual_first)
+    if colsum is not None:  # f32 [N]: column sums of C (bias gradient of C's consumer), fused into the epilogue when possible
+        _chk(colsum, F32, "colsum")
+        args.colsum = colsum.data_ptr()
+        need = L.load().wft_gemm_nt_colsum_workspace_bytes(C.byref(args))
+        if need > 0:
+            ws = _tn_workspace(a.device, need, slot="nt_colsum")
+            args.workspace, args.workspace_bytes = ws.data_ptr(), ws.numel()
     if PROFILE_NT is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
@@ -269,10 +279,10 @@ def gemm_tn(a, b, *, P=None, Q=None, R=None, lda=None, ldb=None, out=None, out_f
 _TN_WS = {}
 
 
-def _tn_workspace(device, nbytes: int) -> torch.Tensor:
-    """Per-device scratch for deterministic split-K weight-gradient GEMMs (grown on demand, reused: all
-    launches are ordered on one stream)."""
-    key = (device.type, device.index)
+def _tn_workspace(device, nbytes: int, slot: str = "tn") -> torch.Tensor:
+    """Per-device scratch for deterministic split-K weight-gradient GEMMs / fused column sums (grown on demand,
+    reused: all launches are ordered on one stream)."""
+    key = (device.type, device.index, slot)
     ws = _TN_WS.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)

@@ -34,6 +34,7 @@ class GemmArgs(C.Structure):
         ("residual_first", C.c_int),
         ("workspace", c_vp), ("workspace_bytes", c_i64),
         ("beta", C.c_float), ("reserved0", C.c_int),
+        ("colsum", c_vp),
     ]
 
 
@@ -71,10 +72,11 @@ SIGNATURES = {
     "wft_layernorm_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_float,
                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp],
     "wft_layernorm_bwd_workspace": [c_i64, C.c_int],
-    "wft_layernorm_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int,
+    "wft_layernorm_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int,
                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp],
     "wft_gemm_nt_bf16": [C.POINTER(GemmArgs), c_vp],
     "wft_gemm_nt_variant": [C.POINTER(GemmArgs)],
+    "wft_gemm_nt_colsum_workspace_bytes": [C.POINTER(GemmArgs)],
     "wft_gemm_tn_bf16": [C.POINTER(GemmArgs), c_vp],
     "wft_gemm_tn_workspace_bytes": [C.POINTER(GemmArgs)],
     "wft_attn_fwd_bf16": [C.POINTER(AttnArgs), c_vp],
@@ -100,7 +102,7 @@ SIGNATURES = {
     "wft_version": [],
 }
 _RESTYPES = {"wft_last_error": C.c_char_p, "wft_version": C.c_char_p, "wft_layernorm_bwd_workspace": c_i64,
-             "wft_gemm_tn_workspace_bytes": c_i64}
+             "wft_gemm_tn_workspace_bytes": c_i64, "wft_gemm_nt_colsum_workspace_bytes": c_i64}
 
 _lib = None
 

@@ -216,7 +216,11 @@ class LinearFn(torch.autograd.Function):
         need_dx = ctx.needs_input_grad[0] or (gelu_pre is not None and ctx.needs_input_grad[2])
         if need_dx:  # WT is the EFFECTIVE weight (base + adapters): one GEMM, as without LoRA
             if gelu_pre is not None:
-                dpre = K.gemm_nt(dy, WT, epilogue=L.EPI_DGELU, aux=gelu_pre)
+                # dpre is the dy of the Linear that produced gelu_pre: its bias gradient (column sums) comes out of this
+                # GEMM's epilogue and travels with the tensor (see _fused_colsum)
+                cs = torch.empty(WT.shape[0], dtype=F32, device=dy.device)
+                dpre = K.gemm_nt(dy, WT, epilogue=L.EPI_DGELU, aux=gelu_pre, colsum=cs)
+                dpre._wft_colsum = cs
             else:
                 dx = K.gemm_nt(dy, WT)
         out: List[Optional[torch.Tensor]] = [dx, dy if ctx.has_res else None, dpre, None]
@@ -234,7 +238,9 @@ class LinearFn(torch.autograd.Function):
         # biases
         b_need = [ctx.needs_input_grad[4 + n_w + i] for i in range(nb)]
         if any(b_need):
-            db = K.colsum(dy)
+            db = _fused_colsum(grads[0], dy)
+            if db is None:
+                db = K.colsum(dy)
             off = bi = 0
             for w, hb in zip(weights, cfg.has_bias):
                 if hb:
@@ -274,6 +280,16 @@ class LinearFn(torch.autograd.Function):
             out.extend(dAs)
             out.extend(dBs)
         return tuple(out)
+
+
+def _fused_colsum(grad, dy):
+    """Column sums a producer kernel already formed for exactly this gradient tensor (LayerNorm backward for the
+    residual stream, the DGELU GEMM epilogue for d(pre-activation)); None if autograd handed over a different tensor
+    (accumulated / cast / re-laid-out), in which case the caller falls back to wft_colsum_bf16."""
+    cs = getattr(grad, "_wft_colsum", None)
+    if cs is None or grad.dtype != BF16 or grad.data_ptr() != dy.data_ptr() or cs.numel() != dy.shape[-1]:
+        return None
+    return cs
 
 
 def _bias_list(cfg, params):
@@ -329,9 +345,11 @@ class LayerNormFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, gamma, mean, rstd = ctx.saved_tensors
         shape = x.shape
-        dx, dg, db = K.layernorm_bwd(dy.reshape(-1, shape[-1]).to(BF16), x.reshape(-1, shape[-1]), gamma.detach(), mean,
-                                     rstd, None, ctx.mask)
-        return dx.view(shape), dg, db, None, None
+        dx, dg, db, cs = K.layernorm_bwd(dy.reshape(-1, shape[-1]).to(BF16), x.reshape(-1, shape[-1]), gamma.detach(), mean,
+                                         rstd, None, ctx.mask, want_colsum=True)
+        dx = dx.view(shape)
+        dx._wft_colsum = cs  # dx is the dy of the Linear that wrote x: its bias gradient, for free
+        return dx, dg, db, None, None
 
 
 class LayerNormForkFn(torch.autograd.Function):
@@ -353,9 +371,11 @@ class LayerNormForkFn(torch.autograd.Function):
         if dy is None:
             return dres, None, None, None, None
         dr = None if dres is None else dres.reshape(-1, shape[-1]).to(BF16)
-        dx, dg, db = K.layernorm_bwd(dy.reshape(-1, shape[-1]).to(BF16), x.reshape(-1, shape[-1]), gamma.detach(), mean,
-                                     rstd, dr, ctx.mask)
-        return dx.view(shape), dg, db, None, None
+        dx, dg, db, cs = K.layernorm_bwd(dy.reshape(-1, shape[-1]).to(BF16), x.reshape(-1, shape[-1]), gamma.detach(), mean,
+                                         rstd, dr, ctx.mask, want_colsum=True)
+        dx = dx.view(shape)
+        dx._wft_colsum = cs
+        return dx, dg, db, None, None
 
 
 # --------------------------------------------------------------------------- attention
