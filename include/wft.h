@@ -182,7 +182,7 @@ typedef struct {
   int B; int H; int Tq; int Tk; int causal; float scale;
   /* backward only */
   const wft_bf16* d_o; int64_t lddo; int64_t do_bs;
-  float* delta;                 /* f32 workspace [B, H, Tq]                  */
+  float* delta;                 /* f32 workspace [2, B, H, Tq]: rowsum(dO*O), then lse*log2(e) */
   wft_bf16* dq; int64_t lddq; int64_t dq_bs;
   wft_bf16* dk; int64_t lddk; int64_t dk_bs;
   wft_bf16* dv; int64_t lddv; int64_t dv_bs;

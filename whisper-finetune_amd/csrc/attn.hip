@@ -396,7 +396,9 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnP p) {
       s += bf2f((unsigned short)(a[e] >> 16)) * bf2f((unsigned short)(d[e] >> 16));
     }
   }
-  p.delta[((long)b * p.H + hd) * p.Tq + qi] = s;
+  const long sidx = ((long)b * p.H + hd) * p.Tq + qi;
+  p.delta[sidx] = s;
+  p.delta[total + sidx] = p.lse[sidx] * LOG2E;  // second half of the workspace: lse in log2 units, staged by LDS-DMA in dK/dV
 }
 
 // ------------------------------------------------------------------------------ dQ
@@ -517,9 +519,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
 }
 
 // ------------------------------------------------------------------------------ dK, dV
+// Per 64-query tile the block stages Q, dO (2 x 8 KiB) AND the tile's 64 lse2 / 64 delta values by LDS-DMA
+// (global_load_lds_dword: no VGPR round trip, so no compiler-inserted vmcnt(0) in front of an LDS store — that wait used
+// to drain the prefetch of the next tile at the START of every tile).  Transposed Q^T / dO^T reads are inline asm
+// issued ahead of the S / dP MFMAs of their 32-query half (hipcc drains all LDS-DMA before a ds_read_tr builtin).
 #define DKDV_BUF (16384 + 512)
+__device__ __forceinline__ void glds4(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const WFT_GLB void*)gsrc, (WFT_LDS void*)lds_wave_base, 4, 0, 0);
+}
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
-  // [buf 2][Q 8K | dO 8K | lse 256 B | delta 256 B]
+  // [buf 2][Q 8K | dO 8K | lse2 256 B | delta 256 B]
   __shared__ __attribute__((aligned(16))) char smem[2 * DKDV_BUF];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -531,8 +540,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
   const unsigned short* vrow = p.v + (long)b * p.v_bs + (long)kc * p.ldv + hd * 64;
   const unsigned short* qb = p.q + (long)b * p.q_bs + hd * 64;
   const unsigned short* dob = p.d_o + (long)b * p.do_bs + hd * 64;
-  const float* lse_b = p.lse + ((long)b * p.H + hd) * p.Tq;
-  const float* dlt_b = p.delta + ((long)b * p.H + hd) * p.Tq;
+  const long sbase = ((long)b * p.H + hd) * p.Tq;
+  const float* dlt_b = p.delta + sbase;
+  const float* lse_b = p.delta + (long)p.B * p.H * p.Tq + sbase;  // lse * log2(e), written by attn_delta_kernel
   bf16x8 kf[4], vf[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
@@ -541,6 +551,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
   }
   const AttOffs offs = att_offsets(lane);
   const AttStage stQ = att_stage_init(p.ldq, wave, lane), stDO = att_stage_init(p.lddo, wave, lane);
+  const unsigned lds0 = lds_addr_of(smem);
+  unsigned tra[2][2];
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) tra[db][t] = lds0 + offs.tr[db][t];
   const float c = p.scale * LOG2E;
   const f32x2 c2 = {c, c};
   const int nqt = (p.Tq + 63) >> 6;
@@ -552,12 +568,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
 
   auto stage_q = [&](char* base, int qt) {
     att_stage2(stQ, qb, p.ldq, base, stDO, dob, p.lddo, base + 8192, qt * 64, p.Tq, wave, lane);
-    if (tid < 64) {
-      const int qq = qt * 64 + tid;
-      ((float*)(base + 16384))[tid] = qq < p.Tq ? lse_b[qq] * LOG2E : 0.f;
-    } else if (tid < 128) {
-      const int qq = qt * 64 + tid - 64;
-      ((float*)(base + 16384 + 256))[tid - 64] = qq < p.Tq ? dlt_b[qq] : 0.f;
+    if (wave < 2) {  // wave 0: 64 lse2 values, wave 1: 64 delta values (rows clamped; out-of-range rows are masked later)
+      int qq = qt * 64 + lane;
+      qq = qq < p.Tq ? qq : p.Tq - 1;
+      glds4((wave == 0 ? lse_b : dlt_b) + qq, base + 16384 + wave * 256);
     }
   };
 
@@ -576,6 +590,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
     if (!(p.causal && kw0 > qq0 + 63)) {
 #pragma unroll
       for (int qb2 = 0; qb2 < 2; ++qb2) {
+        // transposed fragments of this 32-query half: in flight under the S / dP MFMAs and the exponentials
+        s16x4 dot[2][2][2], qt_[2][2][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              dot[ks][db][t] = att_tr_asm<CUR * DKDV_BUF + 8192>(tra[db][t] + (2 * qb2 + ks) * 2048);
+              qt_[ks][db][t] = att_tr_asm<CUR * DKDV_BUF>(tra[db][t] + (2 * qb2 + ks) * 2048);
+            }
         f32x16 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_row_frag(q_l, offs, qb2, 0), kf[0], zero16, 0, 0, 0);
         f32x16 pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_row_frag(do_l, offs, qb2, 0), vf[0], zero16, 0, 0, 0);
 #pragma unroll
@@ -597,7 +622,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
               const bool ok = qg < p.Tq && ki < p.Tk && !(p.causal && ki > qg);
               const float pv = ok ? __builtin_amdgcn_exp2f(fmaf(sacc[4 * a + e], c, -l4[e])) : 0.f;
               sacc[4 * a + e] = pv;
-              dsacc[4 * a + e] = pv * (pacc[4 * a + e] - d4[e]);
+              dsacc[4 * a + e] = ok ? pv * (pacc[4 * a + e] - d4[e]) : 0.f;
             }
           } else {
 #pragma unroll
@@ -615,16 +640,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
             }
           }
         }
+        bf16x8 pf[2], dsf[2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          const bf16x8 pf = att_pack8(sacc, ks);
-          const bf16x8 dsf = att_pack8(dsacc, ks);
+          pf[ks] = att_pack8(sacc, ks);
+          dsf[ks] = att_pack8(dsacc, ks);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
           for (int db = 0; db < 2; ++db) {
-            dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_tr_frag(do_l, offs, 2 * qb2 + ks, db), pf, dvacc[db], 0, 0, 0);
-            dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_tr_frag(q_l, offs, 2 * qb2 + ks, db), dsf, dkacc[db], 0, 0, 0);
+            dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_join(dot[ks][db][0], dot[ks][db][1]), pf[ks], dvacc[db], 0, 0, 0);
+            dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_join(qt_[ks][db][0], qt_[ks][db][1]), dsf[ks], dkacc[db], 0, 0, 0);
           }
-        }
       }
     }
     __syncthreads();

@@ -77,10 +77,18 @@ __device__ __forceinline__ float erf_fast(float x) {
 __device__ __forceinline__ float gelu_f(float x) {
   return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f));
 }
+// gelu'(x) = Phi(x) + x phi(x): the exp(-x^2/2) inside erf_fast(x/sqrt2) IS phi's exponential — one v_exp + one v_rcp
 __device__ __forceinline__ float dgelu_f(float x) {
-  const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  const float ax = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);  // exp(-x^2/2) = 2^(-x^2 / (2 ln 2))
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float half_erfc = 0.5f * poly * t * e;                 // 0.5 * (1 - erf(|x|/sqrt2))
+  const float cdf = x >= 0.f ? 1.0f - half_erfc : half_erfc;
+  return fmaf(x, 0.39894228040143267794f * e, cdf);
 }
 
 // async global -> LDS, 16 bytes per lane; LDS destination = wave-uniform base + lane*16

@@ -326,7 +326,7 @@ def attn_bwd(q, k, v, o, lse, do, n_head: int, causal: bool, scale: float, dq=No
     dq = torch.empty((B, Tq, D), dtype=BF16, device=q.device) if dq is None else dq
     dk = torch.empty((B, Tk, D), dtype=BF16, device=q.device) if dk is None else dk
     dv = torch.empty((B, Tk, D), dtype=BF16, device=q.device) if dv is None else dv
-    delta = torch.empty((B, n_head, Tq), dtype=F32, device=q.device)
+    delta = torch.empty((2, B, n_head, Tq), dtype=F32, device=q.device)  # [0] rowsum(dO*O), [1] lse*log2(e)
     a = L.AttnArgs()
     a.q, a.ldq, a.q_bs = _attn_view(q)
     a.k, a.ldk, a.k_bs = _attn_view(k)

@@ -165,6 +165,7 @@ class LinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, residual, gelu_pre, cfg: _LinearCfg, *params):
+        ctx.set_materialize_grads(False)  # no [M, N] zero tensor for the non-differentiable `act` output
         n_w = cfg.n_w
         weights = list(params[:n_w])
         nb = sum(cfg.has_bias)
@@ -358,6 +359,7 @@ class LayerNormForkFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, mask):
+        ctx.set_materialize_grads(False)  # a missing branch gradient arrives as None, not as a zero tensor
         shape = x.shape
         y, mean, rstd = K.layernorm_fwd(x.reshape(-1, shape[-1]), gamma.detach(), beta.detach(), eps, mask)
         ctx.save_for_backward(x, gamma, mean, rstd)
