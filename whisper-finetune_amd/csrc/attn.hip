@@ -15,11 +15,13 @@
 // ONE source-side swizzle (chunk ^= F(row)) that is conflict-free for both the 32-row
 // ds_read_b128 operand reads and the 4-row transposed reads.
 #include "common.h"
+#include <stdlib.h>
 
 #ifndef ATT_PK
 #define ATT_PK 1
 #endif
 #define ATT_NEG (-1.0e30f)
+#define ATT_TAU 8.0f  // lazy-rescale threshold (log2 units)
 #define LOG2E 1.4426950408889634f
 
 struct AttnP {
@@ -214,6 +216,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   const unsigned short* qrow = p.q + (long)b * p.q_bs + (long)qc * p.ldq + hd * 64;
   const unsigned short* kb = p.k + (long)b * p.k_bs + hd * 64;
   const unsigned short* vb = p.v + (long)b * p.v_bs + hd * 64;
+  const float c = p.scale * LOG2E;
   bf16x8 qf[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) qf[s] = att_load_reg_frag(qrow, s, h);
@@ -231,12 +234,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
     const int last = (q0 + 127) / 64 + 1;
     nkt = nkt < last ? nkt : last;
   }
-  const float c = p.scale * LOG2E;
   const f32x16 zero16 = f32x16{0};
   f32x16 oacc[2];
   oacc[0] = zero16;
   oacc[1] = zero16;
-  float m = ATT_NEG, l = 0.f;
+  // Lazy rescaling: `m` is a STALE running maximum (raw q.k units) that enters the S MFMA chains as their initial
+  // accumulator (minit = -m in every register: S' = S - m costs no VALU), and is only raised when a tile's maximum exceeds
+  // it by more than ATT_TAU in log2 units (P <= 2^ATT_TAU is exact in bf16's exponent range; l is fp32).  Most tiles then
+  // skip the subtraction, the O rescale and the alpha exponential: the kernel is VALU-issue-bound (v_exp_f32 8 cycles,
+  // everything else 4).  Same sums as the eager form up to fp32 rounding of l and O.
+  float m = 0.f, l = 0.f;
+  f32x16 minit = zero16;
 
   att_stage2(stK, kb, p.ldk, smem, stV, vb, p.ldv, smem + 8192, 0, p.Tk, wave, lane);
   if (nkt > 1) {
@@ -274,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
       f32x16 sacc[2];
 #pragma unroll
       for (int kb2 = 0; kb2 < 2; ++kb2) {
-        sacc[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb2][0], qf[0], zero16, 0, 0, 0);
+        sacc[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb2][0], qf[0], minit, 0, 0, 0);
 #pragma unroll
         for (int s = 1; s < 4; ++s) sacc[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb2][s], qf[s], sacc[kb2], 0, 0, 0);
       }
@@ -287,45 +295,37 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
           for (int e = 0; e < 16; ++e)
             sacc[kb2][e] = (32 * kb2 + (e & 3) + 8 * (e >> 2)) < lim ? sacc[kb2][e] : ATT_NEG;
       }
-      const float mnew = att_max2(m, att_xhalf_max(att_max32(sacc[0], sacc[1])));
-      const float alpha = __builtin_amdgcn_exp2f((m - mnew) * c);
-      // packed fp32 math (v_pk_fma_f32 / v_pk_add_f32): the softmax is the VALU-heavy part of this kernel
-#if ATT_PK
-      const f32x2 c2 = {c, c}, mc2 = {mnew * c, mnew * c};
-      f32x2 ls2 = {0.f, 0.f};
+      const float tmax = att_xhalf_max(att_max32(sacc[0], sacc[1]));  // max over the tile of S - m
+      if (kt == 0 || __builtin_amdgcn_ballot_w64(tmax * c > ATT_TAU) != 0) {
+        // rare path: move the reference maximum (first tile: to the tile's own maximum, whatever its sign)
+        const float d = kt == 0 ? tmax : fmaxf(tmax, 0.f);
+        const float alpha = __builtin_amdgcn_exp2f(-d * c);
+        m += d;
+        l *= alpha;
 #pragma unroll
-      for (int kb2 = 0; kb2 < 2; ++kb2)
+        for (int kb2 = 0; kb2 < 2; ++kb2)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          f32x2 t2 = {sacc[kb2][2 * e], sacc[kb2][2 * e + 1]};
-          t2 = t2 * c2 - mc2;
-          f32x2 p2 = {__builtin_amdgcn_exp2f(t2[0]), __builtin_amdgcn_exp2f(t2[1])};
-          ls2 += p2;
-          sacc[kb2][2 * e] = p2[0];
-          sacc[kb2][2 * e + 1] = p2[1];
-        }
-      l = l * alpha + att_xhalf_sum(ls2[0] + ls2[1]);
-#else
-      const float mc = mnew * c;
+          for (int e = 0; e < 16; ++e) sacc[kb2][e] -= d;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) oacc[db][e] *= alpha;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) minit[e] = -m;
+      }
       float ls0 = 0.f, ls1 = 0.f;
 #pragma unroll
       for (int kb2 = 0; kb2 < 2; ++kb2)
 #pragma unroll
         for (int e = 0; e < 16; e += 2) {
-          const float p0 = __builtin_amdgcn_exp2f(fmaf(sacc[kb2][e], c, -mc));
-          const float p1 = __builtin_amdgcn_exp2f(fmaf(sacc[kb2][e + 1], c, -mc));
+          const float p0 = __builtin_amdgcn_exp2f(sacc[kb2][e] * c);
+          const float p1 = __builtin_amdgcn_exp2f(sacc[kb2][e + 1] * c);
           ls0 += p0;
           ls1 += p1;
           sacc[kb2][e] = p0;
           sacc[kb2][e + 1] = p1;
         }
-      l = l * alpha + att_xhalf_sum(ls0 + ls1);
-#endif
-      m = mnew;
-#pragma unroll
-      for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) oacc[db][e] *= alpha;
+      l += att_xhalf_sum(ls0 + ls1);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) pf[ks] = att_pack8(sacc[ks >> 1], ks & 1);
     }
