@@ -58,6 +58,29 @@ def lora_flops_per_clip(d, S: int, r: int) -> float:
     return enc + dec
 
 
+def pmc_traffic_per_launch(batch: int):
+    """HBM bytes per gemm_nt256_kernel launch from the committed rocprofv3 PMC passes of THIS command
+    (profiles/collect_r01.sh: --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, the only tracing next to them
+    being --kernel-trace).  FETCH_SIZE is in KiB and counts 64 B per 128-B request on gfx950 for 16-B/lane streaming
+    reads, so it is doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE (KiB) is exact.  Counters cannot be
+    collected inside the timed run, so the value is only reported when the committed pass used the same batch."""
+    path = ROOT / "profiles" / "r01_c_pmc_summary.json"
+    if not path.exists():
+        return None, "no PMC summary committed"
+    d = json.loads(path.read_text())
+    if d.get("batch", 68) != batch:
+        return None, f"PMC pass was collected at batch {d.get('batch', 68)}"
+    tot = n = 0.0
+    for k, v in d["FETCH_SIZE"].items():
+        if "gemm_nt256_kernel" in k:
+            w = d["WRITE_SIZE"][k]
+            tot += (2.0 * v["sum"] + w["sum"]) * 1024.0
+            n += v["launches"]
+    if n == 0:
+        return None, "kernel not in the PMC summary"
+    return round(tot / n), "profiles/r01_c_pmc_summary.json: (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch, separate --pmc passes"
+
+
 def build_model(name: str, device, sd_p: float = 0.0):
     from whisper_finetune.engine.whisper_model import MODEL_DIMS, Whisper, sinusoids
 
@@ -220,15 +243,17 @@ def main():
         step()
         torch.cuda.synchronize()
         recs, K.PROFILE_NT = K.PROFILE_NT, None
-        big = [(s_.elapsed_time(e_), f) for s_, e_, f, v in recs if v == 256]  # gemm_nt256_kernel launches
-        ms = sum(t for t, _ in big)
-        flops = sum(f for _, f in big)
-        all_ms = sum(s_.elapsed_time(e_) for s_, e_, _, _ in recs)
-        all_fl = sum(f for _, _, f, _ in recs)
+        big = [(s_.elapsed_time(e_), f, nb) for s_, e_, f, v, nb in recs if v == 256]  # gemm_nt256_kernel launches
+        ms = sum(t for t, _, _ in big)
+        flops = sum(f for _, f, _ in big)
+        all_ms = sum(s_.elapsed_time(e_) for s_, e_, _, _, _ in recs)
+        all_fl = sum(f for _, _, f, _, _ in recs)
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        traffic, traffic_note = pmc_traffic_per_launch(B)
         roofline = {
             "kernel": "gemm_nt256_kernel", "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
+            "algorithmic_bytes_per_launch_avg": round(sum(nb for _, _, nb in big) / max(len(big), 1)),
             "launches": len(big), "avg_launch_us": round(ms * 1e3 / max(len(big), 1), 2),
             "flops_per_launch_avg": round(flops / max(len(big), 1)),
             "all_nt_gemm_launches": len(recs), "all_nt_gemm_tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 1) if all_ms > 0 else 0.0,

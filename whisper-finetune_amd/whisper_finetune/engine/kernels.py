@@ -16,7 +16,7 @@ BF16 = torch.bfloat16
 F32 = torch.float32
 
 # bench.py sets this to a list to time every gemm_nt launch with HIP events recorded on the
-# launch stream: entries are (start_event, end_event, algorithmic_flops).
+# launch stream: entries are (start_event, end_event, algorithmic_flops, kernel variant 128|256, algorithmic_bytes).
 PROFILE_NT = None
 
 
@@ -237,7 +237,8 @@ def gemm_nt(a, b, *, M=None, N=None, K=None, lda=None, ldb=None, out=None, out_f
         ev0.record()
         L.check(L.load().wft_gemm_nt_bf16(C.byref(args), L.stream_ptr()), "wft_gemm_nt_bf16")
         ev1.record()
-        PROFILE_NT.append((ev0, ev1, 2.0 * M * N * K * batch, L.load().wft_gemm_nt_variant(C.byref(args))))
+        nbytes = 2.0 * batch * (M * K + N * K + M * N * (2 if out_f32 else 1) + (M * N if residual is not None else 0) + (M * N if aux is not None else 0))
+        PROFILE_NT.append((ev0, ev1, 2.0 * M * N * K * batch, L.load().wft_gemm_nt_variant(C.byref(args)), nbytes))
         return out
     L.check(L.load().wft_gemm_nt_bf16(C.byref(args), L.stream_ptr()), "wft_gemm_nt_bf16")
     return out

@@ -218,10 +218,10 @@ class LinearFn(torch.autograd.Function):
         if need_dx:  # WT is the EFFECTIVE weight (base + adapters): one GEMM, as without LoRA
             if gelu_pre is not None:
                 # dpre is the dy of the Linear that produced gelu_pre: its bias gradient (column sums) comes out of this
-                # GEMM's epilogue and travels with the tensor (see _fused_colsum)
+                # GEMM's epilogue (see _publish_colsum / _fused_colsum)
                 cs = torch.empty(WT.shape[0], dtype=F32, device=dy.device)
                 dpre = K.gemm_nt(dy, WT, epilogue=L.EPI_DGELU, aux=gelu_pre, colsum=cs)
-                dpre._wft_colsum = cs
+                _publish_colsum(dpre, cs)
             else:
                 dx = K.gemm_nt(dy, WT)
         out: List[Optional[torch.Tensor]] = [dx, dy if ctx.has_res else None, dpre, None]
@@ -283,12 +283,32 @@ class LinearFn(torch.autograd.Function):
         return tuple(out)
 
 
+_COLSUMS = {}  # data_ptr -> (producing tensor, colsum)
+
+
+def reset_colsums() -> None:
+    """Drop unconsumed entries (called at the start of every forward and of every backward pass)."""
+    _COLSUMS.clear()
+
+
+def _publish_colsum(t: torch.Tensor, cs: torch.Tensor) -> None:
+    """Remember that `cs` holds the column sums of `t`, a gradient tensor a libwft kernel just wrote.  Autograd hands
+    the consumer a VIEW of t (reshape nodes between modules), so the link is by address.  The entry keeps `t` itself
+    alive until it is consumed or the next pass starts: its storage therefore cannot be recycled for other data, and a
+    consumer tensor with the same address, storage and element count IS this data."""
+    _COLSUMS[t.data_ptr()] = (t, cs)
+
+
 def _fused_colsum(grad, dy):
-    """Column sums a producer kernel already formed for exactly this gradient tensor (LayerNorm backward for the
-    residual stream, the DGELU GEMM epilogue for d(pre-activation)); None if autograd handed over a different tensor
-    (accumulated / cast / re-laid-out), in which case the caller falls back to wft_colsum_bf16."""
-    cs = getattr(grad, "_wft_colsum", None)
-    if cs is None or grad.dtype != BF16 or grad.data_ptr() != dy.data_ptr() or cs.numel() != dy.shape[-1]:
+    """Column sums a producer kernel already formed for exactly this gradient (LayerNorm backward for the residual
+    stream, the DGELU GEMM epilogue for d(pre-activation)); None if autograd handed over different data (accumulated /
+    cast / re-laid-out), in which case the caller falls back to wft_colsum_bf16."""
+    ent = _COLSUMS.pop(dy.data_ptr(), None)
+    if ent is None:
+        return None
+    t, cs = ent
+    if (grad.dtype != BF16 or t.numel() != dy.numel() or cs.numel() != dy.shape[-1] or not dy.is_contiguous()
+            or t.untyped_storage().data_ptr() != dy.untyped_storage().data_ptr()):
         return None
     return cs
 
@@ -349,7 +369,7 @@ class LayerNormFn(torch.autograd.Function):
         dx, dg, db, cs = K.layernorm_bwd(dy.reshape(-1, shape[-1]).to(BF16), x.reshape(-1, shape[-1]), gamma.detach(), mean,
                                          rstd, None, ctx.mask, want_colsum=True)
         dx = dx.view(shape)
-        dx._wft_colsum = cs  # dx is the dy of the Linear that wrote x: its bias gradient, for free
+        _publish_colsum(dx, cs)  # dx is the dy of the Linear that wrote x: its bias gradient, for free
         return dx, dg, db, None, None
 
 
@@ -376,7 +396,7 @@ class LayerNormForkFn(torch.autograd.Function):
         dx, dg, db, cs = K.layernorm_bwd(dy.reshape(-1, shape[-1]).to(BF16), x.reshape(-1, shape[-1]), gamma.detach(), mean,
                                          rstd, dr, ctx.mask, want_colsum=True)
         dx = dx.view(shape)
-        dx._wft_colsum = cs
+        _publish_colsum(dx, cs)
         return dx, dg, db, None, None
 
 
@@ -563,6 +583,7 @@ class FusedCEFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        reset_colsums()  # a new backward pass starts here
         logits, targets, row_lse, stats = ctx.saved_tensors
         V, eps = ctx.cfg
         dl = K.ce_bwd(logits, targets, V, eps, row_lse, stats, g, inplace=True)

@@ -303,6 +303,7 @@ class Whisper(nn.Module):
     def forward(self, mel: Tensor, tokens: Tensor, targets: Optional[Tensor] = None, label_smoothing: float = 0.0) -> Tensor:
         """logits f32 [B, S, V] — or, when `targets` is given (engine extension used by train_step, also
         through a DDP wrapper), the fused label-smoothed cross-entropy loss."""
+        ops.reset_colsums()  # stale fused bias-gradient entries of an earlier backward pass (engine/ops.py)
         if targets is not None:
             return self.forward_loss(mel, tokens, targets, label_smoothing)
         return self.decoder(tokens, self.encoder(mel))
