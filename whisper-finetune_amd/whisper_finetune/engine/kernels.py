@@ -534,8 +534,8 @@ def muon_group_step(params, grads, bufs, lr, wd, momentum, nesterov=True, ns_ste
     flat = []
     for row in (params, grads, bufs):
         for t in row:
-            if t.dtype != F32 or not t.is_contiguous() or t.shape != (rows, cols):
-                raise L.WftError("muon_group_step needs contiguous f32 tensors of one shape")
+            if t.dtype != F32 or not t.is_contiguous() or t.shape != (rows, cols) or not t.is_cuda:
+                raise L.WftError("muon_group_step needs contiguous f32 HIP tensors of one shape (there is no CPU path)")
             flat.append(t.data_ptr())
     tab = torch.tensor(flat, dtype=torch.int64, device=dev)
     U = torch.empty((n, rows, cols), dtype=BF16, device=dev)

@@ -260,7 +260,9 @@ def get_optimizer(model, optimizer_conf: Dict, is_lora_run: bool = False):
     if "betas" in kw:
         kw["betas"] = tuple(kw["betas"])
     on_gpu = bool(params) and params[0].is_cuda
-    if kind == "adamw" and optimizer_conf.get("wft", False):
+    # AdamW on HIP tensors runs in libwft (one launch per step, clip folded in) unless optimizer.wft: false asks for torch's
+    if kind == "adamw" and optimizer_conf.get("wft", on_gpu) and not kw.get("amsgrad", False):
+        kw.pop("amsgrad", None)
         return WftAdamW(params, **kw)
     if kind == "adam":
         return torch.optim.Adam(params, **kw, **({"fused": True} if on_gpu else {}))
