@@ -833,8 +833,11 @@ __global__ __launch_bounds__(256) void tn_splitk_reduce_kernel(const float* ws, 
 
 // ---------------------------------------------------------------------------------- host
 static int g_diag = 0;
+// dispatch thresholds, measured at M = R = 4096 and 8704 (decoder-sized problems; tests/dev_small_gemm.py): the 256x256 kernels win once
+// they can occupy half of the CUs (NT: >= 128 tiles) / have >= 50 output tiles to split (TN).  Tunable: WFT_NT256_MIN_TILES, WFT_TN256_MIN_STEPS.
+static int g_nt256_min_tiles = 128, g_tn256_min_steps = 64;
 static bool g_force_128 = false;  // debugging / A-B switch: WFT_GEMM_FORCE_128=1
-static struct EnvInit { EnvInit() { const char* e = getenv("WFT_GEMM_FORCE_128"); g_force_128 = e && e[0] == '1'; const char* d = getenv("WFT_GEMM_DIAG"); g_diag = d ? atoi(d) : 0; } } g_env_init;
+static struct EnvInit { EnvInit() { const char* e = getenv("WFT_GEMM_FORCE_128"); g_force_128 = e && e[0] == '1'; const char* d = getenv("WFT_GEMM_DIAG"); g_diag = d ? atoi(d) : 0; const char* t1 = getenv("WFT_NT256_MIN_TILES"); if (t1) g_nt256_min_tiles = atoi(t1); const char* t2 = getenv("WFT_TN256_MIN_STEPS"); if (t2) g_tn256_min_steps = atoi(t2); } } g_env_init;
 
 static int fill_params(const wft_gemm_args* a, GemmP& p) {
   p.A = a->A; p.lda = a->lda; p.sA = a->strideA;
@@ -888,7 +891,7 @@ static bool nt_uses_256(const wft_gemm_args* a) {
                                        (!a->aux || (a->ldaux % 8 == 0 && ((uintptr_t)a->aux & 15) == 0)) &&
                                        (!a->bias || ((uintptr_t)a->bias & 15) == 0));
   return !g_force_128 && wide_ok && a->N % 256 == 0 && a->M >= 1024 &&
-         ((a->M + 255) / 256) * (a->N / 256) * a->batch >= 192;
+         ((a->M + 255) / 256) * (a->N / 256) * a->batch >= g_nt256_min_tiles;
 }
 extern "C" int wft_gemm_nt_variant(const wft_gemm_args* a) { return a && nt_uses_256(a) ? 256 : 128; }
 
@@ -973,7 +976,8 @@ extern "C" int wft_gemm_nt_bf16(const wft_gemm_args* a, void* stream) {
 
 static bool tn_uses_256(const wft_gemm_args* a) {
   const long nsteps = ((a->K + 63) / 64) * a->batch;
-  return !g_force_128 && a->c_is_f32 && a->M % 256 == 0 && a->N % 256 == 0 && nsteps >= 256;
+  return !g_force_128 && a->c_is_f32 && a->M % 256 == 0 && a->N % 256 == 0 && nsteps >= g_tn256_min_steps &&
+         (nsteps >= 256 || (a->M / 256) * (a->N / 256) >= 50);
 }
 static int tn256_nsplit(const wft_gemm_args* a) {
   const long t256 = (a->M / 256) * (a->N / 256);
