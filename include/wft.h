@@ -186,9 +186,14 @@ typedef struct {
   wft_bf16* dq; int64_t lddq; int64_t dq_bs;
   wft_bf16* dk; int64_t lddk; int64_t dk_bs;
   wft_bf16* dv; int64_t lddv; int64_t dv_bs;
+  /* optional (backward): bias gradients of the q and v projections formed in the kernels' epilogues instead of a
+   * second pass over dq / dv.  dq_colsum / dv_colsum: f32 [H*64] outputs (sum over batch and time of the bf16 values
+   * written); colsum_ws: f32 scratch of wft_attn_bwd_colsum_workspace_bytes(args) bytes.  All three or none.      */
+  float* dq_colsum; float* dv_colsum; float* colsum_ws;
 } wft_attn_args;
 int wft_attn_fwd_bf16(const wft_attn_args* args, void* stream);
 int wft_attn_bwd_bf16(const wft_attn_args* args, void* stream);
+int64_t wft_attn_bwd_colsum_workspace_bytes(const wft_attn_args* args);
 
 /* -------------------------------------------------------------- Embedding */
 /* TextDecoder: x = token_embedding(tokens) + positional_embedding[:S]

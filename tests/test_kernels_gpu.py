@@ -372,3 +372,21 @@ def test_fused_bias_gradient_column_sums():
         assert torch.equal(c, c0)
         want = c.float().sum(0)
         assert (cs - want).abs().max() < 4e-3 * want.abs().max() + 1e-2  # fused sums are of the un-rounded fp32 values
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk,causal", [(2, 3, 1500, 1500, False), (2, 2, 130, 130, True), (1, 2, 50, 333, False)])
+def test_attention_backward_fused_projection_bias_sums(B, H, Tq, Tk, causal):
+    """dq_colsum / dv_colsum of wft_attn_bwd_bf16 = column sums of the bf16 dq / dv it wrote (ragged last 32-row groups,
+    waves beyond T, causal early exit)."""
+    D = H * 64
+    g = torch.Generator().manual_seed(B + Tq)
+    q = bf(torch.randn(B, Tq, D, generator=g)).to(DEV); k = bf(torch.randn(B, Tk, D, generator=g)).to(DEV)
+    v = bf(torch.randn(B, Tk, D, generator=g)).to(DEV); do = bf(torch.randn(B, Tq, D, generator=g)).to(DEV)
+    o, lse = K.attn_fwd(q, k, v, H, causal, 0.125)
+    cs_q = torch.full((D,), 7.0, device=DEV); cs_v = torch.full((D,), 7.0, device=DEV)
+    dq, dk, dv = K.attn_bwd(q, k, v, o, lse, do, H, causal, 0.125, colsums=(cs_q, cs_v))
+    dq0, dk0, dv0 = K.attn_bwd(q, k, v, o, lse, do, H, causal, 0.125)
+    assert torch.equal(dq, dq0) and torch.equal(dk, dk0) and torch.equal(dv, dv0)
+    for got, full in ((cs_q, dq), (cs_v, dv)):
+        want = full.float().sum((0, 1))
+        assert (got - want).abs().max() < 2e-4 * want.abs().max() + 1e-3

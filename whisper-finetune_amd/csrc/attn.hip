@@ -37,6 +37,8 @@ struct AttnP {
   unsigned short* dq; long lddq, dq_bs;
   unsigned short* dk; long lddk, dk_bs;
   unsigned short* dv; long lddv, dv_bs;
+  float* cs_q;  // [B * ceil(Tq/32)][H*64] per-wave column sums of dq (or NULL)
+  float* cs_v;  // [B * ceil(Tk/32)][H*64] per-wave column sums of dv (or NULL)
 };
 
 __device__ __forceinline__ int att_F(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
@@ -194,6 +196,21 @@ __device__ __forceinline__ float att_xhalf_sum(float v) {
   float a, b;
   att_xhalf(v, a, b);
   return a + b;
+}
+
+// Column sums (over the 32 rows = lanes of one half-wave pair) of a [64 d][32 rows] accumulator pair whose values were
+// just rounded to bf16 for the store: acc[db][4a+e] belongs to column d = 32 db + 8 a + 4 h + e.  Rows >= nvalid are
+// excluded.  Result: lanes r == 0 (h = 0, 1) write 32 floats each to dst[d].
+__device__ __forceinline__ void att_colsum_store(const f32x16 (&acc)[2], float mul, bool row_valid, int r, int h, float* dst) {
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float v = row_valid ? bf2f(f2bf(acc[db][i] * mul)) : 0.f;
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);  // xor masks < 32 stay inside the half-wave
+      if (r == 0) dst[32 * db + 8 * (i >> 2) + 4 * h + (i & 3)] = v;
+    }
 }
 
 template <int V>
@@ -516,6 +533,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
         *(u32x2*)(drow + d) = pk;
       }
   }
+  if (p.cs_q && qw0 < p.Tq)  // q-projection bias gradient: this wave's 32 queries, summed per head column
+    att_colsum_store(dqacc, p.scale, qi < p.Tq, r, h,
+                     p.cs_q + ((long)b * ((p.Tq + 31) >> 5) + (qw0 >> 5)) * (p.H * 64) + hd * 64);
 }
 
 // ------------------------------------------------------------------------------ dK, dV
@@ -682,6 +702,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
         *(u32x2*)(dvrow + d) = pv;
       }
   }
+  if (p.cs_v && kw0 < p.Tk)  // v-projection bias gradient
+    att_colsum_store(dvacc, 1.0f, ki < p.Tk, r, h, p.cs_v + ((long)b * ((p.Tk + 31) >> 5) + (kw0 >> 5)) * (p.H * 64) + hd * 64);
 }
 
 // ------------------------------------------------------------------------------ host
@@ -698,6 +720,7 @@ static int attn_fill(const wft_attn_args* a, AttnP& p) {
   p.dq = a->dq; p.lddq = a->lddq; p.dq_bs = a->dq_bs;
   p.dk = a->dk; p.lddk = a->lddk; p.dk_bs = a->dk_bs;
   p.dv = a->dv; p.lddv = a->lddv; p.dv_bs = a->dv_bs;
+  p.cs_q = nullptr; p.cs_v = nullptr;
   return 0;
 }
 
@@ -718,6 +741,29 @@ extern "C" int wft_attn_fwd_bf16(const wft_attn_args* a, void* stream) {
   return WFT_OK;
 }
 
+// out[chunk][col] = sum over this chunk's partial rows (fixed order).  64 columns per workgroup (256-byte row segments),
+// 4 waves stride the rows; gridDim.y row chunks.  Run twice: [nrows] -> [ATT_CS_CHUNKS] -> [1].
+#define ATT_CS_CHUNKS 32
+__global__ __launch_bounds__(256) void attn_colsum_reduce_kernel(const float* partial, long nrows, int n, float* out) {
+  __shared__ float red[4][64];
+  const int cx = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cx;
+  const long per = (nrows + gridDim.y - 1) / gridDim.y;
+  const long r0 = (long)blockIdx.y * per;
+  const long r1 = r0 + per < nrows ? r0 + per : nrows;
+  float sacc = 0.f;
+  if (col < n)
+    for (long rr = r0 + wv; rr < r1; rr += 4) sacc += partial[rr * n + col];
+  red[wv][cx] = sacc;
+  __syncthreads();
+  if (wv == 0 && col < n) out[(long)blockIdx.y * n + col] = red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx];
+}
+
+extern "C" int64_t wft_attn_bwd_colsum_workspace_bytes(const wft_attn_args* a) {
+  if (!a) return 0;
+  return ((int64_t)a->B * ((a->Tq + 31) / 32) + (int64_t)a->B * ((a->Tk + 31) / 32) + 2 * ATT_CS_CHUNKS) * a->H * 64 * (int64_t)sizeof(float);
+}
+
 extern "C" int wft_attn_bwd_bf16(const wft_attn_args* a, void* stream) {
   WFT_CHECK_ARG(a && a->q && a->k && a->v && a->o && a->lse && a->d_o && a->delta && a->dq && a->dk && a->dv,
                 "null pointer");
@@ -728,13 +774,30 @@ extern "C" int wft_attn_bwd_bf16(const wft_attn_args* a, void* stream) {
                     ATT_ALIGNED(a->dk, a->lddk, a->dk_bs) && ATT_ALIGNED(a->dv, a->lddv, a->dv_bs),
                 "tensors need 16-byte aligned bases and strides that are multiples of 8");
   WFT_CHECK_ARG(!a->causal || a->Tq == a->Tk, "causal attention needs Tq == Tk");
+  WFT_CHECK_ARG((!a->dq_colsum && !a->dv_colsum && !a->colsum_ws) || (a->dq_colsum && a->dv_colsum && a->colsum_ws),
+                "dq_colsum, dv_colsum and colsum_ws go together");
   AttnP p;
   attn_fill(a, p);
+  if (a->colsum_ws) {
+    p.cs_q = a->colsum_ws;
+    p.cs_v = a->colsum_ws + (long)a->B * ((a->Tq + 31) / 32) * a->H * 64;
+  }
   hipStream_t s = (hipStream_t)stream;
   const long total = (long)a->B * a->Tq * a->H;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((a->Tq + 127) / 128, a->H, a->B), dim3(256), 0, s, p);
   hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3((a->Tk + 127) / 128, a->H, a->B), dim3(256), 0, s, p);
+  if (p.cs_q) {
+    const int n = a->H * 64;
+    const long rq = (long)a->B * ((a->Tq + 31) / 32), rk = (long)a->B * ((a->Tk + 31) / 32);
+    float* mid_q = p.cs_v + rk * n;
+    float* mid_v = mid_q + (long)ATT_CS_CHUNKS * n;
+    const dim3 g1((n + 63) / 64, ATT_CS_CHUNKS), g2((n + 63) / 64, 1);
+    hipLaunchKernelGGL(attn_colsum_reduce_kernel, g1, dim3(256), 0, s, (const float*)p.cs_q, rq, n, mid_q);
+    hipLaunchKernelGGL(attn_colsum_reduce_kernel, g1, dim3(256), 0, s, (const float*)p.cs_v, rk, n, mid_v);
+    hipLaunchKernelGGL(attn_colsum_reduce_kernel, g2, dim3(256), 0, s, (const float*)mid_q, (long)ATT_CS_CHUNKS, n, a->dq_colsum);
+    hipLaunchKernelGGL(attn_colsum_reduce_kernel, g2, dim3(256), 0, s, (const float*)mid_v, (long)ATT_CS_CHUNKS, n, a->dv_colsum);
+  }
   WFT_CHECK_LAUNCH();
   return WFT_OK;
 }

@@ -318,7 +318,8 @@ def attn_fwd(q, k, v, n_head: int, causal: bool, scale: float):
     return o, lse
 
 
-def attn_bwd(q, k, v, o, lse, do, n_head: int, causal: bool, scale: float, dq=None, dk=None, dv=None):
+def attn_bwd(q, k, v, o, lse, do, n_head: int, causal: bool, scale: float, dq=None, dk=None, dv=None, colsums=None):
+    """colsums = (cs_q, cs_v): optional f32 [H*64] outputs, the column sums over (batch, time) of dq / dv (bias gradients)."""
     B, Tq, D = q.shape
     Tk = k.shape[1]
     _chk(do, BF16, "do")
@@ -340,6 +341,12 @@ def attn_bwd(q, k, v, o, lse, do, n_head: int, causal: bool, scale: float, dq=No
     a.dq, a.lddq, a.dq_bs = _attn_view(dq)
     a.dk, a.lddk, a.dk_bs = _attn_view(dk)
     a.dv, a.lddv, a.dv_bs = _attn_view(dv)
+    if colsums is not None:
+        cs_q, cs_v = colsums
+        _chk(cs_q, F32, "cs_q"); _chk(cs_v, F32, "cs_v")
+        assert cs_q.numel() == D and cs_v.numel() == D and cs_q.is_contiguous() and cs_v.is_contiguous()
+        ws = _tn_workspace(q.device, L.load().wft_attn_bwd_colsum_workspace_bytes(C.byref(a)), slot="attn_colsum")
+        a.dq_colsum, a.dv_colsum, a.colsum_ws = cs_q.data_ptr(), cs_v.data_ptr(), ws.data_ptr()
     L.check(L.load().wft_attn_bwd_bf16(C.byref(a), L.stream_ptr()), "wft_attn_bwd_bf16")
     return dq, dk, dv
 

@@ -53,6 +53,7 @@ class AttnArgs(C.Structure):
         ("dq", c_vp), ("lddq", c_i64), ("dq_bs", c_i64),
         ("dk", c_vp), ("lddk", c_i64), ("dk_bs", c_i64),
         ("dv", c_vp), ("lddv", c_i64), ("dv_bs", c_i64),
+        ("dq_colsum", c_vp), ("dv_colsum", c_vp), ("colsum_ws", c_vp),
     ]
 
 
@@ -81,6 +82,7 @@ SIGNATURES = {
     "wft_gemm_tn_workspace_bytes": [C.POINTER(GemmArgs)],
     "wft_attn_fwd_bf16": [C.POINTER(AttnArgs), c_vp],
     "wft_attn_bwd_bf16": [C.POINTER(AttnArgs), c_vp],
+    "wft_attn_bwd_colsum_workspace_bytes": [C.POINTER(AttnArgs)],
     "wft_embed_fwd": [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, C.c_int, c_i64, c_vp],
     "wft_embed_bwd": [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, C.c_int, c_i64, c_vp],
     "wft_ce_fwd": [c_vp, c_i64, c_vp, c_i64, c_i64, C.c_float, c_vp, c_vp, c_vp, c_vp, c_vp],
@@ -102,7 +104,8 @@ SIGNATURES = {
     "wft_version": [],
 }
 _RESTYPES = {"wft_last_error": C.c_char_p, "wft_version": C.c_char_p, "wft_layernorm_bwd_workspace": c_i64,
-             "wft_gemm_tn_workspace_bytes": c_i64, "wft_gemm_nt_colsum_workspace_bytes": c_i64}
+             "wft_gemm_tn_workspace_bytes": c_i64, "wft_gemm_nt_colsum_workspace_bytes": c_i64,
+             "wft_attn_bwd_colsum_workspace_bytes": c_i64}
 
 _lib = None
 

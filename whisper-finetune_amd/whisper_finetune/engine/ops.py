@@ -284,6 +284,9 @@ class LinearFn(torch.autograd.Function):
 
 
 _COLSUMS = {}  # data_ptr -> (producing tensor, colsum)
+# whisper's key projection has no bias; a model that gives it one (not whisper) must set this so that the fused q/k/v column
+# sums (which leave the k slice at zero) are not used for it
+_K_HAS_BIAS = [False]
 
 
 def reset_colsums() -> None:
@@ -420,8 +423,11 @@ class SelfAttnFn(torch.autograd.Function):
         n_head, causal, scale = ctx.cfg
         d = qkv.shape[-1] // 3
         dqkv = torch.empty_like(qkv)
+        cs = torch.zeros(3 * d, dtype=F32, device=qkv.device)  # [q | k (no bias in whisper: stays 0) | v]
         K.attn_bwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], o, lse, do.to(BF16), n_head, causal, scale,
-                   dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:])
+                   dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:], colsums=(cs[:d], cs[2 * d:]))
+        if not _K_HAS_BIAS[0]:
+            _publish_colsum(dqkv, cs)  # bias gradients of the fused q/k/v projection, summed in the kernels' epilogues
         return dqkv, None, None
 
 
@@ -444,7 +450,13 @@ class CrossAttnFn(torch.autograd.Function):
         d = q.shape[-1]
         dq = torch.empty_like(q)
         dkv = torch.empty_like(kv)
-        K.attn_bwd(q, kv[..., :d], kv[..., d:], o, lse, do.to(BF16), n_head, False, scale, dq=dq, dk=dkv[..., :d], dv=dkv[..., d:])
+        cs_q = torch.empty(d, dtype=F32, device=q.device)
+        cs_kv = torch.zeros(2 * d, dtype=F32, device=q.device)  # [k (no bias) | v]
+        K.attn_bwd(q, kv[..., :d], kv[..., d:], o, lse, do.to(BF16), n_head, False, scale, dq=dq, dk=dkv[..., :d], dv=dkv[..., d:],
+                   colsums=(cs_q, cs_kv[d:]))
+        _publish_colsum(dq, cs_q)
+        if not _K_HAS_BIAS[0]:
+            _publish_colsum(dkv, cs_kv)
         return dq, dkv, None
 
 
