@@ -91,21 +91,22 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const unsigned short* x, co
 // backward: each wave walks rows (grid-stride), keeps per-lane dgamma/dbeta partials for its
 // columns, then the 4 waves of a block are summed through LDS and written to
 // partial[block][2][cols]; ln_bwd_reduce sums the blocks (deterministic, no atomics).
-template <bool DXSUM>
+// NC = ceil(cols / 512): per-lane column chunks kept in registers (3 for d = 1280: 2 waves/SIMD even with the dx column sums)
+template <bool DXSUM, int NC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const unsigned short* dy, const unsigned short* x,
                                                       const float* gamma, const float* mean,
                                                       const float* rstd, const unsigned short* dres,
                                                       unsigned short* dx, float* partial, long rows, int cols,
                                                       int rpb, int t0, int t1, int c0, int c1) {
-  __shared__ float red[4][DXSUM ? 3 : 2][LN_MAXC * 64 * 8 / 4];  // reused per chunk pass; sized below
+  __shared__ float red[4][DXSUM ? 3 : 2][512];  // one 512-column slot (64 lanes x 8), reused per chunk pass
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const long wave_id = (long)blockIdx.x * 4 + wv;
   const long nwaves = (long)gridDim.x * 4;
   const int nch = cols >> 3;
-  float dg[LN_MAXC][8], db[LN_MAXC][8], gm[LN_MAXC][8];
-  float dsum[DXSUM ? LN_MAXC : 1][8];  // column sums of the bf16 dx this wave writes (bias grad of the producing Linear)
+  float dg[NC][8], db[NC][8], gm[NC][8];
+  float dsum[DXSUM ? NC : 1][8];  // column sums of the bf16 dx this wave writes (bias grad of the producing Linear)
 #pragma unroll
-  for (int c = 0; c < LN_MAXC; ++c) {
+  for (int c = 0; c < NC; ++c) {
     const int ch = lane + c * 64;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -122,10 +123,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const unsigned short* dy, c
       const int t = (int)(row % rpb);
       trow = (t >= t0 && t < t1);
     }
-    float g[LN_MAXC][8], xh[LN_MAXC][8];
+    float g[NC][8], xh[NC][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int c = 0; c < LN_MAXC; ++c) {
+    for (int c = 0; c < NC; ++c) {
       const int ch = lane + c * 64;
       if (ch < nch) {
         float d[8], xv[8];
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const unsigned short* dy, c
     s1 = wave_sum(s1) / cols;
     s2 = wave_sum(s2) / cols;
 #pragma unroll
-    for (int c = 0; c < LN_MAXC; ++c) {
+    for (int c = 0; c < NC; ++c) {
       const int ch = lane + c * 64;
       if (ch < nch) {
         float o[8];
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const unsigned short* dy, c
   float* pb = pg + cols;
   float* ps = pb + cols;
 #pragma unroll
-  for (int c = 0; c < LN_MAXC; ++c) {
+  for (int c = 0; c < NC; ++c) {
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -258,12 +259,16 @@ extern "C" int wft_layernorm_bwd(const wft_bf16* dy, const wft_bf16* x, const fl
   WFT_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && partial, "null pointer");
   WFT_CHECK_ARG(rows >= 1 && cols >= 8 && cols % 8 == 0 && cols <= 2048, "cols must be a multiple of 8, <= 2048");
   const int grid = ln_grid(rows);
-  if (dx_colsum)
-    hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean, rstd,
-                       dres, dx, (float*)partial, (long)rows, cols, rows_per_batch, t0, t1, c0, c1);
-  else
-    hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean, rstd,
-                       dres, dx, (float*)partial, (long)rows, cols, rows_per_batch, t0, t1, c0, c1);
+#define LN_BWD_LAUNCH(DX, NCV)                                                                                     \
+  hipLaunchKernelGGL((ln_bwd_kernel<DX, NCV>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean, rstd, \
+                     dres, dx, (float*)partial, (long)rows, cols, rows_per_batch, t0, t1, c0, c1)
+  const int nc = (cols + 511) / 512;
+  if (dx_colsum) {
+    if (nc == 1) LN_BWD_LAUNCH(true, 1); else if (nc == 2) LN_BWD_LAUNCH(true, 2); else if (nc == 3) LN_BWD_LAUNCH(true, 3); else LN_BWD_LAUNCH(true, 4);
+  } else {
+    if (nc == 1) LN_BWD_LAUNCH(false, 1); else if (nc == 2) LN_BWD_LAUNCH(false, 2); else if (nc == 3) LN_BWD_LAUNCH(false, 3); else LN_BWD_LAUNCH(false, 4);
+  }
+#undef LN_BWD_LAUNCH
   hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((cols + 31) / 32), dim3(256), 0, (hipStream_t)stream,
                      (const float*)partial, grid, cols, dgamma, dbeta, dx_colsum);
   WFT_CHECK_LAUNCH();
