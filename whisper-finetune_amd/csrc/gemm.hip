@@ -836,8 +836,9 @@ static int g_diag = 0;
 // dispatch thresholds, measured at M = R = 4096 and 8704 (decoder-sized problems; tests/dev_small_gemm.py): the 256x256 kernels win once
 // they can occupy half of the CUs (NT: >= 128 tiles) / have >= 50 output tiles to split (TN).  Tunable: WFT_NT256_MIN_TILES, WFT_TN256_MIN_STEPS.
 static int g_nt256_min_tiles = 128, g_tn256_min_steps = 64;
+static bool g_nt256_persistent = true;
 static bool g_force_128 = false;  // debugging / A-B switch: WFT_GEMM_FORCE_128=1
-static struct EnvInit { EnvInit() { const char* e = getenv("WFT_GEMM_FORCE_128"); g_force_128 = e && e[0] == '1'; const char* d = getenv("WFT_GEMM_DIAG"); g_diag = d ? atoi(d) : 0; const char* t1 = getenv("WFT_NT256_MIN_TILES"); if (t1) g_nt256_min_tiles = atoi(t1); const char* t2 = getenv("WFT_TN256_MIN_STEPS"); if (t2) g_tn256_min_steps = atoi(t2); } } g_env_init;
+static struct EnvInit { EnvInit() { const char* e = getenv("WFT_GEMM_FORCE_128"); g_force_128 = e && e[0] == '1'; const char* d = getenv("WFT_GEMM_DIAG"); g_diag = d ? atoi(d) : 0; const char* t1 = getenv("WFT_NT256_MIN_TILES"); if (t1) g_nt256_min_tiles = atoi(t1); const char* t2 = getenv("WFT_TN256_MIN_STEPS"); if (t2) g_tn256_min_steps = atoi(t2); const char* pe = getenv("WFT_NT256_PERSISTENT"); if (pe) g_nt256_persistent = pe[0] != '0'; } } g_env_init;
 
 static int fill_params(const wft_gemm_args* a, GemmP& p) {
   p.A = a->A; p.lda = a->lda; p.sA = a->strideA;
@@ -932,7 +933,10 @@ extern "C" int wft_gemm_nt_bf16(const wft_gemm_args* a, void* stream) {
     static bool attr_done = false;
     const long t256 = ((a->M + 255) / 256) * (a->N / 256) * a->batch;
     const int ncu = wft_num_cus();
-    dim3 grid((unsigned)(t256 < ncu ? t256 : ncu)), block(512);  // persistent: one workgroup per CU walks the tiles
+    // persistent (one workgroup per CU walks the tiles, prefetching across tile seams) unless WFT_NT256_PERSISTENT=0: with
+    // collectives running beside the GEMMs (DDP over RCCL) some CUs are busy when the kernel starts, and a static tile
+    // walk would leave their share for the end; one workgroup per tile lets the hardware dispatcher balance instead
+    dim3 grid((unsigned)((t256 < ncu || !g_nt256_persistent) ? t256 : ncu)), block(512);
 #define LAUNCH_256(E, F)                                                                                   \
   do {                                                                                                    \
     auto kfn = gemm_nt256_kernel<E, F>;                                                                   \

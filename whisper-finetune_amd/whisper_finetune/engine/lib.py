@@ -124,6 +124,11 @@ def load():
             f"HIP extension {LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(make -C whisper-finetune_amd/csrc). There is no CPU fallback for the product path."
         )
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # multi-GPU job: RCCL's collective kernels hold CUs while the GEMMs of the backward pass start, so the 256x256
+        # NT kernel is launched one workgroup per tile (hardware-balanced) instead of persistent (csrc/gemm.hip;
+        # the library reads the variable once, when it is loaded)
+        os.environ.setdefault("WFT_NT256_PERSISTENT", "0")
     lib = C.CDLL(str(LIB_PATH))
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
