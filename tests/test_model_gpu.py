@@ -287,3 +287,74 @@ def test_fused_adamw_update_reaches_the_bf16_weight_shadows():
         want = fresh(mel, y_in.to(DEV))
     assert (w.detach().cpu() - params["encoder.blocks.0.mlp.0.weight"]).abs().max() > 1e-3  # the step moved the weights
     assert torch.equal(after, want)  # same kernels, same fp32 masters -> identical logits
+
+
+def _grad_check(m, p_req, tol_max, tol_med):
+    errs = {n: rel(p.grad, p_req[n].grad) for n, p in m.named_parameters() if p.grad is not None and p_req[n].grad is not None}
+    assert max(errs.values()) < tol_max, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    assert float(np.median(list(errs.values()))) < tol_med
+    return errs
+
+
+def test_base_full_finetune_step_matches_oracle():
+    """BASELINE configs[1] shape (whisper-base, full fine-tune, bf16; 2 of the 8 clips to keep the CPU oracle in seconds):
+    GPU log-mel + SpecAugment-free forward, fused label-smoothed CE, backward vs the fp32 oracle."""
+    dims = O.DIMS["base"]
+    params = O.init_params(dims, seed=3)
+    audio, y_in, y_out = O.synthetic_batch(dims, 2, 32)
+    p_req = {k: v.clone().requires_grad_(k != "encoder.positional_embedding") for k, v in params.items()}
+    mel_ref = O.log_mel_spectrogram(audio, dims.n_mels)
+    loss_ref = O.cross_entropy(O.Oracle(dims, p_req).forward(mel_ref, y_in), y_out, 0.1)
+    loss_ref.backward()
+    m = _engine(dims, params).train()
+    mel = K.logmel(audio.to(DEV), O.mel_filters(dims.n_mels).to(DEV))
+    loss = m(mel, y_in.to(DEV), targets=y_out.to(DEV), label_smoothing=0.1)
+    loss.backward()
+    assert abs(loss.item() - loss_ref.item()) < 2e-3 * loss_ref.item()
+    _grad_check(m, p_req, 8e-2, 2e-2)
+
+
+def test_turbo_lora_prompt_and_timestamp_targets_match_oracle():
+    """BASELINE configs[4] shape: large-v3-turbo (32 encoder / 4 decoder layers, 128 mels), LoRA r=16 alpha=32 on every
+    Linear, a batch item with a prompt (targets -100 up to and including the prompt) and timestamp tokens in the target
+    stream.  One clip, S = 48, against the fp32 oracle with the same adapters (minLoRA parametrization form)."""
+    dims = O.DIMS["large-v3-turbo"]
+    params = O.init_params(dims, seed=5)
+    g = torch.Generator().manual_seed(11)
+    audio = torch.randn(1, 480000, generator=g) * 0.1
+    sot_prev, sot, lang, task, ts0 = 50362, 50258, 50261, 50360, 50365
+    prompt = torch.randint(0, 50257, (20,), generator=g)
+    body = torch.randint(0, 50257, (22,), generator=g)
+    body[::6] = ts0 + torch.randint(0, 1500, (len(body[::6]),), generator=g)  # timestamp tokens inside the text
+    y_in = torch.cat([torch.tensor([sot_prev]), prompt, torch.tensor([sot, lang, task]), body]).unsqueeze(0)
+    y_out = torch.cat([y_in[0, 1:], torch.tensor([50257])]).unsqueeze(0).clone()
+    y_out[0, : 1 + len(prompt)] = -100  # no loss on the prompt (data_loader.py:322-340)
+    assert y_in.shape[1] == 46
+    r, alpha = 16, 32
+    m = _engine(dims, params).train()
+    lora_mod.apply_lora(m, {"rank": r, "lora_alpha": alpha, "lora_dropout": 0.0})
+    ad = {}
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "lora_B" in n:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+            if "lora_" in n:
+                ad[n] = p.detach().cpu().clone()
+    # oracle with the same adapters folded as W + (alpha/r) B A, gradients w.r.t. A and B through that form
+    req = {n: v.clone().requires_grad_(True) for n, v in ad.items()}
+    eff = dict(params)
+    for n in [k for k in req if k.endswith("lora_A")]:
+        base = n.replace(".parametrizations.weight.0.lora_A", ".weight")
+        eff[base] = params[base] + (alpha / r) * req[n.replace("lora_A", "lora_B")] @ req[n]
+    mel_ref = O.log_mel_spectrogram(audio, dims.n_mels)
+    loss_ref = O.cross_entropy(O.Oracle(dims, eff).forward(mel_ref, y_in), y_out, 0.1)
+    loss_ref.backward()
+    mel = K.logmel(audio.to(DEV), O.mel_filters(dims.n_mels).to(DEV))
+    loss = m(mel, y_in.to(DEV), targets=y_out.to(DEV), label_smoothing=0.1)
+    loss.backward()
+    assert abs(loss.item() - loss_ref.item()) < 2e-3 * loss_ref.item()
+    named = dict(m.named_parameters())
+    assert all(p.grad is None for n, p in named.items() if "lora" not in n)  # base weights frozen
+    errs = {n: rel(named[n].grad, req[n].grad) for n in req}
+    assert max(errs.values()) < 1e-1, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    assert float(np.median(list(errs.values()))) < 3e-2
