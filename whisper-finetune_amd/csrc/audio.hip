@@ -17,8 +17,8 @@
 __global__ __launch_bounds__(256) void logmel_kernel(const float* audio, const float* filters, float* out,
                                                       unsigned int* clipmax, int n_samples, int n_mels, int n_frames) {
   __shared__ float span[(FPB - 1) * HOP + NFFT];  // 2800
-  __shared__ float frames[FPB][NFFT];             // windowed
-  __shared__ float tw_c[NFFT], tw_s[NFFT];
+  __shared__ __attribute__((aligned(16))) float frames[FPB][NFFT];  // windowed
+  __shared__ __attribute__((aligned(8))) float tw[NFFT][2];         // (cos, sin)(2 pi i / 400)
   __shared__ float power[FPB][NBIN + 3];
   __shared__ float wmax[4];
   const int tid = threadIdx.x;
@@ -34,33 +34,47 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* audio, const f
   }
   for (int i = tid; i < NFFT; i += 256) {
     // sincospi keeps the table accurate to 1 ulp: angle = 2*pi*i/400
-    float s, c;
-    sincospif((float)i / 200.0f, &s, &c);
-    tw_c[i] = c;
-    tw_s[i] = s;
+    float sn, cs;
+    sincospif((float)i / 200.0f, &sn, &cs);
+    tw[i][0] = cs;
+    tw[i][1] = sn;
   }
   __syncthreads();
   for (int i = tid; i < FPB * NFFT; i += 256) {
     const int f = i / NFFT, n = i - f * NFFT;
-    const float w = 0.5f - 0.5f * tw_c[n];  // periodic Hann
+    const float w = 0.5f - 0.5f * tw[n][0];  // periodic Hann
     frames[f][n] = w * span[f * HOP + n];
   }
   __syncthreads();
-  // DFT: FPB*201 (frame, bin) outputs
-  for (int o = tid; o < FPB * NBIN; o += 256) {
-    const int f = o / NBIN, k = o - f * NBIN;
-    float re = 0.f, im = 0.f;
+  // DFT, register-blocked: thread = one bin k for all FPB frames.  Per 4 samples: 4 twiddle pairs (ds_read_b64) + FPB
+  // broadcast float4 frame reads feed 8*FPB FMAs, so the loop is VALU-bound (the per-(frame, bin) form read 3 LDS words
+  // per 2 FMAs).  Summation order over n is unchanged: results are bit-identical to that form.
+  if (tid < NBIN) {
+    const int k = tid;
+    float re[FPB], im[FPB];
+#pragma unroll
+    for (int f = 0; f < FPB; ++f) { re[f] = 0.f; im[f] = 0.f; }
     int idx = 0;
-    const float* fr = frames[f];
-#pragma unroll 4
-    for (int n = 0; n < NFFT; ++n) {
-      const float x = fr[n];
-      re = fmaf(x, tw_c[idx], re);
-      im = fmaf(x, tw_s[idx], im);
-      idx += k;
-      idx = idx >= NFFT ? idx - NFFT : idx;
+    for (int n = 0; n < NFFT; n += 4) {
+      f32x2 t[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        t[j] = *(const f32x2*)tw[idx];
+        idx += k;
+        idx = idx >= NFFT ? idx - NFFT : idx;
+      }
+#pragma unroll
+      for (int f = 0; f < FPB; ++f) {
+        const f32x4 x = *(const f32x4*)&frames[f][n];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          re[f] = fmaf(x[j], t[j][0], re[f]);
+          im[f] = fmaf(x[j], t[j][1], im[f]);
+        }
+      }
     }
-    power[f][k] = re * re + im * im;
+#pragma unroll
+    for (int f = 0; f < FPB; ++f) power[f][k] = re[f] * re[f] + im[f] * im[f];
   }
   __syncthreads();
   float lmax = -1.0e30f;
