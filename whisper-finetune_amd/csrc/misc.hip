@@ -55,12 +55,45 @@ extern "C" int wft_cast_bf16_f32(const wft_bf16* src, float* dst, int64_t n, voi
   return WFT_OK;
 }
 
-// src f32 [rows, cols] -> dst bf16 [rows_pad, cols_pad], dst_t bf16 [cols_pad, rows_pad]; 64x64 tiles via LDS
+// src f32 [rows, cols] -> dst bf16 [rows_pad, cols_pad], dst_t bf16 [cols_pad, rows_pad]; 64x64 tiles via LDS.
+// Each thread moves 4 consecutive elements (16-B loads, 8-B stores) on both the straight and the transposed side;
+// `fast` = every pointer / leading dimension allows that (checked on the host), otherwise element-wise.
 __global__ __launch_bounds__(256) void cast_pad_t_kernel(const float* src, long rows, long cols, unsigned short* dst,
                                                           unsigned short* dst_t, long rows_pad, long cols_pad,
-                                                          long ld_dst, long ld_dst_t) {
-  __shared__ unsigned short tile[64][66];
+                                                          long ld_dst, long ld_dst_t, int fast) {
+  __shared__ unsigned short tile[64][68];
   const long r0 = (long)blockIdx.y * 64, c0 = (long)blockIdx.x * 64;
+  if (fast) {
+    const int q = threadIdx.x & 15, rr0 = threadIdx.x >> 4;  // 16 threads x 4 columns per row, 16 rows per pass
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int rr = pass * 16 + rr0;
+      const long r = r0 + rr, c = c0 + q * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r < rows && c + 3 < cols) v = *(const f32x4*)(src + r * cols + c);
+      else if (r < rows) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (c + e < cols) ? src[r * cols + c + e] : 0.f;
+      }
+      const u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+      *(u32x2*)&tile[rr][q * 4] = pk;
+      if (r < rows_pad && c < cols_pad) *(u32x2*)(dst + r * ld_dst + c) = pk;  // cols_pad % 4 == 0 in fast mode
+    }
+    if (dst_t) {
+      __syncthreads();
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int cc = pass * 16 + rr0;  // transposed row = source column
+        const long c = c0 + cc, r = r0 + q * 4;
+        if (c < cols_pad && r < rows_pad) {
+          const u32x2 pk = {(unsigned)tile[q * 4][cc] | ((unsigned)tile[q * 4 + 1][cc] << 16),
+                            (unsigned)tile[q * 4 + 2][cc] | ((unsigned)tile[q * 4 + 3][cc] << 16)};
+          *(u32x2*)(dst_t + c * ld_dst_t + r) = pk;  // rows_pad % 4 == 0 in fast mode
+        }
+      }
+    }
+    return;
+  }
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int rr = ty; rr < 64; rr += 4) {
     const long r = r0 + rr, c = c0 + tx;
@@ -84,8 +117,10 @@ extern "C" int wft_cast_pad_transpose_f32_bf16(const float* src, int64_t rows, i
   WFT_CHECK_ARG(rows >= 1 && cols >= 1 && rows_pad >= rows && cols_pad >= cols, "bad shape");
   WFT_CHECK_ARG(ld_dst >= cols_pad && (!dst_t || ld_dst_t >= rows_pad), "leading dimensions too small");
   dim3 grid((unsigned)((cols_pad + 63) / 64), (unsigned)((rows_pad + 63) / 64));
+  const int fast = cols % 4 == 0 && cols_pad % 4 == 0 && rows_pad % 4 == 0 && ld_dst % 4 == 0 && (!dst_t || ld_dst_t % 4 == 0) &&
+                   (((uintptr_t)src) & 15) == 0 && (((uintptr_t)dst) & 7) == 0 && (!dst_t || (((uintptr_t)dst_t) & 7) == 0);
   hipLaunchKernelGGL(cast_pad_t_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, (long)rows, (long)cols, dst, dst_t,
-                     (long)rows_pad, (long)cols_pad, (long)ld_dst, (long)ld_dst_t);
+                     (long)rows_pad, (long)cols_pad, (long)ld_dst, (long)ld_dst_t, fast);
   WFT_CHECK_LAUNCH();
   return WFT_OK;
 }

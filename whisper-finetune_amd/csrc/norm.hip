@@ -196,37 +196,41 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const unsigned short* dy, c
   }
 }
 
-// sums the per-block partials: block = 32 columns x 8 row-lanes, LDS tree over the row-lanes
-__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* partial, int nblocks, int cols,
-                                                             float* dgamma, float* dbeta, float* dxsum) {
-  __shared__ float red[3][8][33];
-  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
-  const int col = blockIdx.x * 32 + cx;
-  const int nset = dxsum ? 3 : 2;
-  float sg = 0.f, sb = 0.f, ss = 0.f;
-  if (col < cols) {
-    for (int b = ry; b < nblocks; b += 8) {
+// sums the per-block partials: 64 columns per workgroup (256-byte row segments), 4 waves stride the partial rows of
+// this workgroup's row chunk (gridDim.y chunks).  Run twice: [nblocks] -> [LN_RED_CHUNKS] -> final (+= dgamma, dbeta; = dx sums).
+#define LN_RED_CHUNKS 16
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* partial, int nblocks, int cols, int nset,
+                                                             float* mid, float* dgamma, float* dbeta, float* dxsum) {
+  __shared__ float red[3][4][64];
+  const int cx = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cx;
+  const int per = (nblocks + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
+  float acc[3] = {0.f, 0.f, 0.f};
+  if (col < cols)
+    for (int b = b0 + wv; b < b1; b += 4) {
       const float* pp = partial + (long)b * nset * cols + col;
-      sg += pp[0];
-      sb += pp[cols];
-      if (dxsum) ss += pp[2 * cols];
-    }
-  }
-  red[0][ry][cx] = sg;
-  red[1][ry][cx] = sb;
-  red[2][ry][cx] = ss;
-  __syncthreads();
-  if (ry == 0 && col < cols) {
-    float tg = 0.f, tb = 0.f, ts = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      tg += red[0][k][cx];
-      tb += red[1][k][cx];
-      ts += red[2][k][cx];
+      for (int k = 0; k < 3; ++k)
+        if (k < nset) acc[k] += pp[(long)k * cols];
     }
-    dgamma[col] += tg;
-    dbeta[col] += tb;
-    if (dxsum) dxsum[col] = ts;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) red[k][wv][cx] = acc[k];
+  __syncthreads();
+  if (wv == 0 && col < cols) {
+    float tot[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tot[k] = red[k][0][cx] + red[k][1][cx] + red[k][2][cx] + red[k][3][cx];
+    if (mid) {
+      float* mp = mid + (long)blockIdx.y * nset * cols + col;
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (k < nset) mp[(long)k * cols] = tot[k];
+    } else {
+      dgamma[col] += tot[0];
+      dbeta[col] += tot[1];
+      if (dxsum) dxsum[col] = tot[2];
+    }
   }
 }
 
@@ -249,7 +253,7 @@ extern "C" int wft_layernorm_fwd(const wft_bf16* x, const float* gamma, const fl
 }
 
 extern "C" int64_t wft_layernorm_bwd_workspace(int64_t rows, int cols) {
-  return (int64_t)ln_grid(rows) * 3 * cols * sizeof(float);
+  return ((int64_t)ln_grid(rows) + LN_RED_CHUNKS) * 3 * cols * sizeof(float);
 }
 
 extern "C" int wft_layernorm_bwd(const wft_bf16* dy, const wft_bf16* x, const float* gamma, const float* mean,
@@ -269,8 +273,12 @@ extern "C" int wft_layernorm_bwd(const wft_bf16* dy, const wft_bf16* x, const fl
     if (nc == 1) LN_BWD_LAUNCH(false, 1); else if (nc == 2) LN_BWD_LAUNCH(false, 2); else if (nc == 3) LN_BWD_LAUNCH(false, 3); else LN_BWD_LAUNCH(false, 4);
   }
 #undef LN_BWD_LAUNCH
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((cols + 31) / 32), dim3(256), 0, (hipStream_t)stream,
-                     (const float*)partial, grid, cols, dgamma, dbeta, dx_colsum);
+  const int nset = dx_colsum ? 3 : 2;
+  float* mid = (float*)partial + (long)grid * nset * cols;
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((cols + 63) / 64, LN_RED_CHUNKS), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)partial, grid, cols, nset, mid, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((cols + 63) / 64, 1), dim3(256), 0, (hipStream_t)stream, (const float*)mid,
+                     LN_RED_CHUNKS, cols, nset, (float*)nullptr, dgamma, dbeta, dx_colsum);
   WFT_CHECK_LAUNCH();
   return WFT_OK;
 }
