@@ -39,6 +39,7 @@ struct AttnP {
   unsigned short* dv; long lddv, dv_bs;
   float* cs_q;  // [B * ceil(Tq/32)][H*64] per-wave column sums of dq (or NULL)
   float* cs_v;  // [B * ceil(Tk/32)][H*64] per-wave column sums of dv (or NULL)
+  int xcd;      // XCD-aware block placement on (WFT_ATTN_XCD=0 switches it off for A/B runs)
 };
 
 __device__ __forceinline__ int att_F(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
@@ -213,6 +214,27 @@ __device__ __forceinline__ void att_colsum_store(const f32x16 (&acc)[2], float m
     }
 }
 
+// XCD-aware block placement.  The hardware deals consecutive workgroup ids round-robin over the 8 XCDs, each with its
+// own 4 MiB L2.  All nx blocks of one (batch, head) re-stream the same K/V (or Q/dO) tiles, so they are mapped onto ONE
+// XCD: the i-th workgroup an XCD receives works on group (i / nx) * 8 + xcd, member i % nx.  (PMC before: FETCH_SIZE of
+// the backward kernels was ~5x their algorithmic bytes — every XCD pulled every head's tiles through the fabric.)
+// Bijective when the number of (batch, head) groups is a multiple of 8; identity order otherwise.
+__device__ __forceinline__ void att_block_coords(int nx, int H, int B, int xcd_on, int& bx, int& hd, int& b) {
+  const int L = blockIdx.x;
+  int g, m;
+  if ((((long)H * B) & 7) == 0 && xcd_on) {
+    const int xcd = L & 7, i = L >> 3;
+    g = (i / nx) * 8 + xcd;
+    m = i - (i / nx) * nx;
+  } else {
+    g = L / nx;
+    m = L - g * nx;
+  }
+  bx = m;
+  hd = g % H;
+  b = g / H;
+}
+
 template <int V>
 struct IntC { static constexpr int value = V; };
 
@@ -226,7 +248,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   __shared__ __attribute__((aligned(16))) char smem[3 * 16384];  // [slot 3][K 8K | V 8K]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int q0 = blockIdx.x * 128, hd = blockIdx.y, b = blockIdx.z;
+  int bx, hd, b;
+  att_block_coords((p.Tq + 127) >> 7, p.H, p.B, p.xcd, bx, hd, b);
+  const int q0 = bx * 128;
   const int qw0 = q0 + wave * 32;
   const int qi = qw0 + r;
   const int qc = qi < p.Tq ? qi : p.Tq - 1;
@@ -423,7 +447,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
   __shared__ __attribute__((aligned(16))) char smem[32768];  // [buf 2][K 8K | V 8K]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int q0 = blockIdx.x * 128, hd = blockIdx.y, b = blockIdx.z;
+  int bx, hd, b;
+  att_block_coords((p.Tq + 127) >> 7, p.H, p.B, p.xcd, bx, hd, b);
+  const int q0 = bx * 128;
   const int qw0 = q0 + wave * 32;
   const int qi = qw0 + r;
   const int qc = qi < p.Tq ? qi : p.Tq - 1;
@@ -552,7 +578,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * DKDV_BUF];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int k0 = blockIdx.x * 128, hd = blockIdx.y, b = blockIdx.z;
+  int bx, hd, b;
+  att_block_coords((p.Tk + 127) >> 7, p.H, p.B, p.xcd, bx, hd, b);
+  const int k0 = bx * 128;
   const int kw0 = k0 + wave * 32;
   const int ki = kw0 + r;
   const int kc = ki < p.Tk ? ki : p.Tk - 1;
@@ -721,6 +749,8 @@ static int attn_fill(const wft_attn_args* a, AttnP& p) {
   p.dk = a->dk; p.lddk = a->lddk; p.dk_bs = a->dk_bs;
   p.dv = a->dv; p.lddv = a->lddv; p.dv_bs = a->dv_bs;
   p.cs_q = nullptr; p.cs_v = nullptr;
+  static const int xcd_on = [] { const char* e = getenv("WFT_ATTN_XCD"); return e ? atoi(e) : 1; }();
+  p.xcd = xcd_on;
   return 0;
 }
 
@@ -735,7 +765,7 @@ extern "C" int wft_attn_fwd_bf16(const wft_attn_args* a, void* stream) {
   WFT_CHECK_ARG(!a->causal || a->Tq == a->Tk, "causal attention needs Tq == Tk");
   AttnP p;
   attn_fill(a, p);
-  dim3 grid((a->Tq + 127) / 128, a->H, a->B), block(256);
+  dim3 grid((unsigned)(((a->Tq + 127) / 128) * a->H * a->B)), block(256);  // 1-D: see att_block_coords
   hipLaunchKernelGGL(attn_fwd_kernel, grid, block, 0, (hipStream_t)stream, p);
   WFT_CHECK_LAUNCH();
   return WFT_OK;
@@ -785,8 +815,8 @@ extern "C" int wft_attn_bwd_bf16(const wft_attn_args* a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const long total = (long)a->B * a->Tq * a->H;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((a->Tq + 127) / 128, a->H, a->B), dim3(256), 0, s, p);
-  hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3((a->Tk + 127) / 128, a->H, a->B), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(((a->Tq + 127) / 128) * a->H * a->B)), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3((unsigned)(((a->Tk + 127) / 128) * a->H * a->B)), dim3(256), 0, s, p);
   if (p.cs_q) {
     const int n = a->H * 64;
     const long rq = (long)a->B * ((a->Tq + 31) / 32), rk = (long)a->B * ((a->Tk + 31) / 32);
