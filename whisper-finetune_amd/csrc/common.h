@@ -96,6 +96,14 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const WFT_GLB void*)gsrc, (WFT_LDS void*)lds_wave_base, 16, 0, 0);
 }
 
+// LDS-DMA with the address split the way the hardware takes it: scalar 64-bit base + per-lane 32-bit byte offset, LDS
+// destination (wave-uniform byte address) in M0.  Inline asm because hipcc folds base + offset into a per-lane 64-bit
+// pointer and then spends a v_lshl_add_u64 per piece per slab on it (vector instructions next to a partner wave that
+// issues MFMAs at raised priority are the expensive part of a load phase).  Counts in vmcnt like the builtin.
+__device__ __forceinline__ void glds16_saddr(unsigned voff, unsigned long long sbase, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
 // transposed LDS read: see cdna_hip_programming.md T10
 __device__ __forceinline__ s16x4 lds_read_tr16(const void* lds_addr) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((WFT_LDS s16x4*)lds_addr);

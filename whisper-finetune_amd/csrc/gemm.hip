@@ -212,29 +212,40 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
   // staging share of this wave: group A (waves 0-3) loads the A part of every slab, group B the B part;
   // wave-instruction = 16 rows x 64 B; this wave owns rows 64*(wave&3) .. +63 of its part (4 instructions)
   const int rr = lane >> 2, cc = lane & 3;
-  const unsigned short* src[4];
+  // Source address of an LDS-DMA piece = wave-uniform tile base (SGPR pair, advanced per slab on the scalar unit) + a
+  // per-lane 32-bit byte offset that is constant for the tile: the `saddr + voffset` form, NO vector instruction per
+  // piece.  (In-kernel stamps: the 12 reads + 4 pieces of an L-unit took 560-820 cycles to ISSUE — the partner wave's
+  // MFMAs run at s_setprio 1 and starve this wave's address arithmetic on the shared VALU port.)
+  const char* sbase;
+  unsigned soff[4];
   auto set_src = [&](int t) {  // PERSISTENT: tile t of this workgroup's sequence
     const int bz = t / tiles, sid = xcd_remap(t - bz * tiles, tiles);
     int tm, tn;
     band_coords(sid, tiles_m, tiles_n, tm, tn);
+    const unsigned long long b64 = !grp_b ? (unsigned long long)(p.A + (long)bz * p.sA + (long)(tm << 8) * p.lda)
+                                          : (unsigned long long)(p.B + (long)bz * p.sB + (long)(tn << 8) * p.ldb);
+    // pin the base to SGPRs (it is wave-uniform by construction; the compiler does not prove it through the tile loop)
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b64), hi = __builtin_amdgcn_readfirstlane((unsigned)(b64 >> 32));
+    sbase = (const char*)(((unsigned long long)hi << 32) | lo);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int row = (wave & 3) * 64 + j * 16 + rr;
+      int row = (wave & 3) * 64 + j * 16 + rr;
       const int chunk = cc ^ nt_g(rr);
       if (!grp_b) {
-        int gm = (tm << 8) + row;
-        gm = gm < p.M ? gm : p.M - 1;
-        src[j] = p.A + (long)bz * p.sA + (long)gm * p.lda + chunk * 8;
+        const int last = p.M - 1 - (tm << 8);  // clamp to the last valid row of A
+        row = row < last ? row : last;
+        soff[j] = (unsigned)(row * (int)p.lda + chunk * 8) * 2u;
       } else {
-        src[j] = p.B + (long)bz * p.sB + (long)((tn << 8) + row) * p.ldb + chunk * 8;
+        soff[j] = (unsigned)(row * (int)p.ldb + chunk * 8) * 2u;
       }
     }
   };
-  char* const stage_dst = dsmem + (grp_b ? 16384 : 0) + (wave & 3) * 4096;
+  const unsigned stage_dst = __builtin_amdgcn_readfirstlane(lds_addr_of(dsmem) + (grp_b ? 16384 : 0) + (wave & 3) * 4096);
   auto stage = [&](int u) {  // this wave's 4 KiB of slab u -> ring slot u & 3
-    char* dst = stage_dst + (u & 3) * 32768;
+    const unsigned dst = stage_dst + (u & 3) * 32768;
+    const unsigned long long sb = (unsigned long long)sbase + (unsigned long long)u * 64;  // wave-uniform
 #pragma unroll
-    for (int j = 0; j < 4; ++j) glds16(src[j] + u * 32, dst + j * 1024);
+    for (int j = 0; j < 4; ++j) glds16_saddr(soff[j], sb, dst + j * 1024);
   };
 
   const int nslab = p.K >> 5;
