@@ -664,19 +664,36 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmP p) {
   const long gbs = grp_b ? p.sB : p.sA;
   const int col0 = grp_b ? q0 : p0;
   char* const stage_dst = dsmem + (grp_b ? 16384 : 0) + (wave & 3) * 4096;
+  const unsigned stage_dst_s = __builtin_amdgcn_readfirstlane(lds_addr_of(stage_dst));
+  // full slabs: scalar base + constant per-lane byte offset (saddr form, no vector instruction per piece; see the NT kernel)
+  unsigned soff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = (wave & 3) * 8 + j * 2 + rr;
+    soff[j] = (unsigned)(r * (int)gld + ((cp ^ (tn_f(r) << 1)) << 3)) * 2u;
+  }
   // (batch item, slab-in-item) of the next slab to stage / to read, advanced incrementally (no division in the loop)
   int ld_b = s_begin / spb, ld_t = s_begin - ld_b * spb;
   int rd_t = ld_t;
   auto stage = [&](int u) {  // local slab index u -> ring slot u & 3; rows past R are clamped (masked at read time)
     const unsigned short* base = gbase + (long)ld_b * gbs + col0;
-    char* dst = stage_dst + (u & 3) * 32768;
+    if (ld_t * 32 + 32 <= R) {
+      const unsigned long long b64 = (unsigned long long)(base + (long)ld_t * 32 * gld);
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b64), hi = __builtin_amdgcn_readfirstlane((unsigned)(b64 >> 32));
+      const unsigned long long sb = ((unsigned long long)hi << 32) | lo;
+      const unsigned dsts = stage_dst_s + (u & 3) * 32768;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = (wave & 3) * 8 + j * 2 + rr;
-      int gr = ld_t * 32 + r;
-      gr = gr < R ? gr : R - 1;
-      const int c = cp ^ (tn_f(r) << 1);
-      glds16(base + (long)gr * gld + (c << 3), dst + j * 1024);
+      for (int j = 0; j < 4; ++j) glds16_saddr(soff[j], sb, dsts + j * 1024);
+    } else {
+      char* dst = stage_dst + (u & 3) * 32768;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = (wave & 3) * 8 + j * 2 + rr;
+        int gr = ld_t * 32 + r;
+        gr = gr < R ? gr : R - 1;
+        const int c = cp ^ (tn_f(r) << 1);
+        glds16(base + (long)gr * gld + (c << 3), dst + j * 1024);
+      }
     }
     if (++ld_t == spb) { ld_t = 0; ++ld_b; }
   };
