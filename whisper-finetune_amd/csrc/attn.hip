@@ -69,14 +69,20 @@ template <bool RAGGED>
 __device__ __forceinline__ void att_stage1(const AttStage& st, const unsigned short* base, long ld, int row0, int nrows,
                                            char* tile, int wave, int lane) {
   const char* tb = (const char*)base + (long)row0 * ld * 2;  // wave-uniform
+  if (!RAGGED) {  // scalar base + constant per-lane offset: the saddr form, no vector instruction per piece
+    const unsigned long long b64 = (unsigned long long)tb;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b64), hi = __builtin_amdgcn_readfirstlane((unsigned)(b64 >> 32));
+    const unsigned long long sb = ((unsigned long long)hi << 32) | lo;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr_of(tile) + wave * 2048);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) glds16_saddr(st.off[j], sb, dst + j * 1024);
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    unsigned off = st.off[j];
-    if (RAGGED) {
-      int rl = st.row[j];
-      rl = row0 + rl < nrows ? rl : nrows - 1 - row0;
-      off = (unsigned)(rl * (int)ld + (((lane & 7) ^ att_F(st.row[j])) << 3)) * 2u;
-    }
+    int rl = st.row[j];
+    rl = row0 + rl < nrows ? rl : nrows - 1 - row0;
+    const unsigned off = (unsigned)(rl * (int)ld + (((lane & 7) ^ att_F(st.row[j])) << 3)) * 2u;
     glds16(tb + off, tile + (wave * 2 + j) * 1024);
   }
 }
