@@ -468,6 +468,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
   }
 }
 
+// ds_read_b64_tr_b16 from inline asm with an immediate offset (contract as lds_read_tr16_asm in common.h)
+template <int IMM>
+__device__ __forceinline__ s16x4 tn_tr_asm(unsigned lds_byte_addr) {
+  s16x4 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(lds_byte_addr), "n"(IMM));
+  return r;
+}
+
 // ---------------------------------------------------------------------------------- TN
 // C[p][q] = sum_r A[r][p] * B[r][q].  LDS tiles are [64 r][128 cols] (256-byte rows);
 // MFMA operands are column reads of those tiles -> ds_read_b64_tr_b16.
@@ -734,14 +742,19 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmP p) {
     {
       const unsigned sa = lds0 + (u & 3) * 32768;
       const unsigned sb = sa + 16384;
+      // the second 4-row group of a fragment is +4 rows = +2048 B: in the instruction's immediate, not a second address
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j) {
+        const unsigned ad = sa + frag_off(colp + j * 16, 0);
+        ph[j][0] = tn_tr_asm<0>(ad);
+        ph[j][1] = tn_tr_asm<2048>(ad);
+      }
 #pragma unroll
-        for (int t = 0; t < 2; ++t) ph[j][t] = lds_read_tr16_asm(sa + frag_off(colp + j * 16, t));
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) qh[i][t] = lds_read_tr16_asm(sb + frag_off(colq + i * 16, t));
+      for (int i = 0; i < 8; ++i) {
+        const unsigned ad = sb + frag_off(colq + i * 16, 0);
+        qh[i][0] = tn_tr_asm<0>(ad);
+        qh[i][1] = tn_tr_asm<2048>(ad);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
