@@ -99,7 +99,9 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 // LDS-DMA with the address split the way the hardware takes it: scalar 64-bit base + per-lane 32-bit byte offset, LDS
 // destination (wave-uniform byte address) in M0.  Inline asm because hipcc folds base + offset into a per-lane 64-bit
 // pointer and then spends a v_lshl_add_u64 per piece per slab on it (vector instructions next to a partner wave that
-// issues MFMAs at raised priority are the expensive part of a load phase).  Counts in vmcnt like the builtin.
+// issues MFMAs at raised priority are the expensive part of a load phase).  Counts in vmcnt like the builtin.  M0 is a
+// reserved register for hipcc (it re-materialises M0 in front of every instruction of its own that reads it), so writing it
+// here needs no clobber — listing it only draws -Winline-asm.
 __device__ __forceinline__ void glds16_saddr(unsigned voff, unsigned long long sbase, unsigned lds_dst) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
