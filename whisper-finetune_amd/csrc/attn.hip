@@ -243,6 +243,14 @@ __device__ __forceinline__ void att_block_coords(int nx, int H, int B, int xcd_o
 
 template <int V>
 struct IntC { static constexpr int value = V; };
+// f(IntC<0>{}), ..., f(IntC<N-1>{}): loop indices usable as template arguments (immediate offsets of asm reads)
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(IntC<N - 1>{});
+  }
+}
 
 // ------------------------------------------------------------------------------ forward
 // K/V tiles travel through a THREE-slot LDS ring, staged two tiles ahead of their use, and the end-of-tile
@@ -320,12 +328,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
     s16x4 vt[4][2][2];
     bf16x8 pf[4];
     if (active) {
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
+      static_for<4>([&](auto ks_tag) {  // the k-step's 2048-byte stride rides in the immediate: no address add per read
+        constexpr int ks = decltype(ks_tag)::value;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
-          for (int t = 0; t < 2; ++t) vt[ks][db][t] = att_tr_asm<CUR * 16384 + 8192>(tra[db][t] + ks * 2048);
+          for (int t = 0; t < 2; ++t) vt[ks][db][t] = att_tr_asm<CUR * 16384 + 8192 + ks * 2048>(tra[db][t]);
+      });
       f32x16 sacc[2];
 #pragma unroll
       for (int kb2 = 0; kb2 < 2; ++kb2) {
@@ -642,19 +651,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
     const float* lse_l = (const float*)(q_l + 16384);
     const float* dlt_l = lse_l + 64;
     if (!(p.causal && kw0 > qq0 + 63)) {
-#pragma unroll
-      for (int qb2 = 0; qb2 < 2; ++qb2) {
+      static_for<2>([&](auto qb_tag) {
+        constexpr int QB2 = decltype(qb_tag)::value;
+        constexpr int qb2 = QB2;
         // transposed fragments of this 32-query half: in flight under the S / dP MFMAs and the exponentials
         s16x4 dot[2][2][2], qt_[2][2][2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        static_for<2>([&](auto ks_tag) {
+          constexpr int ks = decltype(ks_tag)::value;
 #pragma unroll
           for (int db = 0; db < 2; ++db)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-              dot[ks][db][t] = att_tr_asm<CUR * DKDV_BUF + 8192>(tra[db][t] + (2 * qb2 + ks) * 2048);
-              qt_[ks][db][t] = att_tr_asm<CUR * DKDV_BUF>(tra[db][t] + (2 * qb2 + ks) * 2048);
+              dot[ks][db][t] = att_tr_asm<CUR * DKDV_BUF + 8192 + (2 * QB2 + ks) * 2048>(tra[db][t]);
+              qt_[ks][db][t] = att_tr_asm<CUR * DKDV_BUF + (2 * QB2 + ks) * 2048>(tra[db][t]);
             }
+        });
         f32x16 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_row_frag(q_l, offs, qb2, 0), kf[0], zero16, 0, 0, 0);
         f32x16 pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_row_frag(do_l, offs, qb2, 0), vf[0], zero16, 0, 0, 0);
 #pragma unroll
@@ -709,7 +720,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
             dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_join(dot[ks][db][0], dot[ks][db][1]), pf[ks], dvacc[db], 0, 0, 0);
             dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_join(qt_[ks][db][0], qt_[ks][db][1]), dsf[ks], dkacc[db], 0, 0, 0);
           }
-      }
+      });
     }
     __syncthreads();
   };
