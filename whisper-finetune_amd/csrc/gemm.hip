@@ -1085,8 +1085,9 @@ extern "C" int wft_gemm_tn_bf16(const wft_gemm_args* a, void* stream) {
   int nsplit = 1;
   if (a->c_is_f32) {
     double best = 0.0;
-    for (int sp = 1; sp <= 8; ++sp) {
-      if (sp > 1 && nsteps / sp < 16) break;
+    // up to 64 splits: rank-r LoRA gradients are ONE 128-wide tile row (10-40 tiles) over a 48 000+ row reduction
+    for (int sp = 1; sp <= 64; ++sp) {
+      if (sp > 1 && nsteps / sp < (sp <= 8 ? 16 : 12)) break;
       const double waves = (double)(tiles * sp) / 512.0;
       const double eff = waves / (double)((long)(waves + 0.999999));
       if (eff > best + 0.03) { best = eff; nsplit = sp; }
