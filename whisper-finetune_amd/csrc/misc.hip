@@ -131,12 +131,11 @@ extern "C" int wft_cast_pad_transpose_f32_bf16(const float* src, int64_t rows, i
 __global__ __launch_bounds__(256) void lora_merge_kernel(const float* W, long rows, long cols, const float* Bm, const float* Am,
                                                           const float* mask, int r, float scaling, unsigned short* dst,
                                                           unsigned short* dst_t, long rows_pad, long cols_pad, long ld_dst,
-                                                          long ld_dst_t, float* dst_f32) {
-  __shared__ unsigned short tile[64][66];
-  __shared__ float bs[64][65];  // bs[i][q] = B[r0 + i][q]
-  __shared__ float as[64][65];  // as[q][j] = scaling * A[q][c0 + j] * mask[c0 + j]
+                                                          long ld_dst_t, float* dst_f32, int fast) {
+  __shared__ unsigned short tile[64][68];
+  __shared__ float bs[64][65];                                  // bs[i][q] = B[r0 + i][q]
+  __shared__ __attribute__((aligned(16))) float as[64][68];     // as[q][j] = scaling * A[q][c0 + j] * mask[c0 + j]
   const long r0 = (long)blockIdx.y * 64, c0 = (long)blockIdx.x * 64;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < 64 * r; i += 256) {
     const int a = i / r, q = i - a * r;
     bs[a][q] = (r0 + a < rows) ? Bm[(r0 + a) * r + q] : 0.f;
@@ -147,15 +146,59 @@ __global__ __launch_bounds__(256) void lora_merge_kernel(const float* W, long ro
     as[q][j] = (c < cols) ? scaling * Am[(long)q * cols + c] * (mask ? mask[c] : 1.f) : 0.f;
   }
   __syncthreads();
+  if (fast) {  // 4 consecutive columns per thread: 16-B loads of W / A, 8-B stores both ways (cf. cast_pad_t_kernel)
+    const int q4 = threadIdx.x & 15, rr0 = threadIdx.x >> 4;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int rr = pass * 16 + rr0;
+      const long rw = r0 + rr, c = c0 + q4 * 4;
+      f32x4 w = {0.f, 0.f, 0.f, 0.f};
+      const bool in = rw < rows && c + 3 < cols;
+      if (in) {
+        w = *(const f32x4*)(W + rw * cols + c);
+        for (int q = 0; q < r; ++q) {
+          const float bq = bs[rr][q];
+          const f32x4 a4 = *(const f32x4*)&as[q][q4 * 4];
+          w[0] = fmaf(bq, a4[0], w[0]); w[1] = fmaf(bq, a4[1], w[1]); w[2] = fmaf(bq, a4[2], w[2]); w[3] = fmaf(bq, a4[3], w[3]);
+        }
+        if (dst_f32) *(f32x4*)(dst_f32 + rw * cols + c) = w;
+      } else if (rw < rows) {
+        for (int e = 0; e < 4; ++e)
+          if (c + e < cols) {
+            float acc = W[rw * cols + c + e];
+            for (int q = 0; q < r; ++q) acc = fmaf(bs[rr][q], as[q][q4 * 4 + e], acc);
+            w[e] = acc;
+            if (dst_f32) dst_f32[rw * cols + c + e] = acc;
+          }
+      }
+      const u32x2 pk = {pack2bf(w[0], w[1]), pack2bf(w[2], w[3])};
+      *(u32x2*)&tile[rr][q4 * 4] = pk;
+      if (dst && rw < rows_pad && c < cols_pad) *(u32x2*)(dst + rw * ld_dst + c) = pk;
+    }
+    if (dst_t) {
+      __syncthreads();
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int cc = pass * 16 + rr0;
+        const long c = c0 + cc, rw = r0 + q4 * 4;
+        if (c < cols_pad && rw < rows_pad) {
+          const u32x2 pk = {(unsigned)tile[q4 * 4][cc] | ((unsigned)tile[q4 * 4 + 1][cc] << 16),
+                            (unsigned)tile[q4 * 4 + 2][cc] | ((unsigned)tile[q4 * 4 + 3][cc] << 16)};
+          *(u32x2*)(dst_t + c * ld_dst_t + rw) = pk;
+        }
+      }
+    }
+    return;
+  }
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int rr = ty; rr < 64; rr += 4) {
     const long rw = r0 + rr, c = c0 + tx;
     unsigned short v = 0;
     if (rw < rows && c < cols) {
-      float acc = 0.f;
-      for (int q = 0; q < r; ++q) acc += bs[rr][q] * as[q][tx];
-      const float w = W[rw * cols + c] + acc;
-      if (dst_f32) dst_f32[rw * cols + c] = w;
-      v = f2bf(w);
+      float acc = W[rw * cols + c];
+      for (int q = 0; q < r; ++q) acc = fmaf(bs[rr][q], as[q][tx], acc);
+      if (dst_f32) dst_f32[rw * cols + c] = acc;
+      v = f2bf(acc);
     }
     tile[rr][tx] = v;
     if (dst && rw < rows_pad && c < cols_pad) dst[rw * ld_dst + c] = v;
@@ -177,8 +220,11 @@ extern "C" int wft_lora_merge(const float* W, int64_t rows, int64_t cols, const 
   WFT_CHECK_ARG(!dst_t || (dst && ld_dst_t >= rows_pad), "transposed destination needs dst and ld_dst_t >= rows_pad");
   if (!dst) { rows_pad = rows; cols_pad = cols; }
   dim3 grid((unsigned)((cols_pad + 63) / 64), (unsigned)((rows_pad + 63) / 64));
+  const int fast = cols % 4 == 0 && cols_pad % 4 == 0 && rows_pad % 4 == 0 && (!dst || ld_dst % 4 == 0) && (!dst_t || ld_dst_t % 4 == 0) &&
+                   (((uintptr_t)W) & 15) == 0 && (!dst || (((uintptr_t)dst) & 7) == 0) && (!dst_t || (((uintptr_t)dst_t) & 7) == 0) &&
+                   (!dst_f32 || (((uintptr_t)dst_f32) & 15) == 0);
   hipLaunchKernelGGL(lora_merge_kernel, grid, dim3(256), 0, (hipStream_t)stream, W, (long)rows, (long)cols, B, A, mask, rank,
-                     scaling, dst, dst_t, (long)rows_pad, (long)cols_pad, (long)ld_dst, (long)ld_dst_t, dst_f32);
+                     scaling, dst, dst_t, (long)rows_pad, (long)cols_pad, (long)ld_dst, (long)ld_dst_t, dst_f32, fast);
   WFT_CHECK_LAUNCH();
   return WFT_OK;
 }
