@@ -7,12 +7,14 @@
 
 One "step" = one optimizer step of the hot path on every rank: synthetic 30 s clips already
 resident in HBM -> log-mel -> SpecAugment -> encoder/decoder forward -> label-smoothed CE ->
-backward -> (DDP gradient all-reduce over RCCL, overlapped with backward) -> grad-norm clip ->
-AdamW.  Weights: random init of the whisper-large-v3 architecture; data: synthetic (no network).
+backward -> (DDP gradient all-reduce over RCCL, overlapped with backward) -> grad-norm clip folded
+into the libwft multi-tensor AdamW.  68 clips per GPU per step by default (180 GiB of the 288 GB HBM).
+Weights: random init of the whisper-large-v3 architecture; data: synthetic (no network).
 Rank 0 prints ONE JSON line (contract in the task statement); it also carries
   "roofline":     the dominant kernel (gemm_nt256_kernel: the Linear / logits forward and
                   backward-data GEMMs), algorithmic FLOPs (2*M*N*K) / HIP-event time of its launches
-                  during one instrumented step that follows the timed region;
+                  during one instrumented step that follows the timed region; "traffic" = HBM-side
+                  bytes per launch from the committed rocprofv3 PMC passes of this command (profiles/);
   "cpu_baseline": the CPU oracle (oracle/whisper_oracle.py, torch fp32) forward+backward on a
                   bounded sample, timed on this box's host cores (N=1 only).
 """
