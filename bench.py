@@ -170,8 +170,14 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group(backend="nccl")  # RCCL over xGMI
+    force_ddp = os.environ.get("WFT_BENCH_FORCE_DDP") == "1"  # exercise the DDP wrapper on one GPU (1-rank RCCL group)
+    if world > 1 or force_ddp:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group(backend="nccl", rank=0, world_size=1)
+        else:
+            dist.init_process_group(backend="nccl")  # RCCL over xGMI
 
     from whisper_finetune.data.gpu_frontend import GpuFrontend
     from whisper_finetune.engine import kernels as K
@@ -204,7 +210,7 @@ def main():
         # one wft_mt_sumsq + one wft_mt_adamw launch per step: clip_grad_norm_(1.0) folded into the AdamW pass
         opt = WftAdamW([p for p in model.parameters() if p.requires_grad], lr=1e-5, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.1)
     net = model
-    if world > 1:
+    if world > 1 or force_ddp:
         from torch.nn.parallel import DistributedDataParallel as DDP
 
         net = DDP(model, device_ids=[local_rank], output_device=local_rank, broadcast_buffers=False,
@@ -220,7 +226,7 @@ def main():
         return loss
 
     def fence():
-        if world > 1:
+        if world > 1 or force_ddp:
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
@@ -232,18 +238,21 @@ def main():
         loss = step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or force_ddp:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     final_loss = loss.item()
 
     roofline = None
-    if rank == 0 and not args.no_roofline:
-        # one more step with HIP events around every gemm_nt launch (on the launch stream)
-        K.PROFILE_NT = []
+    if not args.no_roofline:
+        # one more step with HIP events around every gemm_nt launch (on the launch stream).  EVERY rank runs the step (its
+        # gradient all-reduce is a collective); only rank 0 records.
+        if rank == 0:
+            K.PROFILE_NT = []
         step()
         torch.cuda.synchronize()
+    if rank == 0 and not args.no_roofline:
         recs, K.PROFILE_NT = K.PROFILE_NT, None
         big = [(s_.elapsed_time(e_), f, nb) for s_, e_, f, v, nb in recs if v == 256]  # gemm_nt256_kernel launches
         ms = sum(t for t, _, _ in big)
@@ -296,9 +305,17 @@ def main():
                                        "sample": f"failed: {exc!r}"}
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_ddp:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes version / path banners through C stdio (flushed only at exit): push them out first so that the JSON
+        # line is the LAST line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
