@@ -1,0 +1,30 @@
+"""bench.py contract on a GPU box: one JSON object as the LAST stdout line with the required keys, plain and through
+the DDP wrapper (1-rank RCCL group), on a small model so that it runs in seconds."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline", "cpu_baseline"}
+
+
+@pytest.mark.parametrize("force_ddp", [False, True])
+def test_bench_prints_one_json_line_last(force_ddp):
+    env = dict(os.environ, WFT_BENCH_FORCE_DDP="1" if force_ddp else "0", MASTER_PORT="29577")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--model", "base", "--batch", "4", "--seq", "32", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, env=env, cwd=str(ROOT), timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.strip()]
+    out = json.loads(lines[-1])  # the JSON object is the last line even when RCCL prints its banners
+    assert REQUIRED <= set(out)
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1 and out["value"] > 0 and out["higher_is_better"] is True
+    assert out["scaling"] == "weak" and out["unit"] == "audio-s/s" and out["dtype"] == "bf16" and "workload" in out["config"]
+    rf = out["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert sum(1 for ln in lines if ln.startswith("{")) == 1
