@@ -1,25 +1,26 @@
-// norm.hip — LayerNorm forward / backward (HBM-bound; one wave per row, 16-byte loads,
+// norm.hip — LayerNorm forward / backward (HBM-bound; one wave per row, next row prefetched,
 // wave-shuffle reductions, fp32 statistics as whisper.model.LayerNorm does).
 // Algorithmic bytes: fwd 2*rows*cols*2 B (read x, write y); bwd 3 reads + 1 write.
 #include "common.h"
 
-#define LN_MAXC 4  // chunks of 8 bf16 per lane -> cols <= 64*8*4 = 2048
-
-__device__ __forceinline__ void load8(const unsigned short* p, float* v) {
-  const u32x4 r = *(const u32x4*)p;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    v[2 * e] = bf2f((unsigned short)(r[e] & 0xffff));
-    v[2 * e + 1] = bf2f((unsigned short)(r[e] >> 16));
-  }
+// Column mapping: 4-column pieces (8-byte loads), lane l owns pieces l, l+64, ... (NQ = ceil(cols / 256) of them: exactly
+// 5 for d = 1280, 2 for 512; a wave instruction still covers 512 contiguous bytes of the row).
+__device__ __forceinline__ void cvt4(const u32x2 r, float* v) {
+  v[0] = bf2f((unsigned short)(r[0] & 0xffff));
+  v[1] = bf2f((unsigned short)(r[0] >> 16));
+  v[2] = bf2f((unsigned short)(r[1] & 0xffff));
+  v[3] = bf2f((unsigned short)(r[1] >> 16));
 }
-__device__ __forceinline__ void store8(unsigned short* p, const float* v) {
-  u32x4 r;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) r[e] = pack2bf(v[2 * e], v[2 * e + 1]);
-  *(u32x4*)p = r;
+__device__ __forceinline__ void store4(unsigned short* p, const float* v) {
+  u32x2 r;
+  r[0] = pack2bf(v[0], v[1]);
+  r[1] = pack2bf(v[2], v[3]);
+  *(u32x2*)p = r;
 }
 
+// forward: one wave per row; gamma/beta stay in registers and the next row's loads are in flight while the current row
+// is reduced and written (software prefetch), 4 waves per SIMD at NQ = 5
+template <int NQ, int VAR>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const unsigned short* x, const float* gamma,
                                                       const float* beta, unsigned short* y, float* mean,
                                                       float* rstd, long rows, int cols, float eps, int rpb,
@@ -27,34 +28,53 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const unsigned short* x, co
   const int lane = threadIdx.x & 63;
   const long wave_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long nwaves = (long)gridDim.x * 4;
-  const int nch = cols >> 3;
-  for (long row = wave_id; row < rows; row += nwaves) {
-    const unsigned short* xr = x + row * cols;
-    float v[LN_MAXC][8];
-    float s = 0.f;
+  const int nch = cols >> 2;
+  const float inv = 1.f / cols;
+  f32x4 gg[NQ], bb[NQ];
+  if (VAR >= 1) {
 #pragma unroll
-    for (int c = 0; c < LN_MAXC; ++c) {
+    for (int c = 0; c < NQ; ++c) {
       const int ch = lane + c * 64;
+      gg[c] = bb[c] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (ch < nch) {
-        load8(xr + ch * 8, v[c]);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s += v[c][e];
+        gg[c] = *(const f32x4*)(gamma + ch * 4);
+        bb[c] = *(const f32x4*)(beta + ch * 4);
       }
     }
-    const float mu = wave_sum(s) / cols;
+  }
+  u32x2 nraw[NQ];
+  auto fetch = [&](long row) {
+#pragma unroll
+    for (int c = 0; c < NQ; ++c) {
+      const int ch = lane + c * 64;
+      nraw[c] = u32x2{0u, 0u};
+      if (ch < nch) nraw[c] = *(const u32x2*)(x + row * cols + ch * 4);
+    }
+  };
+  if (wave_id < rows) fetch(wave_id);
+  for (long row = wave_id; row < rows; row += nwaves) {
+    float v[NQ][4];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NQ; ++c) {
+      cvt4(nraw[c], v[c]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s += v[c][e];
+    }
+    if (VAR >= 1 && row + nwaves < rows) fetch(row + nwaves);
+    const float mu = wave_sum(s) * inv;
     float q = 0.f;
 #pragma unroll
-    for (int c = 0; c < LN_MAXC; ++c) {
-      const int ch = lane + c * 64;
-      if (ch < nch) {
+    for (int c = 0; c < NQ; ++c) {
+      if (lane + c * 64 < nch) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < 4; ++e) {
           const float d = v[c][e] - mu;
           q += d * d;
         }
       }
     }
-    const float rs = rsqrtf(wave_sum(q) / cols + eps);
+    const float rs = rsqrtf(wave_sum(q) * inv + eps);
     if (lane == 0) {
       mean[row] = mu;
       rstd[row] = rs;
@@ -66,132 +86,171 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const unsigned short* x, co
     }
     unsigned short* yr = y + row * cols;
 #pragma unroll
-    for (int c = 0; c < LN_MAXC; ++c) {
+    for (int c = 0; c < NQ; ++c) {
       const int ch = lane + c * 64;
       if (ch < nch) {
-        float o[8];
-        const f32x4 g0 = *(const f32x4*)(gamma + ch * 8), g1 = *(const f32x4*)(gamma + ch * 8 + 4);
-        const f32x4 b0 = *(const f32x4*)(beta + ch * 8), b1 = *(const f32x4*)(beta + ch * 8 + 4);
+        float o[4];
+        if (VAR == 0) {
+          gg[c] = *(const f32x4*)(gamma + ch * 4);
+          bb[c] = *(const f32x4*)(beta + ch * 4);
+        }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float gg = e < 4 ? g0[e] : g1[e - 4];
-          const float bb = e < 4 ? b0[e] : b1[e - 4];
-          o[e] = (v[c][e] - mu) * rs * gg + bb;
+        for (int e = 0; e < 4; ++e) {
+          o[e] = (v[c][e] - mu) * rs * gg[c][e] + bb[c][e];
           if (rpb > 0) {
-            const int col = ch * 8 + e;
+            const int col = ch * 4 + e;
             if (trow || (col >= c0 && col < c1)) o[e] = 0.f;
           }
         }
-        store8(yr + ch * 8, o);
+        if (VAR == 2) {
+          u32x2 r;
+          r[0] = pack2bf(o[0], o[1]);
+          r[1] = pack2bf(o[2], o[3]);
+          __builtin_nontemporal_store(r, (u32x2*)(yr + ch * 4));
+        } else {
+          store4(yr + ch * 4, o);
+        }
       }
     }
+    if (VAR == 0 && row + nwaves < rows) fetch(row + nwaves);
   }
 }
 
-// backward: each wave walks rows (grid-stride), keeps per-lane dgamma/dbeta partials for its
-// columns, then the 4 waves of a block are summed through LDS and written to
-// partial[block][2][cols]; ln_bwd_reduce sums the blocks (deterministic, no atomics).
-// NC = ceil(cols / 512): per-lane column chunks kept in registers (3 for d = 1280: 2 waves/SIMD even with the dx column sums)
-template <bool DXSUM, int NC>
+// backward: each wave walks rows (grid-stride), keeps per-lane dgamma/dbeta partials for its columns, then the 4 waves
+// of a block are summed through LDS and written to partial[block][2 or 3][cols]; ln_bwd_reduce sums the blocks
+// (deterministic, no atomics).  The register file allows two waves per SIMD at d = 1280, so every wave keeps the NEXT
+// row's dy / x / dres loads in flight while it reduces and writes the current one (software prefetch).
+template <bool DXSUM, int NQ, int VAR>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const unsigned short* dy, const unsigned short* x,
                                                       const float* gamma, const float* mean,
                                                       const float* rstd, const unsigned short* dres,
                                                       unsigned short* dx, float* partial, long rows, int cols,
                                                       int rpb, int t0, int t1, int c0, int c1) {
-  __shared__ float red[4][DXSUM ? 3 : 2][512];  // one 512-column slot (64 lanes x 8), reused per chunk pass
+  __shared__ float red[4][DXSUM ? 3 : 2][256];  // one 256-column slot (64 lanes x 4), reused per piece pass
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const long wave_id = (long)blockIdx.x * 4 + wv;
   const long nwaves = (long)gridDim.x * 4;
-  const int nch = cols >> 3;
-  float dg[NC][8], db[NC][8], gm[NC][8];
-  float dsum[DXSUM ? NC : 1][8];  // column sums of the bf16 dx this wave writes (bias grad of the producing Linear)
+  const int nch = cols >> 2;
+  const float inv = 1.f / cols;
+  float dg[NQ][4], db[NQ][4], gm[NQ][4];
+  float dsum[DXSUM ? NQ : 1][4];  // column sums of the bf16 dx this wave writes (bias grad of the producing Linear)
 #pragma unroll
-  for (int c = 0; c < NC; ++c) {
+  for (int c = 0; c < NQ; ++c) {
     const int ch = lane + c * 64;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < 4; ++e) {
       if (DXSUM) dsum[c][e] = 0.f;
       dg[c][e] = 0.f;
       db[c][e] = 0.f;
-      gm[c][e] = (ch < nch) ? gamma[ch * 8 + e] : 0.f;
+      gm[c][e] = (ch < nch) ? gamma[ch * 4 + e] : 0.f;
     }
   }
+  u32x2 ndy[NQ], nx[NQ], nr[NQ];
+  float nmu = 0.f, nrs = 0.f;
+  auto fetch = [&](long row) {
+    nmu = mean[row];
+    nrs = rstd[row];
+#pragma unroll
+    for (int c = 0; c < NQ; ++c) {
+      const int ch = lane + c * 64;
+      ndy[c] = nx[c] = nr[c] = u32x2{0u, 0u};
+      if (ch < nch) {
+        if (VAR == 2) {
+          ndy[c] = __builtin_nontemporal_load((const u32x2*)(dy + row * cols + ch * 4));
+          nx[c] = __builtin_nontemporal_load((const u32x2*)(x + row * cols + ch * 4));
+          if (dres) nr[c] = __builtin_nontemporal_load((const u32x2*)(dres + row * cols + ch * 4));
+        } else {
+          ndy[c] = *(const u32x2*)(dy + row * cols + ch * 4);
+          nx[c] = *(const u32x2*)(x + row * cols + ch * 4);
+          if (dres) nr[c] = *(const u32x2*)(dres + row * cols + ch * 4);
+        }
+      }
+    }
+  };
+  if (wave_id < rows) fetch(wave_id);
   for (long row = wave_id; row < rows; row += nwaves) {
-    const float mu = mean[row], rs = rstd[row];
+    const float mu = nmu, rs = nrs;
+    u32x2 rdy[NQ], rx[NQ], rr[NQ];
+#pragma unroll
+    for (int c = 0; c < NQ; ++c) {
+      rdy[c] = ndy[c];
+      rx[c] = nx[c];
+      rr[c] = nr[c];
+    }
+    if (row + nwaves < rows) fetch(row + nwaves);
     bool trow = false;
     if (rpb > 0) {
       const int t = (int)(row % rpb);
       trow = (t >= t0 && t < t1);
     }
-    float g[NC][8], xh[NC][8];
+    float g[NQ][4], xh[NQ][4];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
+    for (int c = 0; c < NQ; ++c) {
       const int ch = lane + c * 64;
-      if (ch < nch) {
-        float d[8], xv[8];
-        load8(dy + row * cols + ch * 8, d);
-        load8(x + row * cols + ch * 8, xv);
+      float d[4], xv[4];
+      cvt4(rdy[c], d);
+      cvt4(rx[c], xv);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          if (rpb > 0) {
-            const int col = ch * 8 + e;
-            if (trow || (col >= c0 && col < c1)) d[e] = 0.f;
-          }
-          xh[c][e] = (xv[e] - mu) * rs;
-          g[c][e] = d[e] * gm[c][e];
-          s1 += g[c][e];
-          s2 += g[c][e] * xh[c][e];
-          dg[c][e] += d[e] * xh[c][e];
-          db[c][e] += d[e];
+      for (int e = 0; e < 4; ++e) {
+        if (rpb > 0) {
+          const int col = ch * 4 + e;
+          if (trow || (col >= c0 && col < c1)) d[e] = 0.f;
         }
+        // explicit fmas: both instantiations (with / without dx column sums) must round identically
+        xh[c][e] = (ch < nch) ? (xv[e] - mu) * rs : 0.f;
+        g[c][e] = d[e] * gm[c][e];
+        s1 += g[c][e];
+        s2 = __builtin_fmaf(g[c][e], xh[c][e], s2);
+        dg[c][e] = __builtin_fmaf(d[e], xh[c][e], dg[c][e]);
+        db[c][e] += d[e];
       }
     }
-    s1 = wave_sum(s1) / cols;
-    s2 = wave_sum(s2) / cols;
+    s1 = wave_sum(s1) * inv;
+    s2 = wave_sum(s2) * inv;
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
+    for (int c = 0; c < NQ; ++c) {
       const int ch = lane + c * 64;
       if (ch < nch) {
-        float o[8];
+        float o[4], rv[4];
+        cvt4(rr[c], rv);  // zeros without a residual gradient
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = rs * (g[c][e] - s1 - xh[c][e] * s2);
-        if (dres) {
-          float rv[8];
-          load8(dres + row * cols + ch * 8, rv);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] += rv[e];
-        }
+        for (int e = 0; e < 4; ++e) o[e] = __builtin_fmaf(rs, __builtin_fmaf(-xh[c][e], s2, g[c][e] - s1), rv[e]);
         if (DXSUM) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) dsum[c][e] += bf2f(f2bf(o[e]));  // what wft_colsum_bf16 would read back
+          for (int e = 0; e < 4; ++e) dsum[c][e] += bf2f(f2bf(o[e]));  // what wft_colsum_bf16 would read back
         }
-        store8(dx + row * cols + ch * 8, o);
+        if (VAR >= 1) {
+          u32x2 r;
+          r[0] = pack2bf(o[0], o[1]);
+          r[1] = pack2bf(o[2], o[3]);
+          __builtin_nontemporal_store(r, (u32x2*)(dx + row * cols + ch * 4));
+        } else {
+          store4(dx + row * cols + ch * 4, o);
+        }
       }
     }
   }
-  // block reduction of dgamma/dbeta partials, one chunk-slot at a time through LDS
+  // block reduction of dgamma/dbeta partials, one piece-slot at a time through LDS
   float* pg = partial + (long)blockIdx.x * (DXSUM ? 3 : 2) * cols;
   float* pb = pg + cols;
   float* ps = pb + cols;
 #pragma unroll
-  for (int c = 0; c < NC; ++c) {
+  for (int c = 0; c < NQ; ++c) {
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      red[wv][0][lane * 8 + e] = dg[c][e];
-      red[wv][1][lane * 8 + e] = db[c][e];
-      if (DXSUM) red[wv][2][lane * 8 + e] = dsum[c][e];
+    for (int e = 0; e < 4; ++e) {
+      red[wv][0][lane * 4 + e] = dg[c][e];
+      red[wv][1][lane * 4 + e] = db[c][e];
+      if (DXSUM) red[wv][2][lane * 4 + e] = dsum[c][e];
     }
     __syncthreads();
-    // 512 columns of this slot, 256 threads -> 2 each
-    for (int k = threadIdx.x; k < 512; k += 256) {
-      const int col = c * 512 + k;
-      if (col < cols) {
-        pg[col] = red[0][0][k] + red[1][0][k] + red[2][0][k] + red[3][0][k];
-        pb[col] = red[0][1][k] + red[1][1][k] + red[2][1][k] + red[3][1][k];
-        if (DXSUM) ps[col] = red[0][2][k] + red[1][2][k] + red[2][2][k] + red[3][2][k];
-      }
+    const int k = threadIdx.x;  // 256 columns of this slot, one per thread
+    const int col = c * 256 + k;
+    if (col < cols) {
+      pg[col] = red[0][0][k] + red[1][0][k] + red[2][0][k] + red[3][0][k];
+      pb[col] = red[0][1][k] + red[1][1][k] + red[2][1][k] + red[3][1][k];
+      if (DXSUM) ps[col] = red[0][2][k] + red[1][2][k] + red[2][2][k] + red[3][2][k];
     }
   }
 }
@@ -234,20 +293,50 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* partial
   }
 }
 
-static int ln_grid(long rows) {
+static int ln_grid(long rows) {  // backward: 2 waves per SIMD (register-bound), and one partial row per workgroup
   long g = (rows + 3) / 4;
   if (g > 512) g = 512;
   if (g < 1) g = 1;
   return (int)g;
 }
+// forward: as many workgroups as are resident at once (occupancy of the instantiation, queried once), grid-stride rows
+template <int NQ, int VAR>
+static int ln_fwd_grid(long rows) {
+  static int resident = 0;
+  if (!resident) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ln_fwd_kernel<NQ, VAR>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    resident = per_cu * 256;
+  }
+  long g = (rows + 3) / 4;
+  if (g > resident) g = resident;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+#define LN_NT_BYTES (64L << 20)
+#define LN_NQ_SWITCH(nq, M) \
+  switch (nq) { case 1: M(1); break; case 2: M(2); break; case 3: M(3); break; case 4: M(4); break; \
+                case 5: M(5); break; case 6: M(6); break; case 7: M(7); break; default: M(8); break; }
 
 extern "C" int wft_layernorm_fwd(const wft_bf16* x, const float* gamma, const float* beta, wft_bf16* y,
                                  float* mean, float* rstd, int64_t rows, int cols, float eps,
                                  int rows_per_batch, int t0, int t1, int c0, int c1, void* stream) {
   WFT_CHECK_ARG(x && gamma && beta && y && mean && rstd, "null pointer");
   WFT_CHECK_ARG(rows >= 1 && cols >= 8 && cols % 8 == 0 && cols <= 2048, "cols must be a multiple of 8, <= 2048");
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3(ln_grid(rows)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
-                     mean, rstd, (long)rows, cols, eps, rows_per_batch, t0, t1, c0, c1);
+  // VAR 1: gamma/beta in registers + next-row prefetch; VAR 2: the same with non-temporal y stores, used when the
+  // tensor is larger than the caches could keep for the consumer anyway (5.4 -> 6.5 TB/s at 68 x 1500 x 1280);
+  // VAR 0 (no prefetch, 3.4 TB/s) only through WFT_LN_FWD_VAR for A/B runs
+  static int forced = -2;
+  if (forced == -2) { const char* e = getenv("WFT_LN_FWD_VAR"); forced = e ? atoi(e) : -1; }
+  const int var = forced >= 0 ? forced : ((long)rows * cols * 2 >= LN_NT_BYTES ? 2 : 1);
+#define LN_FWD_LAUNCH_V(NQV, V)                                                                                     \
+  hipLaunchKernelGGL((ln_fwd_kernel<NQV, V>), dim3(ln_fwd_grid<NQV, V>(rows)), dim3(256), 0, (hipStream_t)stream, x, gamma, \
+                     beta, y, mean, rstd, (long)rows, cols, eps, rows_per_batch, t0, t1, c0, c1)
+#define LN_FWD_LAUNCH(NQV) \
+  if (var == 0) LN_FWD_LAUNCH_V(NQV, 0); else if (var == 2) LN_FWD_LAUNCH_V(NQV, 2); else LN_FWD_LAUNCH_V(NQV, 1)
+  LN_NQ_SWITCH((cols + 255) / 256, LN_FWD_LAUNCH)
+#undef LN_FWD_LAUNCH
   WFT_CHECK_LAUNCH();
   return WFT_OK;
 }
@@ -263,15 +352,21 @@ extern "C" int wft_layernorm_bwd(const wft_bf16* dy, const wft_bf16* x, const fl
   WFT_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && partial, "null pointer");
   WFT_CHECK_ARG(rows >= 1 && cols >= 8 && cols % 8 == 0 && cols <= 2048, "cols must be a multiple of 8, <= 2048");
   const int grid = ln_grid(rows);
-#define LN_BWD_LAUNCH(DX, NCV)                                                                                     \
-  hipLaunchKernelGGL((ln_bwd_kernel<DX, NCV>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean, rstd, \
+  // VAR 2 (non-temporal dy / x / dres loads and dx stores) for tensors the caches cannot keep; WFT_LN_BWD_VAR forces one
+  static int forced = -2;
+  if (forced == -2) { const char* e = getenv("WFT_LN_BWD_VAR"); forced = e ? atoi(e) : -1; }
+  const int var = forced >= 0 ? forced : ((long)rows * cols * 2 >= LN_NT_BYTES ? 2 : 0);
+#define LN_BWD_LAUNCH_V(DX, NCV, V)                                                                                 \
+  hipLaunchKernelGGL((ln_bwd_kernel<DX, NCV, V>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean, rstd, \
                      dres, dx, (float*)partial, (long)rows, cols, rows_per_batch, t0, t1, c0, c1)
-  const int nc = (cols + 511) / 512;
-  if (dx_colsum) {
-    if (nc == 1) LN_BWD_LAUNCH(true, 1); else if (nc == 2) LN_BWD_LAUNCH(true, 2); else if (nc == 3) LN_BWD_LAUNCH(true, 3); else LN_BWD_LAUNCH(true, 4);
-  } else {
-    if (nc == 1) LN_BWD_LAUNCH(false, 1); else if (nc == 2) LN_BWD_LAUNCH(false, 2); else if (nc == 3) LN_BWD_LAUNCH(false, 3); else LN_BWD_LAUNCH(false, 4);
-  }
+#define LN_BWD_LAUNCH(DX, NCV) \
+  if (var == 0) LN_BWD_LAUNCH_V(DX, NCV, 0); else if (var == 2) LN_BWD_LAUNCH_V(DX, NCV, 2); else LN_BWD_LAUNCH_V(DX, NCV, 1)
+  const int nq = (cols + 255) / 256;
+#define LN_BWD_T(NQV) LN_BWD_LAUNCH(true, NQV)
+#define LN_BWD_F(NQV) LN_BWD_LAUNCH(false, NQV)
+  if (dx_colsum) { LN_NQ_SWITCH(nq, LN_BWD_T) } else { LN_NQ_SWITCH(nq, LN_BWD_F) }
+#undef LN_BWD_T
+#undef LN_BWD_F
 #undef LN_BWD_LAUNCH
   const int nset = dx_colsum ? 3 : 2;
   float* mid = (float*)partial + (long)grid * nset * cols;
