@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const unsigned short* dy, c
 }
 
 // sums the per-block partials: 64 columns per workgroup (256-byte row segments), 4 waves stride the partial rows of
-// this workgroup's row chunk (gridDim.y chunks).  Run twice: [nblocks] -> [LN_RED_CHUNKS] -> final (+= dgamma, dbeta; = dx sums).
+// this workgroup's row chunk (gridDim.y chunks).  Run twice: [nblocks] -> [LN_RED_CHUNKS] -> final (dgamma, dbeta, dx sums written).
 #define LN_RED_CHUNKS 16
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* partial, int nblocks, int cols, int nset,
                                                              float* mid, float* dgamma, float* dbeta, float* dxsum) {
@@ -286,8 +286,8 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* partial
       for (int k = 0; k < 3; ++k)
         if (k < nset) mp[(long)k * cols] = tot[k];
     } else {
-      dgamma[col] += tot[0];
-      dbeta[col] += tot[1];
+      dgamma[col] = tot[0];
+      dbeta[col] = tot[1];
       if (dxsum) dxsum[col] = tot[2];
     }
   }

@@ -156,7 +156,8 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, mask=None):
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, mask=None, want_colsum=False):
-    """returns dx bf16, dgamma f32, dbeta f32 (fresh, zero-initialised accumulators) [, colsum(dx) f32 if want_colsum]."""
+    """returns dx bf16, dgamma f32, dbeta f32 (fresh tensors, each its own allocation so that autograd can keep them as
+    the .grad without a copy) [, colsum(dx) f32 if want_colsum]."""
     _chk(dy, BF16, "dy"); _chk(x, BF16, "x")
     dy = dy.contiguous(); x = x.contiguous()
     if dres is not None:
@@ -167,8 +168,8 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, mask=None, want_colsum=Fa
     lib = L.load()
     ws = torch.empty(lib.wft_layernorm_bwd_workspace(rows, cols), dtype=torch.uint8, device=x.device)
     dx = torch.empty_like(x)
-    dgb = torch.zeros((2, cols), dtype=F32, device=x.device)  # one fill for both accumulators
-    dgamma, dbeta = dgb[0], dgb[1]
+    dgamma = torch.empty(cols, dtype=F32, device=x.device)
+    dbeta = torch.empty(cols, dtype=F32, device=x.device)
     dxs = torch.empty(cols, dtype=F32, device=x.device) if want_colsum else None
     rpb, t0, t1, c0, c1 = mask if mask is not None else (0, 0, 0, 0, 0)
     L.check(
