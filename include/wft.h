@@ -110,7 +110,12 @@ int wft_layernorm_bwd(const wft_bf16* dy, const wft_bf16* x, const float* gamma,
 enum {
   WFT_EPI_NONE = 0,
   WFT_EPI_GELU = 1,   /* C = gelu_erf(acc + bias); if aux != NULL also store pre-activation there */
-  WFT_EPI_DGELU = 2   /* C = acc * gelu'(aux)  (backward through GELU; aux = saved pre-activation) */
+  WFT_EPI_DGELU = 2,  /* C = acc * gelu'(aux)  (backward through GELU; aux = saved pre-activation) */
+  /* The training pair of the MLP (mlp.0 -> GELU -> mlp.2): the forward GEMM stores gelu'(pre) instead of pre — same
+   * bytes — and the backward-data GEMM multiplies by it, so the derivative's exp/rcp/polynomial (about 30 % of a
+   * K = 1280 tile's time when done in the backward epilogue) is computed once, beside gelu() itself.  bf16 C only. */
+  WFT_EPI_GELU_GRAD = 3, /* C = gelu_erf(acc + bias); aux (required) <- gelu'(acc + bias) */
+  WFT_EPI_MUL_AUX = 4    /* C = acc * aux */
 };
 /* C[b][m, n] = alpha * sum_k A[b][m, k] * B[b][n, k]  (+ bias[n]) (epilogue)
  *              (+ residual[b][m, n]);  bf16 inputs, fp32 MFMA accumulation.

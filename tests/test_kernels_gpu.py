@@ -89,6 +89,14 @@ def test_gemm_nt_and_epilogues(M, N, Kd):
     close(K.gemm_nt(ad, bd, epilogue=L.EPI_DGELU, aux=aux), ref * pre.grad, 1e-2, "dgelu")
     close(K.gemm_nt(ad, bd, residual=res.to(DEV), residual_first=True, epilogue=L.EPI_GELU, aux=aux),
           torch.nn.functional.gelu(ref + res.float()), 1e-2, "residual-first gelu")
+    # training pair: the forward stores gelu'(pre) (GELU_GRAD), the backward-data GEMM multiplies by it (MUL_AUX)
+    dact = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    out2 = K.gemm_nt(ad, bd, bias=bias.to(DEV), epilogue=L.EPI_GELU_GRAD, aux=dact)
+    close(out2, torch.nn.functional.gelu(ref + bias), 1e-2, "gelu (GELU_GRAD)")
+    pre32 = (ref + bias).clone().requires_grad_(True)
+    torch.nn.functional.gelu(pre32).backward(torch.ones_like(pre32))
+    close(dact, pre32.grad, 1e-2, "gelu' (GELU_GRAD aux)")
+    close(K.gemm_nt(ad, bd, epilogue=L.EPI_MUL_AUX, aux=dact), ref * dact.float().cpu(), 1e-2, "mul aux")
 
 
 def test_gemm_nt_rejects_bad_shapes():

@@ -91,6 +91,22 @@ __device__ __forceinline__ float dgelu_f(float x) {
   return fmaf(x, 0.39894228040143267794f * e, cdf);
 }
 
+// gelu(x) = x Phi(x) and gelu'(x) from the same exponential, reciprocal and polynomial (WFT_EPI_GELU_GRAD: the forward
+// GEMM stores gelu' so that the backward-data GEMM's epilogue is a single multiply)
+__device__ __forceinline__ void gelu_both_f(float x, float& g, float& d) {
+  const float ax = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float half_erfc = 0.5f * poly * t * e;
+  const float cdf = x >= 0.f ? 1.0f - half_erfc : half_erfc;
+  g = x * cdf;
+  d = fmaf(x, 0.39894228040143267794f * e, cdf);
+}
+
 // async global -> LDS, 16 bytes per lane; LDS destination = wave-uniform base + lane*16
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const WFT_GLB void*)gsrc, (WFT_LDS void*)lds_wave_base, 16, 0, 0);

@@ -157,6 +157,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
         v[1] *= dgelu_f(bf2f((unsigned short)(a2[0] >> 16)));
         v[2] *= dgelu_f(bf2f((unsigned short)(a2[1] & 0xffff)));
         v[3] *= dgelu_f(bf2f((unsigned short)(a2[1] >> 16)));
+      } else if (EPI == WFT_EPI_GELU_GRAD) {
+        float dv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gelu_both_f(v[e], v[e], dv[e]);
+        u32x2 pk = {pack2bf(dv[0], dv[1]), pack2bf(dv[2], dv[3])};
+        *(u32x2*)(p.aux + (long)bz * p.sAux + (long)m * p.ldaux + n) = pk;
+      } else if (EPI == WFT_EPI_MUL_AUX) {
+        const u32x2 a2 = *(const u32x2*)(p.aux + (long)bz * p.sAux + (long)m * p.ldaux + n);
+        v[0] *= bf2f((unsigned short)(a2[0] & 0xffff)); v[1] *= bf2f((unsigned short)(a2[0] >> 16));
+        v[2] *= bf2f((unsigned short)(a2[1] & 0xffff)); v[3] *= bf2f((unsigned short)(a2[1] >> 16));
       }
       if (p.res && !p.res_first) {
         const u32x2 r2 = *(const u32x2*)(p.res + (long)bz * p.sR + (long)m * p.ldr + n);
@@ -339,6 +349,23 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
       }
+      // residual / aux rows are fetched EPI_PF half-passes ahead of their use (a ring of registers): issued one at a time
+      // where they are consumed, each of the 16 half-passes of a tile paid a full memory latency with nothing to cover it.
+      // 4 is what fits beside the 128 accumulator registers (6 and 8 spill; a distance that grows as passes hand their
+      // accumulators back spills more: hipcc does not reuse them for the loads).
+      constexpr int EPI_PF = 4;
+      constexpr bool RD_AUX = (EPI == WFT_EPI_DGELU || EPI == WFT_EPI_MUL_AUX);
+      constexpr bool PF_RES = (EPI == WFT_EPI_NONE || EPI == WFT_EPI_GELU);  // the others (no residual in practice) read it in place: registers
+      u32x4 auxq[EPI_PF], resq[EPI_PF];
+      auto fetch_row = [&](int h, int slot) {
+        const int m = m0 + wm * 128 + (h >> 1) * 16 + (h & 1) * 8 + er;
+        if (m < p.M) {
+          if (RD_AUX) auxq[slot] = *(const u32x4*)(p.aux + (long)bz * p.sAux + (long)m * p.ldaux + ncol);
+          if (PF_RES && p.res) resq[slot] = *(const u32x4*)(p.res + (long)bz * p.sR + (long)m * p.ldr + ncol);
+        }
+      };
+#pragma unroll
+      for (int h = 0; h < EPI_PF; ++h) fetch_row(h, h);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
 #pragma unroll
@@ -350,6 +377,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
           const int lr = g8 * 8 + er;
           const int m = m0 + wm * 128 + i * 16 + lr;
           const int ch = (lane & 7) * 2;
+          const int slot = (i * 2 + g8) % EPI_PF;
           const f32x4 x0 = *(const f32x4*)(lds + lr * 256 + ((ch ^ lr) << 4));
           const f32x4 x1 = *(const f32x4*)(lds + lr * 256 + (((ch + 1) ^ lr) << 4));
           if (m < p.M) {
@@ -357,8 +385,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] = x0[e] * p.alpha + bias8[e]; v[4 + e] = x1[e] * p.alpha + bias8[4 + e]; }
             const long roff = (long)m;
+            u32x4 r4 = resq[slot];
+            if (!PF_RES && p.res) r4 = *(const u32x4*)(p.res + (long)bz * p.sR + roff * p.ldr + ncol);
             if (p.res && p.res_first) {
-              const u32x4 r4 = *(const u32x4*)(p.res + (long)bz * p.sR + roff * p.ldr + ncol);
 #pragma unroll
               for (int e = 0; e < 4; ++e) { v[2 * e] += p.beta * bf2f((unsigned short)(r4[e] & 0xffff)); v[2 * e + 1] += p.beta * bf2f((unsigned short)(r4[e] >> 16)); }
             }
@@ -370,15 +399,27 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
             } else if (EPI == WFT_EPI_DGELU) {
-              const u32x4 a4 = *(const u32x4*)(p.aux + (long)bz * p.sAux + roff * p.ldaux + ncol);
+              const u32x4 a4 = auxq[slot];
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
                 v[2 * e] *= dgelu_f(bf2f((unsigned short)(a4[e] & 0xffff)));
                 v[2 * e + 1] *= dgelu_f(bf2f((unsigned short)(a4[e] >> 16)));
               }
+            } else if (EPI == WFT_EPI_GELU_GRAD) {
+              float dv[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) gelu_both_f(v[e], v[e], dv[e]);
+              u32x4 pk = {pack2bf(dv[0], dv[1]), pack2bf(dv[2], dv[3]), pack2bf(dv[4], dv[5]), pack2bf(dv[6], dv[7])};
+              *(u32x4*)(p.aux + (long)bz * p.sAux + roff * p.ldaux + ncol) = pk;
+            } else if (EPI == WFT_EPI_MUL_AUX) {
+              const u32x4 a4 = auxq[slot];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                v[2 * e] *= bf2f((unsigned short)(a4[e] & 0xffff));
+                v[2 * e + 1] *= bf2f((unsigned short)(a4[e] >> 16));
+              }
             }
             if (p.res && !p.res_first) {
-              const u32x4 r4 = *(const u32x4*)(p.res + (long)bz * p.sR + roff * p.ldr + ncol);
 #pragma unroll
               for (int e = 0; e < 4; ++e) { v[2 * e] += p.beta * bf2f((unsigned short)(r4[e] & 0xffff)); v[2 * e + 1] += p.beta * bf2f((unsigned short)(r4[e] >> 16)); }
             }
@@ -393,6 +434,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
               for (int e = 0; e < 8; ++e) cs8[e] += v[e];
             }
           }
+          if (i * 2 + g8 + EPI_PF < 16) fetch_row(i * 2 + g8 + EPI_PF, slot);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
@@ -446,6 +488,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
           const u32x2 a2 = *(const u32x2*)(p.aux + (long)bz * p.sAux + (long)m * p.ldaux + n);
           v[0] *= dgelu_f(bf2f((unsigned short)(a2[0] & 0xffff))); v[1] *= dgelu_f(bf2f((unsigned short)(a2[0] >> 16)));
           v[2] *= dgelu_f(bf2f((unsigned short)(a2[1] & 0xffff))); v[3] *= dgelu_f(bf2f((unsigned short)(a2[1] >> 16)));
+        } else if (EPI == WFT_EPI_GELU_GRAD) {
+          float dv[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) gelu_both_f(v[e], v[e], dv[e]);
+          u32x2 pk = {pack2bf(dv[0], dv[1]), pack2bf(dv[2], dv[3])};
+          *(u32x2*)(p.aux + (long)bz * p.sAux + (long)m * p.ldaux + n) = pk;
+        } else if (EPI == WFT_EPI_MUL_AUX) {
+          const u32x2 a2 = *(const u32x2*)(p.aux + (long)bz * p.sAux + (long)m * p.ldaux + n);
+          v[0] *= bf2f((unsigned short)(a2[0] & 0xffff)); v[1] *= bf2f((unsigned short)(a2[0] >> 16));
+          v[2] *= bf2f((unsigned short)(a2[1] & 0xffff)); v[3] *= bf2f((unsigned short)(a2[1] >> 16));
         }
         if (p.res && !p.res_first) {
           const u32x2 r2 = *(const u32x2*)(p.res + (long)bz * p.sR + (long)m * p.ldr + n);
@@ -951,7 +1003,10 @@ extern "C" int wft_gemm_nt_bf16(const wft_gemm_args* a, void* stream) {
   WFT_CHECK_ARG(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->B & 15) == 0 && ((uintptr_t)a->C & 15) == 0,
                 "base pointers must be 16-byte aligned");
   WFT_CHECK_ARG(!(a->accumulate && !a->c_is_f32), "accumulate needs an f32 C");
-  WFT_CHECK_ARG(a->epilogue != WFT_EPI_DGELU || a->aux, "DGELU epilogue needs aux");
+  WFT_CHECK_ARG((a->epilogue != WFT_EPI_DGELU && a->epilogue != WFT_EPI_GELU_GRAD && a->epilogue != WFT_EPI_MUL_AUX) || a->aux,
+                "DGELU / GELU_GRAD / MUL_AUX epilogues need aux");
+  WFT_CHECK_ARG((a->epilogue != WFT_EPI_GELU_GRAD && a->epilogue != WFT_EPI_MUL_AUX) || !a->c_is_f32,
+                "GELU_GRAD / MUL_AUX epilogues write a bf16 C");
   WFT_CHECK_ARG(a->M < (1ll << 31) && a->N < (1ll << 31) && a->K < (1ll << 31), "dims exceed int32");
   GemmP p;
   fill_params(a, p);
@@ -990,6 +1045,8 @@ extern "C" int wft_gemm_nt_bf16(const wft_gemm_args* a, void* stream) {
       case WFT_EPI_NONE: if (a->c_is_f32) LAUNCH_256(WFT_EPI_NONE, true); else LAUNCH_256(WFT_EPI_NONE, false); break;
       case WFT_EPI_GELU: if (a->c_is_f32) LAUNCH_256(WFT_EPI_GELU, true); else LAUNCH_256(WFT_EPI_GELU, false); break;
       case WFT_EPI_DGELU: if (a->c_is_f32) LAUNCH_256(WFT_EPI_DGELU, true); else LAUNCH_256(WFT_EPI_DGELU, false); break;
+      case WFT_EPI_GELU_GRAD: LAUNCH_256(WFT_EPI_GELU_GRAD, false); break;
+      case WFT_EPI_MUL_AUX: LAUNCH_256(WFT_EPI_MUL_AUX, false); break;
       default: wft_set_error("wft_gemm_nt_bf16: unknown epilogue %d", a->epilogue); return WFT_ERR_ARG;
     }
 #undef LAUNCH_256
@@ -1011,6 +1068,8 @@ extern "C" int wft_gemm_nt_bf16(const wft_gemm_args* a, void* stream) {
     case WFT_EPI_NONE: LAUNCH_NT(WFT_EPI_NONE); break;
     case WFT_EPI_GELU: LAUNCH_NT(WFT_EPI_GELU); break;
     case WFT_EPI_DGELU: LAUNCH_NT(WFT_EPI_DGELU); break;
+    case WFT_EPI_GELU_GRAD: hipLaunchKernelGGL((gemm_nt_kernel<WFT_EPI_GELU_GRAD, false>), grid, block, 0, s, p); break;
+    case WFT_EPI_MUL_AUX: hipLaunchKernelGGL((gemm_nt_kernel<WFT_EPI_MUL_AUX, false>), grid, block, 0, s, p); break;
     default: wft_set_error("wft_gemm_nt_bf16: unknown epilogue %d", a->epilogue); return WFT_ERR_ARG;
   }
 #undef LAUNCH_NT

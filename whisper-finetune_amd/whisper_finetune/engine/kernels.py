@@ -190,7 +190,7 @@ def gemm_nt(a, b, *, M=None, N=None, K=None, lda=None, ldb=None, out=None, out_f
     """C[M,N] = alpha * A[M,K] @ B[N,K]^T (+bias) (epilogue) (+residual).
 
     a: bf16, row m at a.data_ptr() + m*lda; b: bf16 [N, K] (ldb).  Defaults take the shapes
-    from 2-D contiguous tensors.  `aux`: GELU pre-activation out (EPI_GELU) / in (EPI_DGELU).
+    from 2-D contiguous tensors.  `aux`: GELU pre-activation out (EPI_GELU) / in (EPI_DGELU); gelu' out (EPI_GELU_GRAD) / in (EPI_MUL_AUX).
     """
     _chk(a, BF16, "A"); _chk(b, BF16, "B")
     if M is None:

@@ -57,7 +57,7 @@ class AttnArgs(C.Structure):
     ]
 
 
-EPI_NONE, EPI_GELU, EPI_DGELU = 0, 1, 2
+EPI_NONE, EPI_GELU, EPI_DGELU, EPI_GELU_GRAD, EPI_MUL_AUX = 0, 1, 2, 3, 4
 
 # name -> argtypes (restype is int unless listed in _RESTYPES); this table is also what
 # tests/test_abi.py checks against the declarations in include/wft.h.

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 from typing import List, Optional, Sequence, Tuple
 
+import os
 import torch
 from torch.optim.optimizer import register_optimizer_step_post_hook
 
@@ -153,14 +154,20 @@ class _LinearCfg:
         self.gelu_out, self.gelu_in, self.out_features = gelu_out, gelu_in, out_features
 
 
+# WFT_GELU_PAIR=0: keep the pre-activation and evaluate gelu' in the backward-data GEMM's epilogue (A/B runs)
+_GELU_PAIR = os.environ.get("WFT_GELU_PAIR", "1") != "0"
+
+
 class LinearFn(torch.autograd.Function):
     """y = x @ Wcat^T + bias (+ LoRA) (GELU) (+ residual) as libwft GEMMs.
 
     inputs : x bf16 [M, K]; residual bf16 [M, N] or None; gelu_pre bf16 [M, K] or None
-             (if given, x == gelu(gelu_pre) and the backward returns d(gelu_pre): the GELU
-             derivative is fused into the backward-data GEMM epilogue);
+             (the first output of the gelu_out Linear that produced x: it stands for the pre-activation in the autograd
+             graph — the backward returns d(pre) through it — but its VALUES are gelu'(pre), written by that GEMM's
+             epilogue beside gelu(pre), so the backward-data GEMM here only multiplies by them: WFT_EPI_GELU_GRAD /
+             WFT_EPI_MUL_AUX in include/wft.h);
              cfg; then weights..., biases (only the non-None ones)..., lora A..., lora B...
-    outputs: y   (gelu_out=False)   |   (pre, act) with act non-differentiable (gelu_out=True)
+    outputs: y   (gelu_out=False)   |   (pre*, act) with act non-differentiable (gelu_out=True; pre* as above)
     """
 
     @staticmethod
@@ -184,7 +191,7 @@ class LinearFn(torch.autograd.Function):
         out_pre = None
         if cfg.gelu_out:
             out_pre = torch.empty((M, npad), dtype=BF16, device=x.device)
-            y = K.gemm_nt(x, W, bias=bias, epilogue=L.EPI_GELU, aux=out_pre, residual=residual)
+            y = K.gemm_nt(x, W, bias=bias, epilogue=L.EPI_GELU_GRAD if _GELU_PAIR else L.EPI_GELU, aux=out_pre, residual=residual)
         else:
             y = K.gemm_nt(x, W, bias=bias, residual=residual)
         ctx.cfg = cfg
@@ -220,7 +227,7 @@ class LinearFn(torch.autograd.Function):
                 # dpre is the dy of the Linear that produced gelu_pre: its bias gradient (column sums) comes out of this
                 # GEMM's epilogue (see _publish_colsum / _fused_colsum)
                 cs = torch.empty(WT.shape[0], dtype=F32, device=dy.device)
-                dpre = K.gemm_nt(dy, WT, epilogue=L.EPI_DGELU, aux=gelu_pre, colsum=cs)
+                dpre = K.gemm_nt(dy, WT, epilogue=L.EPI_MUL_AUX if _GELU_PAIR else L.EPI_DGELU, aux=gelu_pre, colsum=cs)
                 _publish_colsum(dpre, cs)
             else:
                 dx = K.gemm_nt(dy, WT)
