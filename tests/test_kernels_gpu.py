@@ -21,12 +21,12 @@ def bf(x):
     return x.to(torch.bfloat16)
 
 
-def close(got, ref, tol, what=""):
+def close(got, ref, tol, what="", atol=1e-30):
     got = got.detach().float().cpu()
     ref = ref.detach().float().cpu()
     err = (got - ref).abs().max().item()
     scale = ref.abs().max().item() + 1e-12
-    assert math.isfinite(err) and err <= tol * scale + 1e-30, f"{what}: max|err|={err:.3e} rel-to-max={err / scale:.3e} tol={tol}"
+    assert math.isfinite(err) and err <= tol * scale + atol, f"{what}: max|err|={err:.3e} rel-to-max={err / scale:.3e} tol={tol}"
 
 
 def test_casts_bit_exact():
@@ -162,7 +162,8 @@ def test_attention_fwd_bwd(B, H, Tq, Tk, causal):
     do = bf(torch.randn(B, Tq, D, generator=g))
     oref.backward(do.float())
     dq, dk, dv = K.attn_bwd(qd, kvd[..., :D], kvd[..., D:], o, lse, do.to(DEV), H, causal, 0.125)
-    close(dq, qr.grad, 2e-2, "dq"); close(dk, kr.grad, 2e-2, "dk"); close(dv, vr.grad, 2e-2, "dv")
+    # atol: with one key the exact dq / dk are 0 (dP == delta); fp32 summation order leaves ~1e-8 on O(1) operands
+    close(dq, qr.grad, 2e-2, "dq", atol=1e-6); close(dk, kr.grad, 2e-2, "dk", atol=1e-6); close(dv, vr.grad, 2e-2, "dv")
 
 
 def test_attention_forced_rescale_branch():

@@ -431,30 +431,49 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
 
 // ------------------------------------------------------------------------------ delta
 // delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d]
+// One wave = 64 consecutive queries of one (b, head): eight lanes share a row (16 bytes of O and dO each: whole 128-byte
+// lines), eight rows per pass, eight passes; the row sums are rotated so that lane L ends up owning query L and the two
+// outputs (delta, lse in log2 units) are written as 256 contiguous bytes.  HBM-bound: 2 * B * Tq * D * 2 bytes.
 __global__ __launch_bounds__(256) void attn_delta_kernel(AttnP p) {
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  const long total = (long)p.B * p.Tq * p.H;
-  if (idx >= total) return;
-  const int hd = (int)(idx % p.H);
-  const long bq = idx / p.H;
-  const int qi = (int)(bq % p.Tq);
-  const int b = (int)(bq / p.Tq);
-  const unsigned short* orow = p.o + (long)b * p.o_bs + (long)qi * p.ldo + hd * 64;
-  const unsigned short* drow = p.d_o + (long)b * p.do_bs + (long)qi * p.lddo + hd * 64;
-  float s = 0.f;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nqb = (p.Tq + 255) >> 8;
+  const int qb = blockIdx.x % nqb;
+  const int hd = (blockIdx.x / nqb) % p.H;
+  const int b = blockIdx.x / (nqb * p.H);
+  const int q0 = qb * 256 + wave * 64;
+  if (q0 >= p.Tq) return;
+  const int sub = lane >> 3, c = lane & 7;
+  const unsigned short* ob = p.o + (long)b * p.o_bs + hd * 64 + c * 8;
+  const unsigned short* db = p.d_o + (long)b * p.do_bs + hd * 64 + c * 8;
+  u32x4 av[8], dv[8];
 #pragma unroll
-  for (int cidx = 0; cidx < 8; ++cidx) {
-    const u32x4 a = *(const u32x4*)(orow + cidx * 8);
-    const u32x4 d = *(const u32x4*)(drow + cidx * 8);
+  for (int it = 0; it < 8; ++it) {
+    int q = q0 + sub * 8 + it;
+    q = q < p.Tq ? q : p.Tq - 1;
+    av[it] = *(const u32x4*)(ob + (long)q * p.ldo);
+    dv[it] = *(const u32x4*)(db + (long)q * p.lddo);
+  }
+  float mine = 0.f;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    float s = 0.f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      s += bf2f((unsigned short)(a[e] & 0xffff)) * bf2f((unsigned short)(d[e] & 0xffff));
-      s += bf2f((unsigned short)(a[e] >> 16)) * bf2f((unsigned short)(d[e] >> 16));
+      s += bf2f((unsigned short)(av[it][e] & 0xffff)) * bf2f((unsigned short)(dv[it][e] & 0xffff));
+      s += bf2f((unsigned short)(av[it][e] >> 16)) * bf2f((unsigned short)(dv[it][e] >> 16));
     }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (c == it) mine = s;  // lane (sub, c) keeps row sub * 8 + c = its own lane number
   }
-  const long sidx = ((long)b * p.H + hd) * p.Tq + qi;
-  p.delta[sidx] = s;
-  p.delta[total + sidx] = p.lse[sidx] * LOG2E;  // second half of the workspace: lse in log2 units, staged by LDS-DMA in dK/dV
+  const int q = q0 + lane;
+  if (q < p.Tq) {
+    const long sidx = ((long)b * p.H + hd) * p.Tq + q;
+    const long total = (long)p.B * p.Tq * p.H;
+    p.delta[sidx] = mine;
+    p.delta[total + sidx] = p.lse[sidx] * LOG2E;  // second half of the workspace: lse in log2 units, staged by LDS-DMA in dK/dV
+  }
 }
 
 // ------------------------------------------------------------------------------ dQ
@@ -830,8 +849,7 @@ extern "C" int wft_attn_bwd_bf16(const wft_attn_args* a, void* stream) {
     p.cs_v = a->colsum_ws + (long)a->B * ((a->Tq + 31) / 32) * a->H * 64;
   }
   hipStream_t s = (hipStream_t)stream;
-  const long total = (long)a->B * a->Tq * a->H;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)(((a->Tq + 255) / 256) * a->H * a->B)), dim3(256), 0, s, p);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(((a->Tq + 127) / 128) * a->H * a->B)), dim3(256), 0, s, p);
   hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3((unsigned)(((a->Tk + 127) / 128) * a->H * a->B)), dim3(256), 0, s, p);
   if (p.cs_q) {
