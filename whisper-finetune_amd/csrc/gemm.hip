@@ -1013,12 +1013,6 @@ extern "C" int wft_gemm_nt_bf16(const wft_gemm_args* a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   // big, 256-aligned-N problems go to the 256x256 kernel (one workgroup per CU, 128 KiB LDS)
   const bool big = nt_uses_256(a);
-#if 0
-  const bool wide_ok = a->c_is_f32 || (a->ldc % 8 == 0 && (!a->residual || (a->ldr % 8 == 0 && ((uintptr_t)a->residual & 15) == 0)) &&
-                                       (!a->aux || (a->ldaux % 8 == 0 && ((uintptr_t)a->aux & 15) == 0)) &&
-                                       (!a->bias || ((uintptr_t)a->bias & 15) == 0));
-  const bool big_unused = false;
-#endif
   const bool cs_fused = a->colsum && big && !a->c_is_f32 && a->batch == 1 && a->workspace &&
                         a->workspace_bytes >= wft_gemm_nt_colsum_workspace_bytes(a);
   if (a->colsum) {
@@ -1026,7 +1020,6 @@ extern "C" int wft_gemm_nt_bf16(const wft_gemm_args* a, void* stream) {
     if (cs_fused) p.cs_part = (float*)a->workspace;
   }
   if (big) {
-    static bool attr_done = false;
     const long t256 = ((a->M + 255) / 256) * (a->N / 256) * a->batch;
     const int ncu = wft_num_cus();
     // persistent (one workgroup per CU walks the tiles, prefetching across tile seams) unless WFT_NT256_PERSISTENT=0: with
@@ -1040,7 +1033,6 @@ extern "C" int wft_gemm_nt_bf16(const wft_gemm_args* a, void* stream) {
     if (!done) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 163840); done = true; } \
     hipLaunchKernelGGL(kfn, grid, block, 163840, s, p);                                                   \
   } while (0)
-    (void)attr_done;
     switch (a->epilogue) {
       case WFT_EPI_NONE: if (a->c_is_f32) LAUNCH_256(WFT_EPI_NONE, true); else LAUNCH_256(WFT_EPI_NONE, false); break;
       case WFT_EPI_GELU: if (a->c_is_f32) LAUNCH_256(WFT_EPI_GELU, true); else LAUNCH_256(WFT_EPI_GELU, false); break;
