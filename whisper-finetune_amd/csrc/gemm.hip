@@ -12,6 +12,7 @@
 // MFMA operands are swapped (D^T = B·A^T) so that each lane ends up with 4 consecutive
 // output columns of one row: 8-byte bf16 / 16-byte f32 stores.
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 struct GemmP {
@@ -207,6 +208,31 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
 // half-periods) ahead behind a COUNTED s_waitcnt vmcnt(8): never drained inside the loop.
 __device__ __forceinline__ int nt_g(int row) { return (4 - ((row >> 2) & 3)) & 3; }  // 64-byte-row swizzle
 
+// s_waitcnt for row h of the NT256 epilogue's register ring in its COUNTED body (the asm ties the wait to the registers it
+// guards; there is exactly one such statement per half-pass, on no branch).  Vector-memory operations younger than row h's
+// load when half-pass h starts — ST stores per half-pass, one ring load per row issued at the end of half-pass h - PF (rows
+// 0 .. PF-1 in a prologue), D = 12 LDS-DMA pieces of the next tile issued at the end of half-pass 0:
+//   h = 0     : rows 1 .. PF-1
+//   0 < h < PF: rows h+1 .. PF-1, then ST + 1 per half-pass before h, + D
+//   h = PF    : D (its load precedes them in half-pass 0), then ST + 1 for half-passes 1 .. PF-1
+//   h > PF    : half-passes h-PF+1 .. h-1: ST, + 1 while rows remain (j + PF < 16)
+template <int ST, int PF>
+__device__ __forceinline__ void nt_wait_ring(int h, u32x4& q) {
+  constexpr int D = 12;
+  int n = 0;
+  if (h == 0) n = PF - 1;
+  else if (h < PF) n = (PF - 1 - h) + h * (ST + 1) + D;
+  else if (h == PF) n = D + (PF - 1) * (ST + 1);
+  else for (int j = h - PF + 1; j < h; ++j) n += ST + (j + PF < 16 ? 1 : 0);
+#define WFT_VM_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(q) :: "memory"); break;
+  switch (n) {  // h is a compile-time constant after unrolling: one case survives
+    WFT_VM_CASE(3) WFT_VM_CASE(4) WFT_VM_CASE(5) WFT_VM_CASE(6) WFT_VM_CASE(7) WFT_VM_CASE(8) WFT_VM_CASE(9)
+    WFT_VM_CASE(16) WFT_VM_CASE(17) WFT_VM_CASE(18) WFT_VM_CASE(19) WFT_VM_CASE(20) WFT_VM_CASE(21)
+    default: asm volatile("s_waitcnt vmcnt(0)" : "+v"(q) :: "memory"); break;
+  }
+#undef WFT_VM_CASE
+}
+
 template <int EPI, bool C_F32>
 __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char dsmem[];  // 128 KiB ring + 32 KiB epilogue staging
@@ -328,19 +354,41 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
     if (!grp_b) __builtin_amdgcn_s_barrier();  // group A idles through group B's last C-unit
 
     // the ring is free: put the next tile's first three slabs in flight, then write this tile out
-    if (t + (int)gridDim.x < total) {
+    const bool more = t + (int)gridDim.x < total;
+    const bool staged = !C_F32 && p.diag != 6;
+    constexpr bool RD_AUX = (EPI == WFT_EPI_DGELU || EPI == WFT_EPI_MUL_AUX);
+    constexpr bool PF_RES = (EPI == WFT_EPI_NONE || EPI == WFT_EPI_GELU);  // the others (no residual in practice) read it in place: registers
+    // COUNTED epilogue body: every vector-memory instruction it issues is known (all 128 rows of the wave valid -> every
+    // lane active in every half-pass; one ring load per row; EPI_ST stores per half-pass; 12 LDS-DMA pieces after half-pass 0)
+    const bool counted = staged && EPI != WFT_EPI_GELU && m0 + wm * 128 + 128 <= p.M && (PF_RES || !p.res) &&
+                         nslab >= 3 && p.diag != 7;
+    if (more && !counted) {
       set_src(t + gridDim.x);
       prefetch();
     }
 
     const long cb = (long)bz * p.sC;
-    if (!C_F32 && p.diag != 6) {
+    if (staged) {
       // ---- epilogue through the 32 KiB of LDS above the ring (4 KiB per wave, one 16-row m-tile per pass,
       // XOR-swizzled 16-byte chunks): every global access below is 16 bytes per lane, 8 lanes = one full
       // 128-byte line (bias / residual / aux / C) instead of 8-byte pieces of 16 different lines.
+      //
+      // Residual / aux rows are fetched EPI_PF half-passes ahead of their use into a ring of registers.  In the general
+      // body (CNT = false) hipcc places the waits, and with row masks and `if (p.res)` around the loads it falls back to
+      // vmcnt(0) in front of every use: each of the 16 half-passes drains its own store and the load issued just before
+      // it (in-kernel stamps: 18 us per tile with a residual / aux operand from HBM, 6.5 us store-only, 8.5 us with the
+      // operand served from L2; main loop 30 - 120 us).  The COUNTED body issues the ring loads as inline asm and waits
+      // with hand-counted s_waitcnt vmcnt(N): the counter retires in issue order (loads, stores, LDS-DMA alike), so "at
+      // most N younger operations outstanding" is exact when every operation of the body is known.  The two bodies are
+      // separate copies of the code: a register that an asm load is still filling must never be copied, and a wait that
+      // exists on one side of a branch only makes hipcc copy the ring at the join.
       char* lds = dsmem + 131072 + wave * 4096;
       const int er = lane >> 3, ec = (lane & 7) * 8;  // row within an 8-row group, first of this lane's 8 columns
       const int ncol = n0 + wn * 64 + ec;
+      auto body = [&](auto cnt_c) {
+      constexpr bool CNT = decltype(cnt_c)::value;
+      constexpr int EPI_PF = 4;  // 6 and 8 spill beside the 128 accumulator registers
+      constexpr int EPI_ST = (EPI == WFT_EPI_GELU || EPI == WFT_EPI_GELU_GRAD) ? 2 : 1;  // stores per half-pass (GELU: with aux)
       float bias8[8], cs8[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) { bias8[e] = 0.f; cs8[e] = 0.f; }
@@ -349,17 +397,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
       }
-      // residual / aux rows are fetched EPI_PF half-passes ahead of their use (a ring of registers): issued one at a time
-      // where they are consumed, each of the 16 half-passes of a tile paid a full memory latency with nothing to cover it.
-      // 4 is what fits beside the 128 accumulator registers (6 and 8 spill; a distance that grows as passes hand their
-      // accumulators back spills more: hipcc does not reuse them for the loads).
-      constexpr int EPI_PF = 4;
-      constexpr bool RD_AUX = (EPI == WFT_EPI_DGELU || EPI == WFT_EPI_MUL_AUX);
-      constexpr bool PF_RES = (EPI == WFT_EPI_NONE || EPI == WFT_EPI_GELU);  // the others (no residual in practice) read it in place: registers
+      const bool ring = RD_AUX || (PF_RES && p.res);
       u32x4 auxq[EPI_PF], resq[EPI_PF];
       auto fetch_row = [&](int h, int slot) {
         const int m = m0 + wm * 128 + (h >> 1) * 16 + (h & 1) * 8 + er;
-        if (m < p.M) {
+        if (CNT) {  // every row valid
+          if (RD_AUX) {
+            const unsigned short* src = p.aux + (long)bz * p.sAux + (long)m * p.ldaux + ncol;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(auxq[slot]) : "v"(src) : "memory");
+          } else if (PF_RES && p.res) {
+            const unsigned short* src = p.res + (long)bz * p.sR + (long)m * p.ldr + ncol;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(resq[slot]) : "v"(src) : "memory");
+          }
+        } else if (m < p.M) {
           if (RD_AUX) auxq[slot] = *(const u32x4*)(p.aux + (long)bz * p.sAux + (long)m * p.ldaux + ncol);
           if (PF_RES && p.res) resq[slot] = *(const u32x4*)(p.res + (long)bz * p.sR + (long)m * p.ldr + ncol);
         }
@@ -374,13 +424,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int g8 = 0; g8 < 2; ++g8) {
+          const int h = i * 2 + g8;
           const int lr = g8 * 8 + er;
           const int m = m0 + wm * 128 + i * 16 + lr;
           const int ch = (lane & 7) * 2;
-          const int slot = (i * 2 + g8) % EPI_PF;
+          const int slot = h % EPI_PF;
           const f32x4 x0 = *(const f32x4*)(lds + lr * 256 + ((ch ^ lr) << 4));
           const f32x4 x1 = *(const f32x4*)(lds + lr * 256 + (((ch + 1) ^ lr) << 4));
-          if (m < p.M) {
+          if (CNT && ring) nt_wait_ring<EPI_ST, EPI_PF>(h, RD_AUX ? auxq[slot] : resq[slot]);
+          if (CNT || m < p.M) {
             float v[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] = x0[e] * p.alpha + bias8[e]; v[4 + e] = x1[e] * p.alpha + bias8[4 + e]; }
@@ -434,24 +486,34 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
               for (int e = 0; e < 8; ++e) cs8[e] += v[e];
             }
           }
-          if (i * 2 + g8 + EPI_PF < 16) fetch_row(i * 2 + g8 + EPI_PF, slot);
+          if (h + EPI_PF < 16) fetch_row(h + EPI_PF, slot);
+          if (CNT && h == 0) {  // the next tile's slabs (or, on the last tile, this tile's again: the count must not depend on it)
+            set_src(more ? t + (int)gridDim.x : t);
+            prefetch();
+          }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
       if (p.cs_part) {  // column sums of this wave's 128 x 64 block: reduce over the 8 row-lanes, lanes 0-7 store 8 columns each
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          float t = cs8[e];
-          t += __shfl_xor(t, 8, 64);
-          t += __shfl_xor(t, 16, 64);
-          t += __shfl_xor(t, 32, 64);
-          cs8[e] = t;
+          float t2 = cs8[e];
+          t2 += __shfl_xor(t2, 8, 64);
+          t2 += __shfl_xor(t2, 16, 64);
+          t2 += __shfl_xor(t2, 32, 64);
+          cs8[e] = t2;
         }
         if (lane < 8) {
           float* dstp = p.cs_part + (long)(tm * 2 + wm) * p.N + ncol;
           *(f32x4*)dstp = f32x4{cs8[0], cs8[1], cs8[2], cs8[3]};
           *(f32x4*)(dstp + 4) = f32x4{cs8[4], cs8[5], cs8[6], cs8[7]};
         }
+      }
+      };  // body
+      if constexpr (EPI == WFT_EPI_GELU) {  // (conv stem / inference only: its counted copy spills)
+        body(std::false_type{});
+      } else {
+        if (counted) body(std::true_type{}); else body(std::false_type{});
       }
       continue;
     }
