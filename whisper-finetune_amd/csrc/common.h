@@ -45,8 +45,12 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
   __bf16 b = (__bf16)f;
   return __builtin_bit_cast(unsigned short, b);
 }
+// two floats -> packed bf16 pair as ONE v_cvt_pk_bf16_f32 (the two scalar casts + shift + or compile to four instructions)
+typedef __attribute__((ext_vector_type(2))) float wft_f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 wft_bf16x2_t;
 __device__ __forceinline__ unsigned int pack2bf(float lo, float hi) {
-  return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
+  const wft_f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, wft_bf16x2_t));
 }
 
 // ---- wave64 reductions

@@ -13,6 +13,9 @@
 // output columns of one row: 8-byte bf16 / 16-byte f32 stores.
 #include "common.h"
 #include <type_traits>
+#ifndef WFT_EPI_PF_CNT
+#define WFT_EPI_PF_CNT 4
+#endif
 #include <stdlib.h>
 
 struct GemmP {
@@ -226,8 +229,7 @@ __device__ __forceinline__ void nt_wait_ring(int h, u32x4& q) {
   else for (int j = h - PF + 1; j < h; ++j) n += ST + (j + PF < 16 ? 1 : 0);
 #define WFT_VM_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(q) :: "memory"); break;
   switch (n) {  // h is a compile-time constant after unrolling: one case survives
-    WFT_VM_CASE(3) WFT_VM_CASE(4) WFT_VM_CASE(5) WFT_VM_CASE(6) WFT_VM_CASE(7) WFT_VM_CASE(8) WFT_VM_CASE(9)
-    WFT_VM_CASE(16) WFT_VM_CASE(17) WFT_VM_CASE(18) WFT_VM_CASE(19) WFT_VM_CASE(20) WFT_VM_CASE(21)
+    WFT_VM_CASE(1) WFT_VM_CASE(2) WFT_VM_CASE(3) WFT_VM_CASE(4) WFT_VM_CASE(5) WFT_VM_CASE(6) WFT_VM_CASE(7) WFT_VM_CASE(8) WFT_VM_CASE(9) WFT_VM_CASE(10) WFT_VM_CASE(11) WFT_VM_CASE(12) WFT_VM_CASE(13) WFT_VM_CASE(14) WFT_VM_CASE(15) WFT_VM_CASE(16) WFT_VM_CASE(17) WFT_VM_CASE(18) WFT_VM_CASE(19) WFT_VM_CASE(20) WFT_VM_CASE(21) WFT_VM_CASE(22) WFT_VM_CASE(23) WFT_VM_CASE(24) WFT_VM_CASE(25) WFT_VM_CASE(26) WFT_VM_CASE(27) WFT_VM_CASE(28) WFT_VM_CASE(29) WFT_VM_CASE(30) WFT_VM_CASE(31) WFT_VM_CASE(32) WFT_VM_CASE(33) WFT_VM_CASE(34) WFT_VM_CASE(35) WFT_VM_CASE(36) WFT_VM_CASE(37) WFT_VM_CASE(38) WFT_VM_CASE(39) WFT_VM_CASE(40)
     default: asm volatile("s_waitcnt vmcnt(0)" : "+v"(q) :: "memory"); break;
   }
 #undef WFT_VM_CASE
@@ -387,7 +389,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
       const int ncol = n0 + wn * 64 + ec;
       auto body = [&](auto cnt_c) {
       constexpr bool CNT = decltype(cnt_c)::value;
-      constexpr int EPI_PF = 4;  // 6 and 8 spill beside the 128 accumulator registers
+      constexpr int EPI_PF = CNT ? WFT_EPI_PF_CNT : 4;  // general body: 6 and 8 spill beside the 128 accumulator registers
       constexpr int EPI_ST = (EPI == WFT_EPI_GELU || EPI == WFT_EPI_GELU_GRAD) ? 2 : 1;  // stores per half-pass (GELU: with aux)
       float bias8[8], cs8[8];
 #pragma unroll
@@ -398,15 +400,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
         for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
       }
       const bool ring = RD_AUX || (PF_RES && p.res);
+      // row er of this wave's block; later rows = + h * 8 * ld, a wave-uniform step (no 64-bit multiply per access)
+      const long row0 = (long)(m0 + wm * 128 + er);
+      unsigned short* const c_row0 = (unsigned short*)p.C + cb + row0 * p.ldc + ncol;
+      unsigned short* const aux_row0 = p.aux ? p.aux + (long)bz * p.sAux + row0 * p.ldaux + ncol : nullptr;
+      const unsigned short* const res_row0 = p.res ? p.res + (long)bz * p.sR + row0 * p.ldr + ncol : nullptr;
       u32x4 auxq[EPI_PF], resq[EPI_PF];
       auto fetch_row = [&](int h, int slot) {
         const int m = m0 + wm * 128 + (h >> 1) * 16 + (h & 1) * 8 + er;
         if (CNT) {  // every row valid
           if (RD_AUX) {
-            const unsigned short* src = p.aux + (long)bz * p.sAux + (long)m * p.ldaux + ncol;
+            const unsigned short* src = aux_row0 + (long)(h * 8) * p.ldaux;
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(auxq[slot]) : "v"(src) : "memory");
           } else if (PF_RES && p.res) {
-            const unsigned short* src = p.res + (long)bz * p.sR + (long)m * p.ldr + ncol;
+            const unsigned short* src = res_row0 + (long)(h * 8) * p.ldr;
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(resq[slot]) : "v"(src) : "memory");
           }
         } else if (m < p.M) {
@@ -462,7 +469,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) gelu_both_f(v[e], v[e], dv[e]);
               u32x4 pk = {pack2bf(dv[0], dv[1]), pack2bf(dv[2], dv[3]), pack2bf(dv[4], dv[5]), pack2bf(dv[6], dv[7])};
-              *(u32x4*)(p.aux + (long)bz * p.sAux + roff * p.ldaux + ncol) = pk;
+              if (CNT) *(u32x4*)(aux_row0 + (long)(h * 8) * p.ldaux) = pk;
+              else *(u32x4*)(p.aux + (long)bz * p.sAux + roff * p.ldaux + ncol) = pk;
             } else if (EPI == WFT_EPI_MUL_AUX) {
               const u32x4 a4 = auxq[slot];
 #pragma unroll
@@ -480,7 +488,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
               for (int e = 0; e < 8; ++e) v[e] = 0.f;
             }
             u32x4 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
-            *(u32x4*)((unsigned short*)p.C + cb + roff * p.ldc + ncol) = pk;
+            if (CNT) *(u32x4*)(c_row0 + (long)(h * 8) * p.ldc) = pk;
+            else *(u32x4*)((unsigned short*)p.C + cb + roff * p.ldc + ncol) = pk;
             if (p.cs_part) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) cs8[e] += v[e];
