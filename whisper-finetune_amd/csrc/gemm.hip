@@ -399,7 +399,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
       }
-      const bool ring = RD_AUX || (PF_RES && p.res);
+      // (the counted body of an epilogue that reads the residual in place is only entered without a residual)
+      const bool has_res = (CNT && !PF_RES) ? false : (p.res != nullptr);
+      const bool ring = RD_AUX || (PF_RES && has_res);
       // row er of this wave's block; later rows = + h * 8 * ld, a wave-uniform step (no 64-bit multiply per access)
       const long row0 = (long)(m0 + wm * 128 + er);
       unsigned short* const c_row0 = (unsigned short*)p.C + cb + row0 * p.ldc + ncol;
@@ -412,13 +414,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
           if (RD_AUX) {
             const unsigned short* src = aux_row0 + (long)(h * 8) * p.ldaux;
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(auxq[slot]) : "v"(src) : "memory");
-          } else if (PF_RES && p.res) {
+          } else if (PF_RES && has_res) {
             const unsigned short* src = res_row0 + (long)(h * 8) * p.ldr;
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(resq[slot]) : "v"(src) : "memory");
           }
         } else if (m < p.M) {
           if (RD_AUX) auxq[slot] = *(const u32x4*)(p.aux + (long)bz * p.sAux + (long)m * p.ldaux + ncol);
-          if (PF_RES && p.res) resq[slot] = *(const u32x4*)(p.res + (long)bz * p.sR + (long)m * p.ldr + ncol);
+          if (PF_RES && has_res) resq[slot] = *(const u32x4*)(p.res + (long)bz * p.sR + (long)m * p.ldr + ncol);
         }
       };
 #pragma unroll
@@ -445,8 +447,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
             for (int e = 0; e < 4; ++e) { v[e] = x0[e] * p.alpha + bias8[e]; v[4 + e] = x1[e] * p.alpha + bias8[4 + e]; }
             const long roff = (long)m;
             u32x4 r4 = resq[slot];
-            if (!PF_RES && p.res) r4 = *(const u32x4*)(p.res + (long)bz * p.sR + roff * p.ldr + ncol);
-            if (p.res && p.res_first) {
+            if (!PF_RES && has_res) r4 = *(const u32x4*)(p.res + (long)bz * p.sR + roff * p.ldr + ncol);
+            if (has_res && p.res_first) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) { v[2 * e] += p.beta * bf2f((unsigned short)(r4[e] & 0xffff)); v[2 * e + 1] += p.beta * bf2f((unsigned short)(r4[e] >> 16)); }
             }
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
                 v[2 * e + 1] *= bf2f((unsigned short)(a4[e] >> 16));
               }
             }
-            if (p.res && !p.res_first) {
+            if (has_res && !p.res_first) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) { v[2 * e] += p.beta * bf2f((unsigned short)(r4[e] & 0xffff)); v[2 * e + 1] += p.beta * bf2f((unsigned short)(r4[e] >> 16)); }
             }
