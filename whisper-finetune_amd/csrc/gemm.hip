@@ -214,18 +214,13 @@ __device__ __forceinline__ int nt_g(int row) { return (4 - ((row >> 2) & 3)) & 3
 // s_waitcnt for row h of the NT256 epilogue's register ring in its COUNTED body (the asm ties the wait to the registers it
 // guards; there is exactly one such statement per half-pass, on no branch).  Vector-memory operations younger than row h's
 // load when half-pass h starts — ST stores per half-pass, one ring load per row issued at the end of half-pass h - PF (rows
-// 0 .. PF-1 in a prologue), D = 12 LDS-DMA pieces of the next tile issued at the end of half-pass 0:
-//   h = 0     : rows 1 .. PF-1
-//   0 < h < PF: rows h+1 .. PF-1, then ST + 1 per half-pass before h, + D
-//   h = PF    : D (its load precedes them in half-pass 0), then ST + 1 for half-passes 1 .. PF-1
-//   h > PF    : half-passes h-PF+1 .. h-1: ST, + 1 while rows remain (j + PF < 16)
+// 0 .. PF-1 in a prologue); the next tile's LDS-DMA pieces are older than all of them (main-loop tail or before the body):
+//   h < PF : rows h+1 .. PF-1, then ST + 1 per half-pass before h
+//   h >= PF: half-passes h-PF+1 .. h-1: ST, + 1 while rows remain (j + PF < 16)
 template <int ST, int PF>
 __device__ __forceinline__ void nt_wait_ring(int h, u32x4& q) {
-  constexpr int D = 12;
   int n = 0;
-  if (h == 0) n = PF - 1;
-  else if (h < PF) n = (PF - 1 - h) + h * (ST + 1) + D;
-  else if (h == PF) n = D + (PF - 1) * (ST + 1);
+  if (h < PF) n = (PF - 1 - h) + h * (ST + 1);
   else for (int j = h - PF + 1; j < h; ++j) n += ST + (j + PF < 16 ? 1 : 0);
 #define WFT_VM_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(q) :: "memory"); break;
   switch (n) {  // h is a compile-time constant after unrolling: one case survives
@@ -322,6 +317,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
     __builtin_amdgcn_s_barrier();
     if (grp_b) __builtin_amdgcn_s_barrier();  // group B runs half a period behind group A
 
+    // CONTINUOUS staging: with another tile to come and nslab % 4 == 0 (slab j of the next tile then belongs in the slot
+    // slab nslab - 4 + j just left), the last three L-units stage the NEXT tile's slabs 0-2 instead of nothing: the 12
+    // LDS-DMA pieces are issued beside the partner group's MFMAs like every other slab, not in the epilogue where both
+    // groups pay their issue cost with nothing to hide it (stamps: 1-2 us per tile), and the waits never drain.
+    const bool more = t + (int)gridDim.x < total;
+    const bool cont = more && (nslab & 3) == 0 && nslab >= 8 && p.diag != 8;
     for (int u = 0; u < nslab; ++u) {
       // ---------------- L-unit (fragment reads first: their latency hides behind the LDS-DMA issue)
       {
@@ -332,12 +333,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
         for (int i = 0; i < 8; ++i) af[i] = *(const bf16x8*)(sl + a_off + i * 1024);
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (u + 3 < nslab) stage(u + 3);
+      if (u + 3 < nslab) {
+        stage(u + 3);
+      } else if (cont) {
+        if (u + 3 == nslab) set_src(t + gridDim.x);  // this tile's source addresses are not needed any more
+        stage(u + 3 - nslab);
+      }
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       // slab u+1's share (issued three L-units ago) must have landed before the partner group reads it
       const int ahead = nslab - 1 - u;
-      if (ahead >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      if (ahead >= 3 || cont) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else if (ahead == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -356,15 +362,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
     if (!grp_b) __builtin_amdgcn_s_barrier();  // group A idles through group B's last C-unit
 
     // the ring is free: put the next tile's first three slabs in flight, then write this tile out
-    const bool more = t + (int)gridDim.x < total;
     const bool staged = !C_F32 && p.diag != 6;
     constexpr bool RD_AUX = (EPI == WFT_EPI_DGELU || EPI == WFT_EPI_MUL_AUX);
     constexpr bool PF_RES = (EPI == WFT_EPI_NONE || EPI == WFT_EPI_GELU);  // the others (no residual in practice) read it in place: registers
     // COUNTED epilogue body: every vector-memory instruction it issues is known (all 128 rows of the wave valid -> every
-    // lane active in every half-pass; one ring load per row; EPI_ST stores per half-pass; 12 LDS-DMA pieces after half-pass 0)
-    const bool counted = staged && EPI != WFT_EPI_GELU && m0 + wm * 128 + 128 <= p.M && (PF_RES || !p.res) &&
-                         nslab >= 3 && p.diag != 7;
-    if (more && !counted) {
+    // lane active in every half-pass; one ring load per row; EPI_ST stores per half-pass)
+    const bool counted = staged && EPI != WFT_EPI_GELU && m0 + wm * 128 + 128 <= p.M && (PF_RES || !p.res) && p.diag != 7;
+    if (more && !cont) {  // (older than everything the epilogue issues: outside its counts)
       set_src(t + gridDim.x);
       prefetch();
     }
@@ -498,10 +502,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
             }
           }
           if (h + EPI_PF < 16) fetch_row(h + EPI_PF, slot);
-          if (CNT && h == 0) {  // the next tile's slabs (or, on the last tile, this tile's again: the count must not depend on it)
-            set_src(more ? t + (int)gridDim.x : t);
-            prefetch();
-          }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
