@@ -32,7 +32,7 @@ struct GemmP {
   int res_first;
   float* ws;  // split-K partial tiles [nsplit][P][Q] fp32 (TN, optional)
   float* cs_part;  // NT256: per-(row tile, wave row) column-sum partials [2*tiles_m][N] fp32, or NULL
-  int diag;  // timing-only diagnostic builds of the 256 kernel (WFT_GEMM_DIAG): 1 no vmcnt wait, 2 no staging loads, 3 = 2 + no barrier
+  int diag;  // WFT_GEMM_DIAG, NT256 A/B switches: 6 skips the staged epilogue (timing only), 7 = general epilogue body everywhere, 8 = no continuous staging
 };
 
 // sid -> (row tile, column tile) in column BANDS of 5 tiles, row-major inside a band: the 32 workgroups an XCD
