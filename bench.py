@@ -66,7 +66,7 @@ def pmc_traffic_per_launch(batch: int):
     being --kernel-trace).  FETCH_SIZE is in KiB and counts 64 B per 128-B request on gfx950 for 16-B/lane streaming
     reads, so it is doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE (KiB) is exact.  Counters cannot be
     collected inside the timed run, so the value is only reported when the committed pass used the same batch."""
-    path = ROOT / "profiles" / "r01_e_pmc_summary.json"
+    path = ROOT / "profiles" / "r01_f_pmc_summary.json"
     if not path.exists():
         return None, "no PMC summary committed"
     d = json.loads(path.read_text())
@@ -80,7 +80,7 @@ def pmc_traffic_per_launch(batch: int):
             n += v["launches"]
     if n == 0:
         return None, "kernel not in the PMC summary"
-    return round(tot / n), "profiles/r01_e_pmc_summary.json: (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch, separate --pmc passes"
+    return round(tot / n), "profiles/r01_f_pmc_summary.json: (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch, separate --pmc passes"
 
 
 def build_model(name: str, device, sd_p: float = 0.0):
