@@ -434,7 +434,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
           *(f32x4*)(lds + frow * 256 + (((jj * 4 + fg) ^ frow) << 4)) = acc[i][jj];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // A wave's LDS instructions execute in order: the reads below see these writes, and the next pass's writes cannot
+        // overtake the reads, so the COUNTED body needs no wait between them — it issues the four reads of both half-passes
+        // at once and lets hipcc place one counted lgkmcnt wait in front of their first use (one LDS round trip per pass
+        // instead of three; two waves per SIMD cannot hide them).  The general body keeps the explicit fences.
+        if (!CNT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        f32x4 xa[2], xb[2];
+        if (CNT) {
+#pragma unroll
+          for (int g8 = 0; g8 < 2; ++g8) {
+            const int lr = g8 * 8 + er, ch = (lane & 7) * 2;
+            xa[g8] = *(const f32x4*)(lds + lr * 256 + ((ch ^ lr) << 4));
+            xb[g8] = *(const f32x4*)(lds + lr * 256 + (((ch + 1) ^ lr) << 4));
+          }
+        }
 #pragma unroll
         for (int g8 = 0; g8 < 2; ++g8) {
           const int h = i * 2 + g8;
@@ -442,8 +455,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
           const int m = m0 + wm * 128 + i * 16 + lr;
           const int ch = (lane & 7) * 2;
           const int slot = h % EPI_PF;
-          const f32x4 x0 = *(const f32x4*)(lds + lr * 256 + ((ch ^ lr) << 4));
-          const f32x4 x1 = *(const f32x4*)(lds + lr * 256 + (((ch + 1) ^ lr) << 4));
+          const f32x4 x0 = CNT ? xa[g8] : *(const f32x4*)(lds + lr * 256 + ((ch ^ lr) << 4));
+          const f32x4 x1 = CNT ? xb[g8] : *(const f32x4*)(lds + lr * 256 + (((ch + 1) ^ lr) << 4));
           if (CNT && ring) nt_wait_ring<EPI_ST, EPI_PF>(h, RD_AUX ? auxq[slot] : resq[slot]);
           if (CNT || m < p.M) {
             float v[8];
@@ -503,7 +516,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
           }
           if (h + EPI_PF < 16) fetch_row(h + EPI_PF, slot);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!CNT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
       if (p.cs_part) {  // column sums of this wave's 128 x 64 block: reduce over the 8 row-lanes, lanes 0-7 store 8 columns each
 #pragma unroll
