@@ -99,6 +99,31 @@ def test_gemm_nt_and_epilogues(M, N, Kd):
     close(K.gemm_nt(ad, bd, epilogue=L.EPI_MUL_AUX, aux=dact), ref * dact.float().cpu(), 1e-2, "mul aux")
 
 
+@pytest.mark.parametrize("M,N,Kd", [(70001, 1280, 128), (20000, 2560, 256), (33000, 1280, 1280)])
+def test_gemm_nt_persistent_epilogues_counted_waits(M, N, Kd):
+    """More tiles than CUs (persistent workgroups, continuous staging across tile seams), with the residual / aux operands
+    whose rows the epilogue fetches ahead by inline-asm loads behind hand-counted s_waitcnt (gemm.hip, COUNTED body), and
+    a ragged last row tile (general body): results against fp32 torch, and bit-identical over repeats (a miscounted wait
+    or a seam race shows up as run-to-run differences)."""
+    g = torch.Generator().manual_seed(M)
+    a = bf(torch.randn(M, Kd, generator=g)).to(DEV); b = bf(torch.randn(N, Kd, generator=g) * 0.05).to(DEV)
+    res = bf(torch.randn(M, N, generator=g)).to(DEV); aux = bf(torch.randn(M, N, generator=g)).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    ref = a.float() @ b.float().t()
+    cases = {
+        "bias+res": (lambda: K.gemm_nt(a, b, bias=bias, residual=res), ref + bias + res.float()),
+        "res beta": (lambda: K.gemm_nt(a, b, residual=res, beta=0.5), ref + 0.5 * res.float()),
+        "mul aux + colsum": (lambda: K.gemm_nt(a, b, epilogue=L.EPI_MUL_AUX, aux=aux, colsum=torch.empty(N, device=DEV)), ref * aux.float()),
+        "gelu_grad": (lambda: K.gemm_nt(a, b, bias=bias, epilogue=L.EPI_GELU_GRAD, aux=torch.empty_like(res)),
+                      torch.nn.functional.gelu(ref + bias)),
+    }
+    for name, (fn, want) in cases.items():
+        first = fn()
+        close(first, want, 1e-2, name)
+        for _ in range(3):
+            assert torch.equal(fn(), first), f"{name}: not reproducible"
+
+
 def test_gemm_nt_rejects_bad_shapes():
     a = torch.zeros(10, 70, dtype=torch.bfloat16, device=DEV)
     with pytest.raises(L.WftError, match="K must be a multiple of 64"):
