@@ -228,7 +228,14 @@ def test_lora_structure_and_merge():
     torch.testing.assert_close(q.weight, expect)
     assert lora.is_lora_enabled(m)
     stats = lora.get_lora_debug_stats(m)
-    assert stats["param_name"].startswith("decoder.blocks.0.cross_attn.query")
+    # the reference's scan (model/lora.py:152-171) reports A of the FIRST adapter and B of the pattern match — checked by
+    # running the reference's own get_lora_debug_stats / LoRAUpdateTracker on this model in the build container
+    assert stats["param_name"] == "encoder.blocks.0.attn.query.parametrizations.weight.0"
+    tr = lora.LoRAUpdateTracker(m)
+    assert tr.A_name == "encoder.blocks.0.attn.query.parametrizations.weight.0.lora_A"
+    assert tr.B_name == "decoder.blocks.0.cross_attn.query.parametrizations.weight.0.lora_B"
+    tr.snapshot()
+    assert tr.get_update_norms() == {"delta_A_norm": 0.0, "delta_B_norm": 0.0}
     lora.merge_lora(m)
     assert not lora.is_lora_enabled(m)
     torch.testing.assert_close(m.decoder.blocks[0].cross_attn.query.weight, expect, atol=1e-5, rtol=0)

@@ -1,6 +1,6 @@
 """Developer script (not collected by pytest): exercises every libwft kernel on the GPU
 against torch fp32 math and prints error / timing tables.  Run on the GPU box:
-    python tests/dev_kernels.py [--perf]
+    python tools/dev_kernels.py [--perf]
 """
 import math
 import sys

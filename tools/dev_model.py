@@ -1,5 +1,5 @@
 """Developer script (GPU box): whole-model parity of the libwft engine against the CPU oracle
-(tiny dims), then a first large-v3 step timing.   python tests/dev_model.py [--perf]"""
+(tiny dims), then a first large-v3 step timing.   python tools/dev_model.py [--perf]"""
 import sys
 import time
 from pathlib import Path

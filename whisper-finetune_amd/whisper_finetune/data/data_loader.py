@@ -18,45 +18,121 @@ import torch
 from torch.nn.utils.rnn import pad_sequence
 from torch.utils.data import DataLoader, Dataset
 
-from whisper_finetune.data.gpu_frontend import HOP_LENGTH, N_FRAMES, N_SAMPLES, GpuFrontend, draw_mask_span
+from whisper_finetune.data import transforms as T
+from whisper_finetune.data.gpu_frontend import HOP_LENGTH, N_FFT, N_FRAMES, N_SAMPLES, GpuFrontend, draw_clip_params, mel_filters
+from whisper_finetune.data.utils import ExtremesFrequencyMasking, TimeWarpAugmenter, pad_or_trim
 
 CHUNK_LENGTH = 30
 _TS = re.compile(r"(<\|[123]?[0-9]\.[0-9][0-9]\|>)")  # <|0.00|> .. <|30.00|>
+_FILTERS = {}
+
+
+def log_mel_spectrogram(audio, n_mels: int = 80, padding: int = 0, device=None) -> torch.Tensor:
+    """`whisper.audio.log_mel_spectrogram` (called at data/data_loader.py:278) on the `wft_logmel`
+    kernel: audio f32 [n] (numpy or tensor, n a multiple of 160) -> f32 [n_mels, n/160] on the device.  There is no
+    host implementation: without a GPU this raises (the batched product path is GpuMelLoader below)."""
+    from whisper_finetune.engine import kernels as K
+    from whisper_finetune.engine.lib import WftError
+
+    if not torch.is_tensor(audio):
+        audio = torch.from_numpy(np.asarray(audio, dtype=np.float32))
+    if device is None and not audio.is_cuda:
+        if not torch.cuda.is_available():
+            raise WftError("log_mel_spectrogram runs on the GPU in this build (wft_logmel) and no device is visible")
+        device = torch.device("cuda", torch.cuda.current_device())
+    if device is not None:
+        audio = audio.to(device)
+    if padding > 0:
+        audio = torch.nn.functional.pad(audio, (0, padding))
+    if audio.dim() != 1 or audio.shape[0] % HOP_LENGTH:
+        raise ValueError(f"expected a 1-D clip whose length is a multiple of {HOP_LENGTH}, got {tuple(audio.shape)}")
+    key = (n_mels, audio.device)
+    if key not in _FILTERS:
+        _FILTERS[key] = mel_filters(n_mels).to(audio.device)
+    return K.logmel(audio.float()[None], _FILTERS[key], audio.shape[0] // HOP_LENGTH)[0]
 
 
 class AudioDataset(Dataset):
     """Items: (audio f32 [480000], decoder_input i64, decoder_output i64, aug i32 [8], extremes i32 [2], cut_frames).
 
     hu_dataset: indexable records {"audio": {"array"}, "text", "language", optional "prompt"}; tokenizer: whisper-style
-    (sot, eot, sot_prev, no_timestamps, no_speech, timestamp_begin, special_tokens[...], encode(text, **kw))."""
+    (sot, eot, sot_prev, no_timestamps, no_speech, timestamp_begin, special_tokens[...], encode(text, **kw)).
 
-    def __init__(self, hu_dataset, tokenizer, n_mels: int = 80, no_timestamp_training: bool = False, max_prompt_length: int = 223,
-                 prompt_use_rate: float = 0.5, no_timestamps_rate: float = 0.5, spec_augment: bool = False,
-                 spec_augment_params: Optional[dict] = None, extremes_spec_augment: bool = False,
-                 extremes_spec_augment_params: Optional[dict] = None, bpe_dropout: float = 0.0, device=None, **audio_aug_flags):
-        if any(audio_aug_flags.get(k) for k in ("apply_baseline_aug", "apply_office_aug", "apply_advanced_aug")):
+    Same constructor arguments and attributes as the reference's class (data/data_loader.py:40-160).  `__getitem__`
+    ships the raw clip plus the DRAWN augmentation parameters (the batch is turned into mels on the device by
+    GpuMelLoader); `_calculate_mel` is the reference's per-clip form of the same arithmetic on the same kernels."""
+
+    def __init__(self, hu_dataset, tokenizer, device=None, no_timestamp_training: bool = False, n_mels: int = 80,
+                 max_prompt_length: int = 223, prompt_use_rate: float = 0.5, no_timestamps_rate: float = 0.5,
+                 spec_augment: bool = False, spec_augment_params: Optional[dict] = None, extremes_spec_augment: bool = False,
+                 extremes_spec_augment_params: Optional[dict] = None, apply_baseline_aug: bool = False, apply_office_aug: bool = False,
+                 apply_advanced_aug: bool = False, time_stretch_min_rate: float = 0.8, time_stretch_max_rate: float = 1.25,
+                 bpe_dropout: float = 0.0):
+        if apply_baseline_aug or apply_office_aug or apply_advanced_aug:
             raise NotImplementedError("audio-domain augmentation (model/augment.py) is outside the GPU hot path (SURVEY.md §2)")
-        self.hu_dataset, self.tokenizer, self.n_mels = hu_dataset, tokenizer, n_mels
+        self.hu_dataset, self.tokenizer, self.n_mels, self.device = hu_dataset, tokenizer, n_mels, device
         self.no_timestamp_training = no_timestamp_training
         self.max_prompt_length, self.prompt_use_rate, self.no_timestamps_rate = max_prompt_length, prompt_use_rate, no_timestamps_rate
+        self.spec_augment, self.extremes_spec_augment = spec_augment, extremes_spec_augment
+        self.apply_baseline_aug = self.apply_office_aug = self.apply_advanced_aug = False
+        self.time_stretch_min_rate, self.time_stretch_max_rate = time_stretch_min_rate, time_stretch_max_rate
         self.bpe_dropout = bpe_dropout
-        self.model_n_text_ctx = 448
+        if spec_augment:
+            self.spec_augment_p = float(spec_augment_params.get("p", 1.0))
+            if not 0.0 <= self.spec_augment_p <= 1.0:
+                raise ValueError(f"spec_augment p must be between 0 and 1, got {self.spec_augment_p}")
+            self.time_masking = T.TimeMasking(time_mask_param=spec_augment_params["time_mask_param"])
+            self.freq_masking = T.FrequencyMasking(freq_mask_param=spec_augment_params["freq_mask_param"])
+            self.time_warping = TimeWarpAugmenter(W=spec_augment_params["time_warp_w"])
+        else:
+            self.spec_augment_p = 0.0
+            self.time_masking = self.freq_masking = self.time_warping = None
+        self.extreme_freq_masking = (ExtremesFrequencyMasking(low_freq_range=extremes_spec_augment_params["low_freq_range"],
+                                                              high_freq_range=extremes_spec_augment_params["high_freq_range"])
+                                     if extremes_spec_augment else None)
+        self.aud_augment = None
         self.num_frames_per_second = N_FRAMES / CHUNK_LENGTH
-        # parameter drawer shared with the GPU front end (no device work here: filters are not needed to draw)
-        self._aug = GpuFrontend.__new__(GpuFrontend)
-        p, e = spec_augment_params or {}, extremes_spec_augment_params or {}
-        self._aug.n_mels, self._aug.spec_augment = n_mels, spec_augment
-        self._aug.p = float(p.get("p", 1.0)) if spec_augment else 0.0
-        if spec_augment and not 0.0 <= self._aug.p <= 1.0:
-            raise ValueError(f"spec_augment p must be between 0 and 1, got {self._aug.p}")
-        self._aug.time_mask_param, self._aug.freq_mask_param = p.get("time_mask_param", 0), p.get("freq_mask_param", 0)
-        self._aug.time_warp_w = p.get("time_warp_w", 0)
-        self._aug.extremes = extremes_spec_augment
-        self._aug.low_freq_range, self._aug.high_freq_range = e.get("low_freq_range", 0), e.get("high_freq_range", 0)
+        self.timestamp_pattern = _TS
+        self.model_n_text_ctx = 448
         cols = getattr(hu_dataset, "column_names", None)
         if cols is not None:
             assert {"audio", "text", "language"} <= set(cols), "dataset needs audio / text / language columns"
         self.invalid_indices = set()
+
+    # ---- augmentation (reference: data_loader.py:273-301)
+    def _should_apply_spec_augment(self) -> bool:
+        if not self.spec_augment:
+            return False
+        if self.spec_augment_p >= 1.0:
+            return True
+        if self.spec_augment_p <= 0.0:
+            return False
+        return torch.rand(1).item() < self.spec_augment_p
+
+    def _calculate_mel(self, audio_array, next_partial_segment_start: Optional[float], no_timestamps: bool) -> torch.Tensor:
+        """Per-clip form: log-mel -> cut at a partial segment + minimum-value pad -> [warp -> time mask -> freq mask] w.p. p
+        -> extremes masking, every stage a libwft kernel on the device."""
+        if self.aud_augment is not None:
+            audio_array = self.aud_augment(audio_array, sample_rate=16000)
+        mel = log_mel_spectrogram(audio_array, n_mels=self.n_mels, device=self.device)
+        if no_timestamps and next_partial_segment_start is not None:
+            mel = mel[:, : int(next_partial_segment_start * self.num_frames_per_second)]
+        if mel.shape[1] != N_FRAMES:
+            mel = pad_or_trim(mel, N_FRAMES)
+        if self._should_apply_spec_augment():
+            mel = self.time_warping(mel)
+            mel = self.time_masking(mel)
+            mel = self.freq_masking(mel)
+        if self.extreme_freq_masking:
+            mel = self.extreme_freq_masking(mel)
+        return mel
+
+    def _draw_aug_params(self):
+        """The draws `_calculate_mel` would make for one clip (same default-generator order), as kernel arguments."""
+        return draw_clip_params(self._should_apply_spec_augment,
+                                self.time_warping.W if self.time_warping is not None else 0,
+                                self.time_masking, self.freq_masking, self.n_mels,
+                                self.extreme_freq_masking, N_FRAMES)
 
     def __len__(self) -> int:
         return len(self.hu_dataset)
@@ -155,9 +231,9 @@ class AudioDataset(Dataset):
         audio = np.asarray(rec["audio"]["array"], dtype=np.float32)
         audio = np.pad(audio, (0, N_SAMPLES - audio.shape[0]), "constant")  # pad in the audio domain (negative pad raises, as upstream)
         cut = int(seg_start * self.num_frames_per_second) if (no_ts and seg_start is not None) else N_FRAMES
-        params, ext = self._aug.draw(1)
+        params, ext = self._draw_aug_params()
         return (torch.from_numpy(audio), torch.tensor(dec_in, dtype=torch.int64), torch.tensor(dec_out, dtype=torch.int64),
-                params[0], ext[0], cut)
+                params, ext, cut)
 
 
 def collate_fn(data):
@@ -243,11 +319,12 @@ def get_dataloader(hu_dataset, tokenizer, batch_size: int = 1, n_mels: int = 80,
                    apply_advanced_aug: bool = False, time_stretch_min_rate: float = 0.8, time_stretch_max_rate: float = 1.25,
                    bpe_dropout: float = 0.0, drop_last: bool = False):
     print(f"Found {len(hu_dataset)} records in the dataset.")
-    ds = AudioDataset(hu_dataset, tokenizer, n_mels=n_mels, no_timestamp_training=no_timestamp_training,
+    ds = AudioDataset(hu_dataset, tokenizer, n_mels=n_mels, device=device, no_timestamp_training=no_timestamp_training,
                       max_prompt_length=max_prompt_length, prompt_use_rate=prompt_use_rate, no_timestamps_rate=no_timestamps_rate,
                       spec_augment=spec_augment, spec_augment_params=spec_augment_params, extremes_spec_augment=extremes_spec_augment,
                       extremes_spec_augment_params=extremes_spec_augment_params, bpe_dropout=bpe_dropout,
-                      apply_baseline_aug=apply_baseline_aug, apply_office_aug=apply_office_aug, apply_advanced_aug=apply_advanced_aug)
+                      apply_baseline_aug=apply_baseline_aug, apply_office_aug=apply_office_aug, apply_advanced_aug=apply_advanced_aug,
+                      time_stretch_min_rate=time_stretch_min_rate, time_stretch_max_rate=time_stretch_max_rate)
     if sampler is not None:
         shuffle = False  # DataLoader does not allow both
     loader = DataLoader(ds, batch_size=batch_size, sampler=sampler, shuffle=shuffle, num_workers=num_workers,

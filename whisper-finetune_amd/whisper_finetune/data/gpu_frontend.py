@@ -49,12 +49,27 @@ def mel_filters(n_mels: int) -> torch.Tensor:
     return torch.from_numpy(w.astype(np.float32))
 
 
-def draw_mask_span(mask_param: int, size: int) -> Tuple[int, int]:
-    """torchaudio TimeMasking/FrequencyMasking draw: value, then min_value."""
-    value = torch.rand(1) * mask_param
-    min_value = torch.rand(1) * (size - value)
-    start = int(min_value.long())
-    return start, start + int(value.long())
+from whisper_finetune.data.transforms import FrequencyMasking, TimeMasking, draw_mask_span  # noqa: E402,F401
+
+
+def draw_clip_params(should_apply, warp_w: int, time_masking, freq_masking, n_mels: int, extremes, T: int = N_FRAMES):
+    """Host draws of ONE clip in the order `AudioDataset._calculate_mel` makes them (data/data_loader.py:284-290):
+    gate -> warp `randint(W, T-W)`, `randint(-W, W)` (data/utils.py:107,111) -> time span -> frequency span -> extremes
+    ratio.  Returns (params i32 [8] = {apply_warp, warp_p, warp_d, t0, t1, f0, f1, 0}, extremes i32 [2]) for wft_specaug.
+    `should_apply` is a callable (the dataset's `_should_apply_spec_augment`); the maskers offer `draw(size)`;
+    `extremes` is an ExtremesFrequencyMasking or None."""
+    params = np.zeros(8, dtype=np.int32)
+    ext = np.zeros(2, dtype=np.int32)
+    if should_apply():
+        warp_p = int(torch.randint(warp_w, T - warp_w, (1,)))
+        warp_d = int(torch.randint(-warp_w, warp_w, (1,)))
+        t0, t1 = time_masking.draw(T)
+        f0, f1 = freq_masking.draw(n_mels)
+        params[:] = (1, warp_p, warp_d, t0, t1, f0, f1, 0)
+    if extremes is not None:
+        r = torch.rand(1).item()
+        ext[:] = (int(round(r * extremes.low_freq_range)), int(round(r * extremes.high_freq_range)))
+    return torch.from_numpy(params), torch.from_numpy(ext)
 
 
 class GpuFrontend:
@@ -83,20 +98,12 @@ class GpuFrontend:
 
     def draw(self, batch: int, T: int = N_FRAMES):
         """Host draws for a batch -> (params i32 [B,8], extremes i32 [B,2]) in the reference's per-clip order."""
-        params = np.zeros((batch, 8), dtype=np.int32)
-        ext = np.zeros((batch, 2), dtype=np.int32)
-        W = self.time_warp_w
-        for b in range(batch):
-            if self._should_apply():
-                warp_p = int(torch.randint(W, T - W, (1,)))
-                warp_d = int(torch.randint(-W, W, (1,)))
-                t0, t1 = draw_mask_span(self.time_mask_param, T)
-                f0, f1 = draw_mask_span(self.freq_mask_param, self.n_mels)
-                params[b] = (1, warp_p, warp_d, t0, t1, f0, f1, 0)
-            if self.extremes:
-                r = torch.rand(1).item()
-                ext[b] = (int(round(r * self.low_freq_range)), int(round(r * self.high_freq_range)))
-        return torch.from_numpy(params), torch.from_numpy(ext)
+        from whisper_finetune.data.utils import ExtremesFrequencyMasking
+
+        tm, fm = TimeMasking(self.time_mask_param), FrequencyMasking(self.freq_mask_param)
+        ex = ExtremesFrequencyMasking(self.low_freq_range, self.high_freq_range) if self.extremes else None
+        rows = [draw_clip_params(self._should_apply, self.time_warp_w, tm, fm, self.n_mels, ex, T) for _ in range(batch)]
+        return torch.stack([r[0] for r in rows]), torch.stack([r[1] for r in rows])
 
     def log_mel(self, audio: torch.Tensor) -> torch.Tensor:
         """audio f32 [B, 480000] on the device -> f32 [B, n_mels, 3000]."""

@@ -3,6 +3,8 @@ ExtremesFrequencyMasking, pad_or_trim.  The augmenters keep the reference's host
 parameters to the `wft_specaug` kernel; dataset IO stays on HF `datasets` (host)."""
 from __future__ import annotations
 
+import warnings
+from collections import defaultdict
 from pathlib import Path
 from typing import List, Optional, Sequence
 
@@ -10,7 +12,11 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from whisper_finetune.data.languages import LANGUAGES, TO_LANGUAGE_CODE
+
 N_SAMPLES = 480000
+N_FFT = 400
+HOP_LENGTH = 160
 
 
 def load_hf_dataset(path_or_name: str, **kwargs):
@@ -25,32 +31,127 @@ def load_hf_dataset(path_or_name: str, **kwargs):
     return load_dataset(path_or_name, **kwargs)
 
 
-def process_dataset(dataset_names: Sequence[str], select_n_per_ds: Optional[Sequence[Optional[int]]] = None, split_name: str = "train",
-                    groupby_col: Optional[Sequence[Optional[str]]] = None, select_language_tag: Optional[Sequence[Optional[str]]] = None,
-                    return_sizes: bool = False):
-    """Load, optionally filter by language / subsample, cast to the common schema {audio, text, language, prompt} and
-    concatenate the listed datasets (data/utils.py:238-352)."""
-    from datasets import Value, concatenate_datasets
+def _pad_list_with_none(values, target_len: int, label: str) -> list:
+    """Per-dataset option lists shorter than the dataset list are extended with None (with a warning) so that zip()
+    never silently drops a dataset (data/utils.py:193-203)."""
+    out = list(values) if values is not None else []
+    if len(out) < target_len:
+        missing = target_len - len(out)
+        warnings.warn(f"{label} has {len(out)} entries for {target_len} datasets; appending {missing} None value(s) to avoid "
+                      "dropping data in zip().", stacklevel=2)
+        out += [None] * missing
+    return out
 
-    n = len(dataset_names)
-    pad = lambda xs: list(xs or []) + [None] * (n - len(xs or []))  # noqa: E731
+
+def _cast_large_string_columns(dataset):
+    """Arrow `large_string` columns -> `string`, so datasets written by different tool versions concatenate
+    (data/utils.py:206-222)."""
+    from datasets import Features, Value
+
+    feats = dict(dataset.features)
+    large = [c for c, f in feats.items() if isinstance(f, Value) and f.dtype == "large_string"]
+    if not large:
+        return dataset
+    print("Casting large_string columns to string for dataset schema alignment.")
+    for c in large:
+        feats[c] = Value("string")
+    return dataset.cast(Features(feats))
+
+
+def _filter_language_tags(dataset, language_tags, dataset_name):
+    """Keep the rows whose `language` is one of `language_tags` (None = keep all) — data/utils.py:225-235."""
+    if language_tags is None:
+        return dataset
+    keep = set(language_tags)
+    before = len(dataset)
+    print(f"Filtering dataset {dataset_name} to language tag(s): {sorted(keep)}")
+    dataset = dataset.filter(lambda batch: [lang in keep for lang in batch["language"]], batched=True)
+    print(f"Filtered dataset size: {len(dataset)} (from {before})")
+    return dataset
+
+
+def add_fixed_value(batch, col_name, fixed_value):
+    batch[col_name] = [fixed_value] * len(batch["text"])
+    return batch
+
+
+def _normalize_language_value(language) -> str:
+    """'German' / ' DE ' -> 'de'; anything that is not a Whisper language code or name raises (data/utils.py:355-368)."""
+    if not isinstance(language, str):
+        raise ValueError(f"Language value {language!r} is not a string.")
+    key = language.strip().lower()
+    if key in LANGUAGES:
+        return key
+    code = TO_LANGUAGE_CODE.get(key)
+    if code is None:
+        raise ValueError(f"Unsupported language value {language!r}.")
+    return code
+
+
+def normalize_language_values(batch):
+    batch["language"] = [_normalize_language_value(v) for v in batch["language"]]
+    return batch
+
+
+def _subsample_indices(dataset, n: int, groupby: Optional[str]):
+    """`n` rows per distinct value of `groupby` (with replacement when a group is smaller), else min(n, len) rows without
+    replacement — numpy's global RNG, as the reference (data/utils.py:316-332)."""
+    if groupby and groupby in dataset.column_names:
+        print(f"Performing groupby sampling on column: {groupby}")
+        groups = defaultdict(list)
+        for i, v in enumerate(dataset[groupby]):
+            groups[v].append(i)
+        picked = []
+        for members in groups.values():
+            picked.extend(np.random.choice(members, size=n, replace=len(members) < n))
+        return picked
+    print("Performing regular random sampling")
+    return np.random.choice(len(dataset), size=min(n, len(dataset)), replace=False)
+
+
+def process_dataset(dataset_names, select_n_per_ds, split_name, groupby_col, print_examples=False, example_count=5,
+                    return_sizes=False, select_language_tag=None):
+    """Load every listed dataset, pick the split (falling back to 'train', then to the first split), rename `sentence` /
+    `sentence_de` to `text`, make sure `language` (normalised; 'de' when absent) and `prompt` ('' when absent) exist, filter
+    by language tag BEFORE sub-sampling, sub-sample, align string types, concatenate (data/utils.py:238-352; same positional
+    signature).  `print_examples` / `example_count` are accepted and unused, as in the reference."""
+    from datasets import concatenate_datasets
+
+    names = list(dataset_names)
+    select_n_per_ds = _pad_list_with_none(select_n_per_ds, len(names), "select_n_per_ds")
+    groupby_col = _pad_list_with_none(groupby_col, len(names), "groupby_col")
+    select_language_tag = ([None] * len(names) if select_language_tag is None
+                           else _pad_list_with_none(select_language_tag, len(names), "select_language_tag"))
     parts, sizes = [], []
-    for name, n_sel, _grp, lang in zip(dataset_names, pad(select_n_per_ds), pad(groupby_col), pad(select_language_tag)):
+    for n_sel, groupby, tags, name in zip(select_n_per_ds, groupby_col, select_language_tag, names):
         ds = load_hf_dataset(name)
-        if hasattr(ds, "keys") and split_name in ds:
-            ds = ds[split_name]
-        if lang is not None and "language" in ds.column_names:
-            ds = ds.filter(lambda r: r["language"] == lang)
-        if "language" not in ds.column_names:
-            ds = ds.add_column("language", ["de"] * len(ds))
+        if split_name not in ds:
+            print(f"Split name {split_name} not found in dataset {name}. Available splits: {list(ds.keys())}")
+            split_name = "train" if "train" in ds else list(ds.keys())[0]  # sticky for the following datasets, as upstream
+            print(f"Defaulting to split: {split_name}")
+        ds = ds[split_name]
+        print(f"Processing dataset: {name}")
+        print(f"Original dataset size: {len(ds)}")
+        for alias in ("sentence", "sentence_de"):
+            if alias in ds.column_names:
+                ds = ds.rename_column(alias, "text")
+        if "language" in ds.column_names:
+            ds = ds.map(normalize_language_values, batched=True)
+        else:
+            ds = ds.map(add_fixed_value, batched=True, fn_kwargs={"col_name": "language", "fixed_value": "de"})
         if "prompt" not in ds.column_names:
-            ds = ds.add_column("prompt", [""] * len(ds))
-        if n_sel is not None and n_sel < len(ds):
-            ds = ds.shuffle(seed=42).select(range(n_sel))
-        ds = ds.cast_column("text", Value("string")).select_columns(["audio", "text", "language", "prompt"])
+            ds = ds.map(add_fixed_value, batched=True, fn_kwargs={"col_name": "prompt", "fixed_value": ""})
+        ds = _filter_language_tags(ds, tags, name)
+        if n_sel is not None:
+            ds = ds.select(_subsample_indices(ds, n_sel, groupby))
+            print(f"Number of samples selected: {len(ds)}")
+        else:
+            print("No sampling performed (N is None)")
+        ds = _cast_large_string_columns(ds)
         parts.append(ds)
         sizes.append(len(ds))
-    out = concatenate_datasets(parts) if len(parts) > 1 else parts[0]
+    out = concatenate_datasets(parts)
+    print(f"Total rows in concatenated dataset: {len(out)}")
     return (out, sizes) if return_sizes else out
 
 
@@ -92,15 +193,16 @@ class ExtremesFrequencyMasking:
             specs = torch.tensor(specs)
         single = specs.dim() == 2
         x = specs.unsqueeze(0) if single else specs
-        n_mels = x.shape[1]
+        if not x.is_cuda:
+            raise RuntimeError("ExtremesFrequencyMasking runs on the GPU in this build (wft_specaug); move the spectrogram to the device")
+        from whisper_finetune.engine import kernels as K
+
+        ext = torch.zeros((x.shape[0], 2), dtype=torch.int32)
         for b in range(x.shape[0]):
             r = torch.rand(1).item()
-            lo, hi = int(round(r * self.low_freq_range)), int(round(r * self.high_freq_range))
-            if lo > 0:
-                x[b, : min(lo, n_mels)] = 0
-            if hi > 0:
-                x[b, max(n_mels - hi, 0):] = 0
-        return x.squeeze(0) if single else x
+            ext[b, 0], ext[b, 1] = int(round(r * self.low_freq_range)), int(round(r * self.high_freq_range))
+        out = K.specaug(x.float(), torch.zeros((x.shape[0], 8), dtype=torch.int32, device=x.device), ext.to(x.device))
+        return out.squeeze(0) if single else out
 
 
 def pad_or_trim(array, length: int = N_SAMPLES, *, axis: int = -1):

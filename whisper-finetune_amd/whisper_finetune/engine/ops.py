@@ -9,6 +9,8 @@ from __future__ import annotations
 
 from typing import List, Optional, Sequence, Tuple
 
+import itertools
+
 import os
 import torch
 from torch.optim.optimizer import register_optimizer_step_post_hook
@@ -46,10 +48,18 @@ class LoraSpec:
     """Low-rank adapter of one Linear (minLoRA semantics):
     W_eff = W + scaling * B @ (A * mask);  A [r, in], B [out, r], mask [1, in] (already drawn)."""
 
-    __slots__ = ("A", "B", "scaling", "mask")
+    __slots__ = ("A", "B", "scaling", "mask", "draw_id")
+    _draws = itertools.count(1)
 
     def __init__(self, A, B, scaling: float, mask: Optional[torch.Tensor]):
         self.A, self.B, self.scaling, self.mask = A, B, float(scaling), mask
+        # a freshly drawn dropout mask is a new tensor with _version 0 whose storage the caching allocator very likely
+        # recycles from the previous micro-batch's mask: (data_ptr, _version) cannot tell two draws apart.  Every drawn
+        # mask therefore carries a process-wide serial number that is part of the shadow-cache keys.
+        self.draw_id = 0 if mask is None else next(LoraSpec._draws)
+
+    def key(self):
+        return (_ver(self.A), _ver(self.B), self.draw_id, self.scaling)
 
 
 class LinearGroup:
@@ -82,7 +92,7 @@ class LinearGroup:
         live = any(t is not None and t.requires_grad for t in list(weights) + list(biases))
         lkey = None
         if loras is not None and any(sp is not None for sp in loras):
-            lkey = tuple(None if sp is None else (_ver(sp.A), _ver(sp.B), _ver(sp.mask), sp.scaling) for sp in loras)
+            lkey = tuple(None if sp is None else sp.key() for sp in loras)
             live = True
         key = (tuple(_ver(w) for w in weights), tuple(_ver(b) for b in biases), want_t, _SHADOW_EPOCH[0] if live else -1, lkey)
         if key != self.key:
@@ -120,7 +130,7 @@ class LinearGroup:
     def lora_shadows(self, weights, loras: Sequence[Optional[LoraSpec]]):
         """(A*mask) stacked [Rpad, K] and block-diagonal scaling*B [Npad, Rpad], both (+T) in bf16: the operands of the
         rank-r gradient GEMMs (backward only)."""
-        key = tuple(None if s is None else (_ver(s.A), _ver(s.B), _ver(s.mask), s.scaling) for s in loras) + (_SHADOW_EPOCH[0],)
+        key = tuple(None if s is None else s.key() for s in loras) + (_SHADOW_EPOCH[0],)
         if key != self.lkey:
             n, k, npad = self.dims(weights)
             dev = weights[0].device

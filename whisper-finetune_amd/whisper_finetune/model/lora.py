@@ -117,7 +117,14 @@ def apply_lora(model: nn.Module, lora_config: dict, train_only_decoder: bool = F
 def _strip(layer: nn.Module, merge: bool) -> None:
     if "parametrizations" not in layer._modules:
         return
-    plist = layer.parametrizations.weight
+    plist = layer.parametrizations["weight"] if "weight" in layer.parametrizations else None
+    if not isinstance(plist, ParametrizationList):
+        # a layer parametrized through torch.nn.utils.parametrize (minLoRA on a plain nn.Linear): the reference's route
+        import torch.nn.utils.parametrize as parametrize
+
+        for attr in list(layer.parametrizations.keys()):
+            parametrize.remove_parametrizations(layer, attr, leave_parametrized=merge)
+        return
     with torch.no_grad():
         W = plist[0].eval()(plist.original) if merge else plist.original
         new = nn.Parameter(W.detach().clone(), requires_grad=plist.original.requires_grad)
@@ -153,14 +160,16 @@ _REP = "decoder.blocks.0.cross_attn.query.parametrizations.weight"
 
 
 def _representative(model: nn.Module, pattern: str):
-    """First lora_A / lora_B pair, preferring names that contain `pattern` (model/lora.py:127,194)."""
+    """The (name, parameter) pairs the reference reports on (model/lora.py:152-171,207-216).  Its scan takes the FIRST
+    lora_A / lora_B it meets while nothing has been found yet, and afterwards only names containing `pattern` — so with the
+    default pattern A comes from the first adapted Linear of the model and B from `decoder.blocks.0.cross_attn.query`.
+    Reproduced as is: the logged numbers are compared across runs of the two code bases."""
     a = b = None
-    named = list(model.named_parameters())
-    for pool in ([x for x in named if pattern in x[0]], named):
-        for n, p in pool:
-            if a is None and "lora_A" in n:
+    for n, p in model.named_parameters():
+        if pattern in n or (a is None and b is None):
+            if "lora_A" in n and a is None:
                 a = (n, p)
-            if b is None and "lora_B" in n:
+            elif "lora_B" in n and b is None:
                 b = (n, p)
         if a is not None and b is not None:
             break
@@ -189,7 +198,7 @@ class LoRAUpdateTracker:
     """||dA||, ||dB|| of one representative adapter across optimizer steps (model/lora.py:180-252)."""
 
     def __init__(self, model: nn.Module, representative_module_pattern: str = _REP):
-        self.model = model
+        self.model, self.pattern = model, representative_module_pattern
         a, b = _representative(model, representative_module_pattern)
         self.A_name, self._A = a if a else (None, None)
         self.B_name, self._B = b if b else (None, None)
@@ -202,11 +211,11 @@ class LoRAUpdateTracker:
             self.prev_B = self._B.detach().clone().float()
 
     def get_update_norms(self) -> dict:
-        out = {"lora_A_update_norm": None, "lora_B_update_norm": None}
-        if self.prev_A is not None:
-            out["lora_A_update_norm"] = (self._A.detach().float() - self.prev_A).norm().item()
-        if self.prev_B is not None:
-            out["lora_B_update_norm"] = (self._B.detach().float() - self.prev_B).norm().item()
+        out = {"delta_A_norm": None, "delta_B_norm": None}
+        if self._A is not None and self.prev_A is not None:
+            out["delta_A_norm"] = (self._A.detach().float() - self.prev_A).norm().item()
+        if self._B is not None and self.prev_B is not None:
+            out["delta_B_norm"] = (self._B.detach().float() - self.prev_B).norm().item()
         return out
 
 
@@ -219,5 +228,7 @@ def log_lora_debug_info(model: nn.Module, step: int, tracker: Optional[LoRAUpdat
     if tracker is not None:
         stats.update(tracker.get_update_norms())
     if log_to_wandb:
-        rt.log({f"lora_debug/{k}": v for k, v in stats.items() if isinstance(v, (int, float))}, step=step)
+        payload = {f"lora_debug/{k}": v for k, v in stats.items() if v is not None and k != "param_name"}
+        if payload:
+            rt.log(payload, step=step)
     return stats

@@ -14,9 +14,11 @@ What is different, and why it is still a drop-in:
 from __future__ import annotations
 
 import copy
+import io
+import os
 from dataclasses import asdict
 from functools import partial
-from typing import Callable, Iterator, Optional
+from typing import Callable, Iterator, Optional, Union
 
 import torch
 import torch.nn.functional as F
@@ -24,7 +26,8 @@ from torch import Tensor
 from torch.utils.checkpoint import checkpoint
 
 import whisper_finetune.runtime as rt
-from whisper_finetune.engine.whisper_model import AudioEncoder, TextDecoder, Whisper
+from whisper_finetune.data import transforms as T  # the reference's `import torchaudio.transforms as T` (model_utils.py:10)
+from whisper_finetune.engine.whisper_model import AudioEncoder, LayerNorm, TextDecoder, Whisper
 
 _ILLEGAL = "CUDA error: an illegal memory"
 
@@ -228,14 +231,41 @@ class CheckpointedStochasticTextDecoder(StochasticDepthMixin, TextDecoder):
         return self.ln(x)
 
 
+def load_model_and_set_heads(model: Whisper, name: str, device: Union[str, torch.device] = "cpu", download_root: Optional[str] = None,
+                             in_memory: bool = False) -> Whisper:
+    """Load a {"dims", "model_state_dict"} checkpoint file into `model` and move it to `device`
+    (model/model_utils.py:330-379).  The reference also accepts the official model names and downloads them with
+    `whisper._download`; there is no network here, so a name that is not a file raises the reference's RuntimeError."""
+    if not os.path.isfile(name):
+        from whisper_finetune.engine.whisper_model import MODEL_DIMS
+
+        raise RuntimeError(f"Model {name} not found; available models = {sorted(MODEL_DIMS)} (official checkpoints are "
+                           "downloaded by openai-whisper, which this build does not ship: pass a checkpoint path)")
+    if in_memory:
+        with open(name, "rb") as fh:
+            blob = fh.read()
+        checkpoint = torch.load(io.BytesIO(blob), map_location=device)
+    else:
+        checkpoint = torch.load(name, map_location=device)
+    model.load_state_dict(checkpoint["model_state_dict"])
+    return model.to(device)
+
+
 def register_deep_spec_augment_hooks(model, time_mask_param: int, freq_mask_param: int, p: float = 1.0,
                                      layer_indices: Optional[list] = None) -> None:
     """SpecAugment on the normalised features after `attn_ln` of encoder blocks (all but the last by
     default): one time span <= time_mask_param and one channel span <= freq_mask_param are zeroed for
-    the whole batch; on/off is decided once per encoder forward with probability p."""
+    the whole batch; on/off is decided once per encoder forward with probability p (model/model_utils.py:382-437).
+
+    The maskers are built from the module-level namespace `T` like the reference's.  On the engine's LayerNorm with the
+    native maskers the two spans are DRAWN here (same generator, same order) and applied inside the LayerNorm kernel;
+    any other `attn_ln` module or masker type gets the reference's forward hook (permute -> time -> freq -> permute)."""
     p = float(p)
     if not 0.0 <= p <= 1.0:
         raise ValueError(f"deep_spec_augment p must be between 0 and 1, got {p}")
+    time_mask = T.TimeMasking(time_mask_param=time_mask_param)
+    freq_mask = T.FrequencyMasking(freq_mask_param=freq_mask_param)
+    native = isinstance(time_mask, T._AxisMasking) and isinstance(freq_mask, T._AxisMasking)
     n_blocks = len(model.encoder.blocks)
     state = {"apply": False}
 
@@ -243,22 +273,20 @@ def register_deep_spec_augment_hooks(model, time_mask_param: int, freq_mask_para
         # kept until the next encoder forward so a checkpoint recompute sees the same on/off state
         state["apply"] = True if p >= 1.0 else False if p <= 0.0 else torch.rand(1).item() < p
 
-    def span(param: int, size: int):
-        # torchaudio mask_along_axis draw order: value, then min_value (both torch.rand(1), CPU generator)
-        value = torch.rand(1) * param
-        lo = torch.rand(1) * (size - value)
-        start = int(lo.long())
-        return start, start + int(value.long())
+    def draw():
+        if not state["apply"]:
+            return None
+        n_ctx, n_state = model.encoder.positional_embedding.shape
+        t0, t1 = time_mask.draw(n_ctx)    # time mask first ...
+        c0, c1 = freq_mask.draw(n_state)  # ... then the "frequency" (= channel) mask
+        return t0, t1, c0, c1
 
-    def make_drawer(ln):
-        def draw():
-            if not state["apply"]:
-                return None
-            n_ctx, n_state = model.encoder.positional_embedding.shape
-            t0, t1 = span(time_mask_param, n_ctx)    # time mask first ...
-            c0, c1 = span(freq_mask_param, n_state)  # ... then the "frequency" (= channel) mask
-            return t0, t1, c0, c1
-        return draw
+    def norm_hook(module, inputs, output):
+        if module.training and state["apply"]:
+            x = output.permute(0, 2, 1)  # [B, d, T]: "frequency" = channel axis, time last
+            x = freq_mask(time_mask(x))
+            return x.permute(0, 2, 1)
+        return output
 
     if layer_indices is None:
         layer_indices = range(n_blocks - 1)
@@ -268,5 +296,8 @@ def register_deep_spec_augment_hooks(model, time_mask_param: int, freq_mask_para
         if idx == n_blocks - 1:
             continue  # never augment the last block: let the model recover
         ln = model.encoder.blocks[idx].attn_ln
-        ln.deep_spec_augment = make_drawer(ln)
+        if native and isinstance(ln, LayerNorm):
+            ln.deep_spec_augment = draw
+        else:
+            ln.register_forward_hook(norm_hook)
     model.encoder.register_forward_pre_hook(decide)

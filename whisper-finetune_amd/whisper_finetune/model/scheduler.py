@@ -53,6 +53,21 @@ def _warm_restarts(step: int, *, warmup: int, total: int, cycles: int, gamma: fl
     return max(0.0, 0.5 * (1.0 + math.cos(math.pi * ((cycles * prog) % 1.0))) * peak)
 
 
+def get_cosine_annealing_with_warmup_restarts(optimizer: Optimizer, num_warmup_steps: int, num_training_steps: int,
+                                              num_cycles: int = 1, last_epoch: int = -1, gamma: float = 1.0) -> LambdaLR:
+    """Public constructor with the reference's name and argument order (model/scheduler.py:74-90)."""
+    return LambdaLR(optimizer, partial(_warm_restarts, warmup=num_warmup_steps, total=num_training_steps, cycles=num_cycles,
+                                       gamma=gamma), last_epoch)
+
+
+def get_cosine_annealing_with_warmup_restarts_chill(optimizer: Optimizer, num_warmup_steps: int, num_training_steps: int,
+                                                    num_cycles: int = 1, last_epoch: int = -1, gamma: float = 1.0,
+                                                    chill_steps: int = 100, chill_range: float = 0.02) -> LambdaLR:
+    """model/scheduler.py:93-111."""
+    return LambdaLR(optimizer, partial(_warm_restarts, warmup=num_warmup_steps, total=num_training_steps, cycles=num_cycles,
+                                       gamma=gamma, chill_steps=chill_steps, chill_range=chill_range), last_epoch)
+
+
 def get_scheduler(optimizer: Optimizer, s_conf: dict, train_steps: int) -> LambdaLR:
     kind, warm = s_conf["type"], s_conf["warmup_steps"]
     if kind == "linear":
@@ -62,10 +77,12 @@ def get_scheduler(optimizer: Optimizer, s_conf: dict, train_steps: int) -> Lambd
     elif kind == "cosine_with_restarts":
         fn = partial(_cosine_hard_restarts, warmup=warm, total=train_steps, cycles=s_conf["lr_num_cycles"])
     elif kind == "cosine_with_warmup_restarts":
-        fn = partial(_warm_restarts, warmup=warm, total=train_steps, cycles=s_conf["lr_num_cycles"], gamma=s_conf["lr_gamma"])
+        return get_cosine_annealing_with_warmup_restarts(optimizer, warm, train_steps, num_cycles=s_conf["lr_num_cycles"],
+                                                         gamma=s_conf["lr_gamma"])
     elif kind == "cosine_with_warmup_restarts_chill":
-        fn = partial(_warm_restarts, warmup=warm, total=train_steps, cycles=s_conf["lr_num_cycles"], gamma=s_conf["lr_gamma"],
-                     chill_steps=s_conf["chill_steps"], chill_range=s_conf["chill_range"])
+        return get_cosine_annealing_with_warmup_restarts_chill(optimizer, warm, train_steps, num_cycles=s_conf["lr_num_cycles"],
+                                                               gamma=s_conf["lr_gamma"], chill_steps=s_conf["chill_steps"],
+                                                               chill_range=s_conf["chill_range"])
     else:
         raise Exception(f"Unknown learning rate scheduler: {kind}. Must be linear, cosine, cosine_with_restarts or cosine_with_warmup_restarts")
     return LambdaLR(optimizer, fn)

@@ -63,3 +63,46 @@ def set_seed(seed: int):
 def get_unique_base_path() -> str:
     job = os.environ.get("SLURM_JOB_ID")
     return job if job else datetime.now().strftime("%Y%m%d_%H%M%S")
+
+
+def disable_all_grads(model) -> None:
+    """Freeze every parameter of `model` (utils.py:138-140; finetune.py freezes the encoder / decoder half with it)."""
+    for p in model.parameters():
+        p.requires_grad = False
+
+
+def print_trainable_parameters(model) -> None:
+    """utils.py:129-135."""
+    total = trainable = 0
+    for p in model.parameters():
+        total += p.numel()
+        trainable += p.numel() if p.requires_grad else 0
+    print(f"Number of trainable parameters: {trainable:,} out of total {total:,}.")
+
+
+def print_size_of_model(model, label: str = "") -> int:
+    """Serialised size of the state dict in bytes (utils.py:120-126); goes through a scratch file like the reference."""
+    import tempfile
+
+    with tempfile.NamedTemporaryFile(suffix=".p") as fh:
+        torch.save(model.state_dict(), fh.name)
+        size = os.path.getsize(fh.name)
+    print("model: ", label, " \t", "Size (MB):", size / 1e6)
+    return size
+
+
+def handle_cuda_memory_operations(config: dict) -> None:
+    """Dump the allocator's memory-history snapshot to memory/memory_<bfloat16>_<lora>_<batch>_<mp>_<dtype>.pt and stop
+    recording (utils.py:91-117).  torch.cuda.memory is the HIP caching allocator on ROCm; failures are reported, not raised."""
+    m, d, t = config.get("model", {}), config.get("dataset", {}), config.get("training", {})
+    tag = "_".join(str(v) for v in ("memory", m.get("bfloat16", "NA"), m.get("lora", "NA"), d.get("batch_size", "NA"),
+                                    t.get("mixed_precision_training", "NA"), t.get("mp_dtype", "NA")))
+    try:
+        os.makedirs("memory", exist_ok=True)
+        torch.cuda.memory._dump_snapshot(f"memory/{tag}.pt")
+    except Exception as exc:
+        print(f"Failed to dump CUDA memory snapshot: {exc}")
+    try:
+        torch.cuda.memory._record_memory_history(enabled=None)
+    except Exception as exc:
+        print(f"Failed to stop CUDA memory snapshotting: {exc}")
