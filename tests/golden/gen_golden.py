@@ -162,6 +162,7 @@ def _install_stubs(tmp: Path):
         "        idx=[slice(None)]*x.dim(); idx[self.axis]=slice(s,e); x[tuple(idx)]=0.0\n        return x\n"
         "class TimeMasking(_M):\n    def __init__(self, time_mask_param): super().__init__(time_mask_param, -1)\n"
         "class FrequencyMasking(_M):\n    def __init__(self, freq_mask_param): super().__init__(freq_mask_param, -2)\n")
+    (tmp / "audiomentations.py").write_text("def __getattr__(name):\n    return type(name, (), {'__init__': lambda self, *a, **k: None})\n")
     (tmp / "jiwer.py").write_text("def wer(*a,**k): raise RuntimeError\ndef cer(*a,**k): raise RuntimeError\n")
 
 
@@ -358,7 +359,226 @@ def gen_ref_optim():
     print("ref_optim.json written", len(muon), len(aux))
 
 
+def _ref_imports():
+    """sys.path set up so that `whisper_finetune` is the REFERENCE's package (with the import stubs)."""
+    tmp = Path(tempfile.mkdtemp())
+    _install_stubs(tmp)
+    sys.path.insert(0, str(tmp))
+    sys.path.insert(0, str(REF / "src"))
+    sys.dont_write_bytecode = True
+    return tmp
+
+
+def gen_ref_sched():
+    """LR tables from the reference's own get_scheduler (model/scheduler.py:114-151; transformers' schedules for linear /
+    cosine / cosine_with_restarts, the in-tree lambdas for the warm-restart variants).  The chill variant draws
+    random.uniform per step: the table is taken under random.seed(0), which the test repeats."""
+    import json
+    import random
+    _ref_imports()
+    from whisper_finetune.model import scheduler as rs
+
+    confs = {
+        "linear": {"type": "linear", "warmup_steps": 10},
+        "cosine": {"type": "cosine", "warmup_steps": 7},
+        "cosine_with_restarts": {"type": "cosine_with_restarts", "warmup_steps": 5, "lr_num_cycles": 3},
+        "cosine_with_warmup_restarts": {"type": "cosine_with_warmup_restarts", "warmup_steps": 6, "lr_num_cycles": 4, "lr_gamma": 0.8},
+        "cosine_with_warmup_restarts_chill": {"type": "cosine_with_warmup_restarts_chill", "warmup_steps": 6, "lr_num_cycles": 3,
+                                              "lr_gamma": 0.9, "chill_steps": 12, "chill_range": 0.02},
+    }
+    out = {}
+    for kind, conf in confs.items():
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.SGD([p], lr=1.0)
+        random.seed(0)
+        s = rs.get_scheduler(opt, dict(conf), 120)
+        lrs = []
+        for _ in range(125):
+            lrs.append(opt.param_groups[0]["lr"])
+            opt.step(); s.step()
+        out[kind] = {"conf": conf, "lrs": lrs}
+    (HERE / "ref_sched.json").write_text(json.dumps(out, indent=0))
+    print("ref_sched.json written", {k: len(v["lrs"]) for k, v in out.items()})
+
+
+class OracleModule(torch.nn.Module):
+    """nn.Module face of oracle.Oracle (parameters registered under their openai-whisper names, '.' -> '/'), so the
+    reference's train_step / optimizers can drive the CPU oracle: model(mel, tokens) -> logits f32 [B, S, V]."""
+
+    def __init__(self, dims, params):
+        super().__init__()
+        self.dims = dims
+        self.names = list(params)
+        self.buffers_ = {k: v for k, v in params.items() if k == "encoder.positional_embedding"}
+        self.ps = torch.nn.ParameterDict({k.replace(".", "/"): torch.nn.Parameter(v.clone()) for k, v in params.items()
+                                          if k != "encoder.positional_embedding"})
+
+    def state(self):
+        d = {k.replace("/", "."): v for k, v in self.ps.items()}
+        d.update(self.buffers_)
+        return d
+
+    def forward(self, mel, tokens):
+        return O.Oracle(self.dims, self.state()).forward(mel, tokens)
+
+
+def train_step_case(seed=11, steps=4, accum=2, B=2, S=12):
+    """Inputs of the train_step golden: `steps * accum` micro-batches of B synthetic (mel, y_in, y_out)."""
+    g = torch.Generator().manual_seed(seed)
+    batches = []
+    for _ in range(steps * accum):
+        mel = torch.randn(B, ARCH_DIMS.n_mels, 2 * ARCH_DIMS.n_audio_ctx, generator=g)
+        y_in = torch.randint(0, ARCH_DIMS.n_vocab, (B, S), generator=g)
+        y_out = torch.randint(0, ARCH_DIMS.n_vocab, (B, S), generator=g)
+        y_out[0, :2] = -100
+        batches.append((mel, y_in, y_out))
+    return batches
+
+
+TRAIN_STEP_CFG = {"mixed_precision_training": False, "accum_grad_steps": 2, "max_grad_norm": 0.5, "mp_dtype": "bf16",
+                  "label_smoothing": 0.1}
+TRAIN_STEP_OPT = {"lr": 2e-3, "weight_decay": 0.1, "betas": (0.9, 0.98), "eps": 1e-6}
+
+
+def gen_ref_train_step():
+    """the REFERENCE'S OWN train_step (model/model_utils.py:23-127) drives the CPU oracle model for 4
+    optimizer steps x 2 micro-batches (fp32, label smoothing 0.1, clip 0.5, AdamW, linear schedule with warm-up):
+    the loss sequence, the learning rates and the norms of every parameter afterwards."""
+    _ref_imports()
+    import warnings
+    from whisper_finetune.model import model_utils as rmu
+    from whisper_finetune.model import scheduler as rs
+
+    model = OracleModule(ARCH_DIMS, arch_params(ARCH_DIMS, seed=3))
+    opt = torch.optim.AdamW(model.parameters(), **TRAIN_STEP_OPT)
+    sched = rs.get_scheduler(opt, {"type": "linear", "warmup_steps": 2}, 4)
+    it = iter(train_step_case())
+    losses, lrs = [], []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # autocast("cuda", enabled=False) on a CPU-only box
+        for step in range(1, 5):
+            lrs.append(opt.param_groups[0]["lr"])
+            losses.append(rmu.train_step(model, it, opt, sched, dict(TRAIN_STEP_CFG), step=step))
+    out = {"losses": np.array(losses, dtype=np.float64), "lrs": np.array(lrs, dtype=np.float64)}
+    for k, v in model.state().items():
+        out["final_norm/" + k] = np.float64(v.detach().double().norm().item())
+    np.savez_compressed(HERE / "ref_train_step.npz", **out)
+    print("ref_train_step.npz written", losses)
+
+
+class GoldenTokenizer:
+    """Whisper-shaped stub tokenizer of the data-path golden (byte-level text tokens; the v2 special-token layout)."""
+    eot, sot, sot_prev, no_speech, no_timestamps, timestamp_begin = 50257, 50258, 50361, 50362, 50363, 50364
+    special_tokens = {"<|de|>": 50261, "<|en|>": 50259, "<|transcribe|>": 50359}
+
+    def encode(self, text, **kwargs):
+        return list(text.encode("utf-8"))
+
+
+class GoldenRecords:
+    column_names = ["audio", "text", "language", "prompt"]
+
+    def __init__(self, records):
+        self.records = records
+
+    def with_format(self, type=None):
+        return self
+
+    def __len__(self):
+        return len(self.records)
+
+    def __getitem__(self, i):
+        r = self.records[i]
+        if isinstance(r, Exception):
+            raise r
+        return dict(r)
+
+
+def dataset_cases():
+    """(records, [(dataset kwargs, index, seed)]) of the data-path golden: prompts, timestamps, partial-segment cut,
+    no-speech, prompt truncation (> max_prompt_length and > 448 total), an unreadable row, SpecAugment draws."""
+    def rec(text, prompt="", lang="de", secs=1.0):
+        return {"audio": {"array": torch.zeros(int(secs * 16000))}, "text": text, "language": lang, "prompt": prompt}
+    records = [
+        rec("<|0.00|>hallo welt<|2.40|><|2.40|>noch ein satz<|5.00|>", prompt="<|1.00|>vorher<|3.00|>"),
+        rec("<|0.00|>teil eins<|3.00|><|3.00|>", prompt="kontext ohne zeitstempel"),      # partial segment -> cut at 3.00 s
+        rec("", prompt="p"),                                                                    # empty text -> no_speech
+        rec("<|0.00|>" + "x" * 300 + "<|9.98|>", prompt="y" * 400, lang="en"),                   # > 448: the prompt is shortened
+        RuntimeError("corrupt row"),                                                            # skipped lazily
+        rec("ohne zeitstempel", prompt="<|0.00|>z<|0.50|>"),
+    ]
+    sa = {"time_mask_param": 100, "freq_mask_param": 27, "time_warp_w": 80, "p": 1.0}
+    ex = {"low_freq_range": 10, "high_freq_range": 6}
+    base = dict(no_timestamp_training=False, max_prompt_length=223, prompt_use_rate=1.0, no_timestamps_rate=0.0)
+    runs = []
+    for idx in range(len(records)):
+        runs.append((dict(base), idx, 100 + idx))
+        runs.append(({**base, "no_timestamp_training": True}, idx, 200 + idx))
+        runs.append(({**base, "prompt_use_rate": 0.0, "no_timestamps_rate": 1.0}, idx, 300 + idx))
+        runs.append(({**base, "prompt_use_rate": 0.5, "no_timestamps_rate": 0.5, "spec_augment": True, "spec_augment_params": sa,
+                      "extremes_spec_augment": True, "extremes_spec_augment_params": ex}, idx, 400 + idx))
+        runs.append(({**base, "prompt_use_rate": 0.5, "no_timestamps_rate": 0.5, "spec_augment": True,
+                      "spec_augment_params": {**sa, "p": 0.5}}, idx, 500 + idx))
+    runs.append(({**base, "max_prompt_length": 5}, 0, 600))
+    return records, runs
+
+
+def gen_ref_dataset():
+    """The REFERENCE'S OWN AudioDataset.__getitem__ (data/data_loader.py:190-359) on stub records / tokenizer: decoder
+    input and target sequences, the partial-segment cut (read off a ramp standing in for the log-mel), the positions the
+    reference's SpecAugment zeroed, and the next default-generator draw after the item (proves the same NUMBER and ORDER of
+    draws)."""
+    import json
+    tmp = _ref_imports()
+    # a log-mel stand-in that makes the cut / masks readable: mel[m, t] = 1 + t + 3000 * m  (all > 0, minimum 1)
+    (tmp / "whisper/audio.py").write_text(
+        "import torch\nSAMPLE_RATE=16000\nN_FFT=400\nHOP_LENGTH=160\nCHUNK_LENGTH=30\nN_SAMPLES=480000\nN_FRAMES=3000\n"
+        "def log_mel_spectrogram(audio, n_mels=80, padding=0, device=None):\n"
+        "    return 1.0 + torch.arange(3000.0)[None, :] + 3000.0 * torch.arange(float(n_mels))[:, None]\n")
+    for mod in [m for m in sys.modules if m.startswith("whisper")]:
+        del sys.modules[mod]
+    from whisper_finetune.data import data_loader as rdl
+
+    records, runs = dataset_cases()
+    ds_records = GoldenRecords(records)
+    out = []
+    for kw, idx, seed in runs:
+        ds = rdl.AudioDataset(ds_records, GoldenTokenizer(), n_mels=80, **kw)
+        torch.manual_seed(seed)
+        mel, y_in, y_out = ds[idx]
+        nxt = torch.rand(1).item()
+        m = mel.numpy()
+        ramp = 1.0 + np.arange(3000.0)[None, :] + 3000.0 * np.arange(80.0)[:, None]
+        zero_t = np.where((m == 0).all(axis=0))[0]
+        zero_f = np.where((m == 0).all(axis=1))[0]
+        # frames kept before the minimum-value pad: only readable without a time warp (the non-augmented runs)
+        untouched = not kw.get("spec_augment", False)
+        kept = int((m[0] == ramp[0]).sum()) if untouched else None
+        if untouched and kept < 3000:
+            assert (m[:, kept:] == m[:, :kept].min()).all()
+        out.append({"kw": kw, "index": idx, "seed": seed, "y_in": y_in.tolist(), "y_out": y_out.tolist(), "kept_frames": kept,
+                    "zero_time": [int(zero_t.min()), int(zero_t.max()) + 1] if zero_t.size else None,
+                    "zero_mels": sorted(int(v) for v in zero_f), "next_rand": nxt,
+                    "invalid": sorted(ds.invalid_indices)})
+    bad = []
+    ds = rdl.AudioDataset(GoldenRecords([{"audio": {"array": torch.zeros(16000)}, "text": "<|0.01|>odd", "language": "de", "prompt": ""}]),
+                          GoldenTokenizer(), n_mels=80, no_timestamps_rate=0.0, prompt_use_rate=0.0)
+    try:
+        ds[0]
+    except Exception as exc:
+        bad.append([type(exc).__name__, str(exc)])
+    (HERE / "ref_dataset.json").write_text(json.dumps({"runs": out, "errors": bad}, indent=0))
+    print("ref_dataset.json written", len(out), bad)
+
+
 if __name__ == "__main__":
+    import subprocess
+
+    if len(sys.argv) > 1:  # one generator per process: several of them import the reference under different stubs
+        globals()[sys.argv[1]]()
+        sys.exit(0)
+    for fn in ("gen_ref_sched", "gen_ref_train_step", "gen_ref_dataset"):
+        subprocess.run([sys.executable, __file__, fn], check=True)
     gen_ref_optim()
     gen_ref_eval()
     gen_arch()

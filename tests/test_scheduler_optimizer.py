@@ -1,5 +1,5 @@
 """LR schedules against the reference's own get_scheduler output (tests/golden/ref_sched.json, generated in the build
-container by importing model/scheduler.py), optimizer factory behaviour."""
+container by tests/golden/gen_golden.py:gen_ref_sched from the reference's own model/scheduler.py), optimizer factory behaviour."""
 import json
 from pathlib import Path
 
@@ -16,6 +16,9 @@ GOLD = json.loads((Path(__file__).parent / "golden" / "ref_sched.json").read_tex
 def test_schedule_matches_reference(kind):
     p = torch.nn.Parameter(torch.zeros(1))
     opt = torch.optim.SGD([p], lr=1.0)
+    import random
+
+    random.seed(0)  # the chill variant jitters with random.uniform: the table was taken under this seed
     s = get_scheduler(opt, GOLD[kind]["conf"], 120)
     for ref in GOLD[kind]["lrs"]:
         assert abs(opt.param_groups[0]["lr"] - ref) < 1e-12

@@ -272,7 +272,26 @@ class TextDecoder(nn.Module):
         return self.logits_from_hidden(self.hidden(x, xa, kv_cache))
 
 
+def check_amp_request(model, mixed_precision: bool, mp_dtype: str) -> None:
+    """The engine computes with bf16 MFMA inputs, fp32 accumulation and fp32 master weights — the arithmetic of the reference's
+    `autocast(dtype=bfloat16)` (model/model_utils.py:37-48,64).  A caller that asks an engine model for true fp32
+    (`mixed_precision_training: False`) or for fp16 autocast gets an error instead of silently different numerics; other
+    modules (the reference's tests drive train_step with plain nn.Modules) are not concerned."""
+    if not isinstance(model, Whisper):
+        return
+    if not mixed_precision:
+        raise ValueError("training.mixed_precision_training: False asks for fp32 compute, which the libwft engine does not build "
+                         "(bf16 MFMA inputs, fp32 accumulation, fp32 master weights); set mixed_precision_training: True and "
+                         "mp_dtype: bf16")
+    if mp_dtype == "fp16":
+        raise ValueError("training.mp_dtype: fp16 asks for fp16 autocast + loss scaling; the libwft engine computes in bf16 "
+                         "(same 16-bit storage, 8-bit exponent, no GradScaler needed): set mp_dtype: bf16 "
+                         "(scripts/finetune.py does this rewrite itself, with a warning)")
+
+
 class Whisper(nn.Module):
+    wft_compute_dtype = "bf16"
+
     def __init__(self, dims: ModelDimensions):
         super().__init__()
         self.dims = dims

@@ -47,6 +47,9 @@ def evaluate_single_dataset(model, dataloader, dataset_name: str, t_config: dict
     device = next(model.parameters()).device
     mixed = t_config.get("mixed_precision_training", True)
     amp_dtype = torch.float16 if t_config.get("mp_dtype", "fp16") == "fp16" else torch.bfloat16
+    from whisper_finetune.engine.whisper_model import check_amp_request
+
+    check_amp_request(model, mixed, t_config.get("mp_dtype", "fp16"))
     if tokenizer is None:
         tokenizer = _default_tokenizer()
     specials = set(tokenizer.special_tokens.values())

@@ -27,7 +27,7 @@ from torch.utils.checkpoint import checkpoint
 
 import whisper_finetune.runtime as rt
 from whisper_finetune.data import transforms as T  # the reference's `import torchaudio.transforms as T` (model_utils.py:10)
-from whisper_finetune.engine.whisper_model import AudioEncoder, LayerNorm, TextDecoder, Whisper
+from whisper_finetune.engine.whisper_model import AudioEncoder, LayerNorm, TextDecoder, Whisper, check_amp_request
 
 _ILLEGAL = "CUDA error: an illegal memory"
 
@@ -62,6 +62,7 @@ def train_step(
     is_lora_run = t_config.get("is_lora_run", False)
     if fp16 and scaler is None:
         raise ValueError("fp16 mixed precision training requires a persistent GradScaler.")
+    check_amp_request(rt.unwrap_model(model), mixed, t_config["mp_dtype"])
     if not fp16:
         scaler = None
 

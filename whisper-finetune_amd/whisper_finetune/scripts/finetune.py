@@ -38,8 +38,8 @@ from whisper_finetune.model.model_utils import (CheckpointedStochasticAudioEncod
                                                 save_model, train_step)
 from whisper_finetune.model.optimizer import get_optimizer  # noqa: E402
 from whisper_finetune.model.scheduler import get_scheduler  # noqa: E402
-from whisper_finetune.utils import (calculate_training_steps, calculate_val_steps, get_unique_base_path, read_config,  # noqa: E402
-                                    resolve_local_accum_grad_steps, set_seed)
+from whisper_finetune.utils import (calculate_training_steps, calculate_val_steps, disable_all_grads, get_unique_base_path,  # noqa: E402
+                                    read_config, resolve_local_accum_grad_steps, set_seed)
 
 LAYER_PRESETS = {"whisper-4832": ("large-v3", 48, 32), "whisper-3248": ("large-v3", 32, 48)}  # finetune.py:51-54
 
@@ -74,30 +74,39 @@ def build_model(config: dict) -> Whisper:
         init_random_(model, seed=config["seed"])
     else:
         model.load_state_dict({k: v.float() for k, v in state.items()})
-    sd_p = float(t_cfg.get("stochastic_depth", 0.0))
-    ckpt_enc = t_cfg.get("gradient_checkpointing_encoder", False) or t_cfg.get("gradient_checkpointing_encoder_last_only", False)
-    ckpt_dec = t_cfg.get("gradient_checkpointing_decoder", False)
-    if ckpt_enc or sd_p > 0:
-        saved = model.state_dict()
+    # Stochastic depth exists only on the checkpointed encoder / decoder classes, which the reference swaps in when the
+    # gradient_checkpointing_* flag of that half is set; the frozen half of an encoder- / decoder-only run gets p = 0
+    # (scripts/finetune.py:413-455).
+    sd = float(t_cfg.get("stochastic_depth", 0.0))
+    enc_p = 0.0 if t_cfg.get("train_only_decoder", False) else sd
+    dec_p = 0.0 if t_cfg.get("train_only_encoder", False) else sd
+    ckpt_enc = bool(t_cfg.get("gradient_checkpointing_encoder", False))
+    ckpt_dec = bool(t_cfg.get("gradient_checkpointing_decoder", False))
+    saved = model.state_dict() if (ckpt_enc or ckpt_dec) else None
+    if ckpt_enc:
+        if t_cfg.get("gradient_checkpointing_encoder_last_only", False):
+            raise ValueError("gradient_checkpointing_encoder_last_only is not supported when gradient_checkpointing_encoder is enabled")
         model.encoder = CheckpointedStochasticAudioEncoder(dims.n_mels, dims.n_audio_ctx, dims.n_audio_state, dims.n_audio_head,
-                                                           dims.n_audio_layer, sd_p)
-        model.load_state_dict(saved)
-    if ckpt_dec or sd_p > 0:
-        saved = model.state_dict()
+                                                           dims.n_audio_layer, enc_p)
+    if ckpt_dec:
         model.decoder = CheckpointedStochasticTextDecoder(dims.n_vocab, dims.n_text_ctx, dims.n_text_state, dims.n_text_head,
-                                                          dims.n_text_layer, sd_p)
-        model.load_state_dict(saved)
+                                                          dims.n_text_layer, dec_p)
+    if saved is not None:
+        missing, unexpected = model.load_state_dict(saved, strict=True)
+        if missing or unexpected:
+            raise RuntimeError(f"Unexpected state-dict mismatch. Missing: {missing}, Unexpected: {unexpected}")
     for part in (model.encoder, model.decoder):
         if hasattr(part, "recompute"):
-            part.recompute = bool(t_cfg.get("wft_recompute", False))  # 288 GB HBM: keep activations resident by default
-    resize_whisper_layers(model, enc_layers, dec_layers)
-    model.is_bfloat = t_cfg.get("mp_dtype", "fp16") != "fp16"
+            # the flag selects the reference's module classes (and with them stochastic depth); whether the kept blocks are
+            # RECOMPUTED in the backward is a memory decision: 288 GB of HBM keep the activations resident by default
+            part.recompute = bool(t_cfg.get("wft_recompute", False))
+    if resize_whisper_layers(model, enc_layers, dec_layers):
+        print(f"Whisper architecture override active: encoder={model.dims.n_audio_layer}, decoder={model.dims.n_text_layer}")
+    model.is_bfloat = False  # scripts/finetune.py:410: always False, AMP handles precision
     if t_cfg.get("train_only_decoder", False):
-        for p in model.encoder.parameters():
-            p.requires_grad = False
+        disable_all_grads(model.encoder)
     if t_cfg.get("train_only_encoder", False):
-        for p in model.decoder.parameters():
-            p.requires_grad = False
+        disable_all_grads(model.decoder)
     config["training"]["is_lora_run"] = bool(m_cfg.get("lora", False))
     if m_cfg.get("lora", False):
         apply_lora(model, m_cfg["lora_config"], train_only_decoder=t_cfg.get("train_only_decoder", False),
@@ -148,10 +157,32 @@ def main_loop(model, train_loader, dev_loaders, optimizer, scheduler, save_dir, 
     return losses
 
 
+def resolve_precision(t_cfg: dict) -> None:
+    """Map the YAML's precision request onto what the engine computes (bf16 MFMA inputs, fp32 accumulate, fp32 masters).
+    Every shipped reference YAML says `mp_dtype: fp16`; on MI355X that becomes bf16 autocast without a GradScaler — said
+    loudly, once, and recorded in the config dump — while a request for pure fp32 is refused (engine/whisper_model.py:
+    check_amp_request)."""
+    if not t_cfg["mixed_precision_training"]:
+        raise ValueError("training.mixed_precision_training: False (fp32 compute) is not built on the libwft engine; use "
+                         "mixed_precision_training: True with mp_dtype: bf16")
+    if t_cfg["mp_dtype"] == "fp16":
+        import warnings
+
+        msg = ("training.mp_dtype: fp16 -> running bf16 autocast on MI355X (fp32 master weights and accumulation, no "
+               "GradScaler: bf16 has fp32's exponent range).  Set mp_dtype: bf16 to silence this.")
+        warnings.warn(msg, stacklevel=2)
+        rt.print_once("WARNING: " + msg)
+        t_cfg["wft_requested_mp_dtype"] = "fp16"
+        t_cfg["mp_dtype"] = "bf16"
+
+
 def main(config: dict):
     device = rt.setup_distributed()
     set_seed(config["seed"] + rt.RANK)
     t_cfg, d_cfg = config["training"], config["dataset"]
+    resolve_precision(t_cfg)
+    if config.get("model", {}).get("bfloat16", False):
+        print("WARNING: config['model']['bfloat16'] is deprecated and will be ignored!")
     config["training"]["global_accum_grad_steps"] = t_cfg["accum_grad_steps"]
     t_cfg["accum_grad_steps"] = resolve_local_accum_grad_steps(t_cfg["accum_grad_steps"], rt.WORLD_SIZE)
     config["save_dir"] = os.path.join(config.get("save_dir", "output"), get_unique_base_path())
@@ -174,17 +205,27 @@ def main(config: dict):
         val_sets = {"synthetic_val": SyntheticDataset(int(syn.get("val", 0)), seed=config["seed"] + 10_000)} if (rt.IS_MAIN and syn.get("val")) else {}
         boundaries = get_dataset_boundary_indices([len(train_ds)])
     else:
-        from whisper_finetune.data.utils import process_dataset  # HF datasets path (needs the dataset on disk / network)
+        from whisper_finetune.data.utils import _pad_list_with_none, process_dataset  # HF datasets path (disk / network)
         from whisper.tokenizer import get_tokenizer
 
         tokenizer = get_tokenizer(multilingual=True, language="de", task="transcribe")
-        train_ds, sizes = process_dataset(d_cfg["train_datasets"], d_cfg.get("select_n_per_t_ds"), d_cfg.get("train_split_name", "train"),
-                                          d_cfg.get("groupby_col"), d_cfg.get("select_language_tag"), return_sizes=True)
+        train_ds, sizes = process_dataset(d_cfg["train_datasets"], d_cfg["select_n_per_t_ds"], d_cfg["train_split_name"],
+                                          d_cfg["groupby_col"], return_sizes=True, select_language_tag=d_cfg.get("select_language_tag"))
         boundaries = get_dataset_boundary_indices(sizes)
         val_sets = {}
-        if rt.IS_MAIN:
-            for name, path in zip(d_cfg.get("val_dataset_names", d_cfg["val_datasets"]), d_cfg["val_datasets"]):
-                val_sets[name] = process_dataset([path], d_cfg.get("select_n_per_v_ds"), d_cfg.get("valid_split_name", "validation"))
+        if rt.IS_MAIN:  # validation sets only exist on rank 0 (scripts/finetune.py:543-576)
+            val_paths = d_cfg.get("val_datasets", [])
+            val_paths = [val_paths] if isinstance(val_paths, str) else list(val_paths)
+            names = d_cfg.get("val_dataset_names")
+            if names is None:
+                names = [v.split("/")[-1] for v in val_paths]
+            else:
+                names = _pad_list_with_none(names, len(val_paths), "val_dataset_names")
+            sel_n, groupby = d_cfg["select_n_per_v_ds"], d_cfg.get("groupby_col", [])
+            for i, (path, name) in enumerate(zip(val_paths, names)):
+                n_i = sel_n[i] if i < len(sel_n) else None
+                g_i = groupby[i] if i < len(groupby) else None
+                val_sets[name] = process_dataset([path], [n_i], d_cfg["valid_split_name"], [g_i])
 
     # ---- step arithmetic
     drop_last = d_cfg.get("drop_last", True)
@@ -208,6 +249,7 @@ def main(config: dict):
                                        sched_cfg["warmup_steps"] * t_cfg["accum_grad_steps"], d_cfg["batch_size"])
     sa = aug.get("spec_augment", {})
     ex = aug.get("extremes_spec_augment", {})
+    aa = aug.get("audio_augment", {})  # forwarded like the reference does: AudioDataset refuses what is out of scope
     n_mels = rt.unwrap_model(model).dims.n_mels
     loader_kw = dict(n_mels=n_mels, no_timestamp_training=d_cfg.get("no_timestamp_training", False),
                      max_prompt_length=d_cfg.get("max_prompt_length", 223), prompt_use_rate=d_cfg.get("prompt_use_rate", 0.5),
@@ -216,10 +258,15 @@ def main(config: dict):
                                   num_workers=d_cfg.get("train_num_workers", min(os.cpu_count() or 1, 8)),
                                   spec_augment=sa.get("apply", False), spec_augment_params=sa,
                                   extremes_spec_augment=ex.get("apply", False), extremes_spec_augment_params=ex,
+                                  apply_baseline_aug=aa.get("apply_baseline_aug", False), apply_office_aug=aa.get("apply_office_aug", False),
+                                  apply_advanced_aug=aa.get("apply_advanced_aug", False),
+                                  time_stretch_min_rate=aa.get("time_stretch", {}).get("min_rate", 0.8),
+                                  time_stretch_max_rate=aa.get("time_stretch", {}).get("max_rate", 1.25),
                                   bpe_dropout=aug.get("bpe_dropout", 0.0), drop_last=drop_last, **loader_kw)
     dev_loaders = {name: get_dataloader(ds, tokenizer, batch_size=d_cfg.get("batch_size_eval", d_cfg["batch_size"]), shuffle=False,
                                         num_workers=d_cfg.get("eval_num_workers", 0), **{**loader_kw, "no_timestamp_training": True,
-                                                                                         "prompt_use_rate": 0.0})
+                                                                                         "prompt_use_rate": 0,
+                                                                                         "no_timestamps_rate": 0})
                    for name, ds in val_sets.items()}
 
     optimizer = get_optimizer(model, config["optimizer"], is_lora_run=t_cfg["is_lora_run"])
