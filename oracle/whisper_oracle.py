@@ -293,22 +293,100 @@ def lora_init(fan_out: int, fan_in: int, rank: int, generator=None) -> Tuple[Ten
     return A, torch.zeros(fan_out, rank)
 
 
+
+# ----------------------------------------------------------------------------------------------
+# bf16-emulation mode (tests only): the fp32 restatement above is the parity reference; the emulation rounds to bf16
+# at the points where the libwft kernels round (GEMM outputs after their fused epilogue, LayerNorm outputs, the
+# probabilities / dS that feed the attention MFMAs, the residual stream), with fp32 accumulation everywhere — the
+# arithmetic contract of the reference's autocast(bf16) path (SURVEY.md §7 "Numerics contract").  Comparing the GPU path
+# with THIS removes the common rounding noise, so a mis-scaled term in a single tensor shows (per-tensor bound 2e-2
+# instead of the 6-8e-2 a bf16-vs-fp32 comparison needs).
+def _bf16(x: Tensor) -> Tensor:
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+class _RoundAct(torch.autograd.Function):
+    """Activation rounding: bf16 forward, and the gradient that flows back is a bf16 tensor in HBM too."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return _bf16(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _bf16(g)
+
+
+class _RoundWeight(torch.autograd.Function):
+    """Weight shadow rounding: bf16 forward; weight gradients are fp32 GEMM outputs (no rounding)."""
+
+    @staticmethod
+    def forward(ctx, w):
+        return _bf16(w)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _EmulatedAttention(torch.autograd.Function):
+    """The attention kernels' arithmetic (csrc/attn.hip) on [B, H, T, 64] fp32 tensors holding bf16 values:
+    forward  S = q k^T (fp32) -> P = exp(scale*S - max) -> l = sum P (fp32, unrounded P) -> O = (bf16(P) v) / l -> bf16;
+    backward recompute P = exp(scale*S - lse), delta = sum_d dO*O, dP = dO v^T, dS = P (dP - delta),
+             dV = bf16(P)^T dO, dQ = scale * bf16(dS) k, dK = scale * bf16(dS)^T q, each stored as bf16."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, causal: bool, scale: float):
+        s = (q @ k.transpose(-1, -2)) * scale
+        if causal:
+            T = s.shape[-1]
+            s = s + torch.full((T, T), float("-inf")).triu_(1)
+        m = s.amax(dim=-1, keepdim=True)
+        p = torch.exp(s - m)
+        l = p.sum(dim=-1, keepdim=True)
+        o = _bf16((_bf16(p) @ v) / l)
+        ctx.save_for_backward(q, k, v, o, m + torch.log(l))
+        ctx.cfg = (causal, scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        causal, scale = ctx.cfg
+        do = _bf16(do)
+        s = (q @ k.transpose(-1, -2)) * scale
+        if causal:
+            T = s.shape[-1]
+            s = s + torch.full((T, T), float("-inf")).triu_(1)
+        p = torch.exp(s - lse)
+        delta = (do * o).sum(dim=-1, keepdim=True)
+        ds = _bf16(p * (do @ v.transpose(-1, -2) - delta))
+        dv = _bf16(_bf16(p).transpose(-1, -2) @ do)
+        dq = _bf16((ds @ k) * scale)
+        dk = _bf16((ds.transpose(-1, -2) @ q) * scale)
+        return dq, dk, dv, None, None
+
+
 class Oracle:
     """Functional Whisper forward over a state dict (fp32).  Hooks for the reference's training-
     time extras: stochastic depth decisions, deep-SpecAugment masks and LoRA adapters."""
 
-    def __init__(self, dims: ModelDimensions, params: Dict[str, Tensor], lora: Optional[dict] = None):
+    def __init__(self, dims: ModelDimensions, params: Dict[str, Tensor], lora: Optional[dict] = None, emulate_bf16: bool = False):
         self.dims = dims
         self.p = params
         # lora: {"<module prefix>": (A, B, scaling, mask or None)} keyed by e.g. "encoder.blocks.0.attn.query"
         self.lora = lora or {}
+        # emulate_bf16: round where the libwft kernels round (see _RoundAct above); False = the fp32 restatement
+        self.emulate = emulate_bf16
+        self.ra = _RoundAct.apply if emulate_bf16 else (lambda t: t)
+        self.rw = _RoundWeight.apply if emulate_bf16 else (lambda t: t)
 
     def weight(self, prefix: str) -> Tensor:
         W = self.p[prefix + ".weight"]
         if prefix in self.lora:
             A, B, s, m = self.lora[prefix]
             W = lora_effective_weight(W, A, B, s, m)
-        return W
+        return self.rw(W)
 
     def linear(self, x: Tensor, prefix: str) -> Tensor:
         return F.linear(x, self.weight(prefix), self.p.get(prefix + ".bias"))
@@ -316,11 +394,16 @@ class Oracle:
     def attention(self, x: Tensor, prefix: str, n_head: int, xa: Optional[Tensor] = None, causal: bool = False) -> Tensor:
         """MultiHeadAttention.forward + qkv_attention (non-SDPA branch): q,k scaled by d_h^-0.25 each,
         softmax in fp32; mask = -inf strictly above the diagonal (decoder self-attention only)."""
-        q = self.linear(x, prefix + ".query")
+        q = self.ra(self.linear(x, prefix + ".query"))
         src = x if xa is None else xa
-        k = self.linear(src, prefix + ".key")
-        v = self.linear(src, prefix + ".value")
+        k = self.ra(self.linear(src, prefix + ".key"))
+        v = self.ra(self.linear(src, prefix + ".value"))
         B, T, D = q.shape
+        if self.emulate:
+            def heads(t):
+                return t.view(B, t.shape[1], n_head, -1).permute(0, 2, 1, 3)
+            o = _EmulatedAttention.apply(heads(q), heads(k), heads(v), causal, (D // n_head) ** -0.5)
+            return self.linear(o.permute(0, 2, 1, 3).flatten(start_dim=2), prefix + ".out")
         scale = (D // n_head) ** -0.25
         qh = q.view(B, T, n_head, -1).permute(0, 2, 1, 3) * scale
         kh = k.view(B, k.shape[1], n_head, -1).permute(0, 2, 3, 1) * scale
@@ -336,22 +419,23 @@ class Oracle:
               ln_mask: Optional[Tuple[int, int, int, int]] = None) -> Tensor:
         """ResidualAttentionBlock.  ln_mask=(t0,t1,c0,c1): the deep-SpecAugment forward hook on attn_ln
         (model/model_utils.py:409-417): time rows then channel columns zero-filled."""
-        h = layer_norm(x, self.p[prefix + ".attn_ln.weight"], self.p[prefix + ".attn_ln.bias"])
+        ra = self.ra  # identity in fp32 mode; the residual add is fused in the out-projection / fc2 GEMM epilogues
+        h = ra(layer_norm(x, self.p[prefix + ".attn_ln.weight"], self.p[prefix + ".attn_ln.bias"]))
         if ln_mask is not None:
             t0, t1, c0, c1 = ln_mask
             h = h.clone()
             h[:, t0:t1, :] = 0.0
             h[:, :, c0:c1] = 0.0
-        x = x + self.attention(h, prefix + ".attn", n_head, causal=causal)
+        x = ra(x + self.attention(h, prefix + ".attn", n_head, causal=causal))
         if xa is not None:
-            h = layer_norm(x, self.p[prefix + ".cross_attn_ln.weight"], self.p[prefix + ".cross_attn_ln.bias"])
-            x = x + self.attention(h, prefix + ".cross_attn", n_head, xa=xa)
-        h = layer_norm(x, self.p[prefix + ".mlp_ln.weight"], self.p[prefix + ".mlp_ln.bias"])
-        h = F.gelu(self.linear(h, prefix + ".mlp.0"))
-        return x + self.linear(h, prefix + ".mlp.2")
+            h = ra(layer_norm(x, self.p[prefix + ".cross_attn_ln.weight"], self.p[prefix + ".cross_attn_ln.bias"]))
+            x = ra(x + self.attention(h, prefix + ".cross_attn", n_head, xa=xa))
+        h = ra(layer_norm(x, self.p[prefix + ".mlp_ln.weight"], self.p[prefix + ".mlp_ln.bias"]))
+        h = ra(F.gelu(self.linear(h, prefix + ".mlp.0")))
+        return ra(x + self.linear(h, prefix + ".mlp.2"))
 
     @staticmethod
-    def stochastic_depth(x: Tensor, fn, p: float, training: bool, skip: bool) -> Tensor:
+    def stochastic_depth(x: Tensor, fn, p: float, training: bool, skip: bool, ra=None) -> Tensor:
         """StochasticDepthMixin.stochastic_depth (model/model_utils.py:226-250) with the
         `torch.rand(1).item() < p` decision passed in as `skip`."""
         if training and p > 0.0 and skip:
@@ -361,35 +445,37 @@ class Oracle:
             keep = 1.0 - p
             if keep <= 0.0:
                 return x
-            return x + (out - x) / keep
+            y = x + (out - x) / keep
+            return y if ra is None else ra(y)  # ra: the bf16 rounding of the fused rescale kernel (emulation mode)
         return out
 
     def encoder(self, mel: Tensor, sd_p: float = 0.0, training: bool = False, skips: Optional[List[bool]] = None,
                 ln_masks: Optional[Dict[int, Tuple[int, int, int, int]]] = None) -> Tensor:
         """model/model_utils.py:271-288."""
         p = self.p
-        x = F.gelu(F.conv1d(mel, p["encoder.conv1.weight"], p["encoder.conv1.bias"], padding=1))
-        x = F.gelu(F.conv1d(x, p["encoder.conv2.weight"], p["encoder.conv2.bias"], stride=2, padding=1))
+        ra, rw = self.ra, self.rw
+        x = ra(F.gelu(F.conv1d(ra(mel), rw(p["encoder.conv1.weight"]), p["encoder.conv1.bias"], padding=1)))
+        x = F.gelu(F.conv1d(x, rw(p["encoder.conv2.weight"]), p["encoder.conv2.bias"], stride=2, padding=1))
         x = x.permute(0, 2, 1)
         assert x.shape[1:] == p["encoder.positional_embedding"].shape, "incorrect audio shape"
-        x = (x + p["encoder.positional_embedding"]).to(x.dtype)
+        x = ra((x + rw(p["encoder.positional_embedding"])).to(x.dtype))
         for i in range(self.dims.n_audio_layer):
             mk = (ln_masks or {}).get(i)
             fn = lambda t, i=i, mk=mk: self.block(t, f"encoder.blocks.{i}", self.dims.n_audio_head, ln_mask=mk)  # noqa: E731
-            x = self.stochastic_depth(x, fn, sd_p, training, bool(skips[i]) if skips else False)
-        return layer_norm(x, p["encoder.ln_post.weight"], p["encoder.ln_post.bias"])
+            x = self.stochastic_depth(x, fn, sd_p, training, bool(skips[i]) if skips else False, ra=self.ra)
+        return self.ra(layer_norm(x, p["encoder.ln_post.weight"], p["encoder.ln_post.bias"]))
 
     def decoder(self, tokens: Tensor, xa: Tensor, sd_p: float = 0.0, training: bool = False,
                 skips: Optional[List[bool]] = None) -> Tensor:
         """model/model_utils.py:309-327 (kv_cache=None in training)."""
         p = self.p
         x = F.embedding(tokens, p["decoder.token_embedding.weight"]) + p["decoder.positional_embedding"][: tokens.shape[-1]]
-        x = x.to(xa.dtype)
+        x = self.ra(x.to(xa.dtype))
         for i in range(self.dims.n_text_layer):
             fn = lambda t, i=i: self.block(t, f"decoder.blocks.{i}", self.dims.n_text_head, xa=xa, causal=True)  # noqa: E731
-            x = self.stochastic_depth(x, fn, sd_p, training, bool(skips[i]) if skips else False)
-        x = layer_norm(x, p["decoder.ln.weight"], p["decoder.ln.bias"])
-        return (x @ p["decoder.token_embedding.weight"].to(x.dtype).T).float()
+            x = self.stochastic_depth(x, fn, sd_p, training, bool(skips[i]) if skips else False, ra=self.ra)
+        x = self.ra(layer_norm(x, p["decoder.ln.weight"], p["decoder.ln.bias"]))
+        return self.ra(x @ self.rw(p["decoder.token_embedding.weight"]).to(x.dtype).T).float()
 
     def forward(self, mel: Tensor, tokens: Tensor, **kw) -> Tensor:
         """Whisper.forward = decoder(tokens, encoder(mel)) -> logits f32 [B, S, V]."""

@@ -1,0 +1,53 @@
+"""Multi-process paths on the GPU box (one GPU): the engine under DDP on a 1-rank RCCL group, and the rank-sharded Muon
+step with two processes over gloo on the same device.  No scaling number comes out of these — they make the N > 1 code
+paths execute on hardware."""
+import socket
+
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _spawn(fn, world, timeout=400):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=fn, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout)
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    return sorted(q.get(timeout=10) for _ in range(world))
+
+
+@pytest.mark.timeout(600)
+def test_engine_under_ddp_matches_the_plain_run():
+    from tests._gpu_dist_workers import ddp_engine_worker
+
+    (rank, l_plain, l_ddp, worst, n_nosync), = _spawn(ddp_engine_worker, 1)
+    assert n_nosync == 3  # accumulation 2: one no_sync() micro-batch per optimizer step
+    assert l_plain == pytest.approx(l_ddp, rel=1e-6)
+    assert worst <= 1e-6, worst  # same kernels, same order of accumulation: the bucket views change nothing
+
+
+@pytest.mark.timeout(600)
+def test_sharded_muon_equals_the_single_process_step():
+    from tests._gpu_dist_workers import sharded_muon_worker
+
+    res = _spawn(sharded_muon_worker, 2)
+    for rank, worst, n_state, n_muon, same in res:
+        assert worst == 0.0, (rank, worst)        # same kernels on the same matrices: bit-identical
+        assert same                               # every rank ends with the same parameters
+        assert 0 < n_state < n_muon               # momentum only for the matrices this rank owns
+    assert sum(r[2] for r in res) == res[0][3]    # every Muon matrix has exactly one owner

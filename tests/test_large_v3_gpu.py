@@ -1,0 +1,198 @@
+"""BASELINE configs[2] / configs[3] model-level parity: the whisper-large-v3 32/32-layer engine (B = 1, S = 128) against
+the CPU oracle — loss and EVERY per-tensor gradient.
+
+Two comparisons per case:
+  * against the oracle's bf16-emulation mode (oracle/whisper_oracle.py: rounds where the kernels round, fp32
+    accumulation): the common rounding noise cancels, so the per-tensor bound is 2e-2 relative L2 — tight enough
+    that a mis-scaled term in one tensor cannot hide;
+  * against the plain fp32 restatement (the parity reference proper): the looser bf16-vs-fp32 bound (8e-2 max, 2e-2 median).
+The CPU oracle takes ~20-40 s per forward+backward at this size on the GPU box's host cores.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import whisper_oracle as O  # noqa: E402
+from whisper_finetune.data.gpu_frontend import GpuFrontend  # noqa: E402
+from whisper_finetune.engine import kernels as K  # noqa: E402
+from whisper_finetune.engine.whisper_model import MODEL_DIMS, ModelDimensions, Whisper  # noqa: E402
+from whisper_finetune.model import lora as lora_mod  # noqa: E402
+from whisper_finetune.model import model_utils  # noqa: E402
+from whisper_finetune.model.optimizer import get_optimizer  # noqa: E402
+
+DEV = torch.device("cuda:0")
+EMU_MAX, EMU_MED = 2e-2, 8e-3     # vs the bf16-emulating oracle
+F32_MAX, F32_MED = 8e-2, 2e-2     # vs the fp32 oracle (bf16 activations, 8 mantissa bits, 64+ layers deep)
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-20)).item()
+
+
+def _large_v3_params(seed=7):
+    dims = O.DIMS["large-v3"]
+    params = O.init_params(dims, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    for k, v in params.items():  # non-trivial biases / LayerNorm gains so that every gradient term is exercised
+        if k.endswith("bias"):
+            params[k] = torch.randn(v.shape, generator=g) * 0.02
+        elif "ln" in k and k.endswith("weight"):
+            params[k] = 1 + torch.randn(v.shape, generator=g) * 0.05
+    return dims, params
+
+
+def _oracle_grads(dims, params, mel, y_in, y_out, emulate, lora=None, **fwd_kw):
+    """loss and gradients of one oracle forward/backward; `params` values that require grad are the leaves."""
+    orc = O.Oracle(dims, params, lora=lora, emulate_bf16=emulate)
+    loss = O.cross_entropy(orc.forward(mel, y_in, **fwd_kw), y_out, 0.1)
+    loss.backward()
+    return loss.item()
+
+
+def _report(errs, tag):
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    print(f"[{tag}] max {worst[0][1]:.4f} median {np.median(list(errs.values())):.4f} worst {worst}")
+    return worst
+
+
+def test_large_v3_full_finetune_step_matches_oracle():
+    """configs[3] arithmetic (reference: model/model_utils.py:54-73): log-mel on the GPU, forward, label-smoothed CE,
+    backward of the full 32/32 model — all 1 259 parameter tensors compared."""
+    dims, params = _large_v3_params()
+    audio, y_in, y_out = O.synthetic_batch(dims, 1, 128)
+    y_out[0, :3] = -100
+    mel_ref = O.log_mel_spectrogram(audio, dims.n_mels)
+    m = Whisper(ModelDimensions(**vars(dims)))
+    m.load_state_dict(params)
+    m.to(DEV).train()
+    mel = K.logmel(audio.to(DEV), O.mel_filters(dims.n_mels).to(DEV))
+    assert (mel.cpu() - mel_ref).abs().max() < 2e-3
+    loss = m(mel, y_in.to(DEV), targets=y_out.to(DEV), label_smoothing=0.1)
+    loss.backward()
+    got = {n: p.grad.detach().cpu() for n, p in m.named_parameters()}
+    del m
+    torch.cuda.empty_cache()
+    for emulate, tmax, tmed, ltol in ((True, EMU_MAX, EMU_MED, 1e-3), (False, F32_MAX, F32_MED, 2e-3)):
+        p_req = {k: v.clone().requires_grad_(k != "encoder.positional_embedding") for k, v in params.items()}
+        loss_ref = _oracle_grads(dims, p_req, mel.cpu() if emulate else mel_ref, y_in, y_out, emulate)
+        assert abs(loss.item() - loss_ref) < ltol * loss_ref, (emulate, loss.item(), loss_ref)
+        errs = {n: rel(g, p_req[n].grad) for n, g in got.items()}
+        assert len(errs) == len([k for k in params if k != "encoder.positional_embedding"])
+        worst = _report(errs, "full-FT emulated" if emulate else "full-FT fp32")
+        assert worst[0][1] < tmax, worst
+        assert float(np.median(list(errs.values()))) < tmed
+
+
+def test_large_v3_lora_muon_config_step_matches_oracle():
+    """configs[2] = configs/config_large_v3_best_muon.yaml with model.lora: true: LoRA r16 alpha32 on all 512 Linears with a
+    FIXED non-trivial dropout mask per Linear (p = 0.1), SpecAugment with the YAML's parameters (time 100, freq 43, warp 80),
+    deep SpecAugment (100 / 43) and stochastic depth 0.1 with the host draws replayed into the oracle, label smoothing 0.1;
+    then ONE Muon + auxiliary-Adam step (the YAML's optimizer block) against the oracle's restatement of the update."""
+    dims, params = _large_v3_params(seed=17)
+    t_cfg = {"stochastic_depth": 0.1}
+    audio, y_in, y_out = O.synthetic_batch(dims, 1, 128, seed=99)
+    r, alpha, p_drop = 16, 32, 0.1
+    from whisper_finetune.model.model_utils import CheckpointedStochasticAudioEncoder, CheckpointedStochasticTextDecoder
+
+    m = Whisper(ModelDimensions(**vars(dims)))
+    m.encoder = CheckpointedStochasticAudioEncoder(dims.n_mels, dims.n_audio_ctx, dims.n_audio_state, dims.n_audio_head,
+                                                   dims.n_audio_layer, t_cfg["stochastic_depth"])
+    m.decoder = CheckpointedStochasticTextDecoder(dims.n_vocab, dims.n_text_ctx, dims.n_text_state, dims.n_text_head,
+                                                  dims.n_text_layer, t_cfg["stochastic_depth"])
+    m.load_state_dict(params)
+    lora_mod.apply_lora(m, {"rank": r, "lora_alpha": alpha, "lora_dropout": p_drop})
+    g = torch.Generator().manual_seed(23)
+    adapters = {}
+    for name, mod in m.named_modules():
+        if "parametrizations" in mod._modules:
+            ad = mod.parametrizations.weight[0]
+            with torch.no_grad():
+                ad.lora_B.copy_(torch.randn(ad.lora_B.shape, generator=g) * 0.02)
+            mask = (torch.rand(1, ad.lora_A.shape[1], generator=g) >= p_drop).float() / (1.0 - p_drop)
+            adapters[name] = (ad, mask)
+    assert len(adapters) == 512
+    m.to(DEV).train()
+    for ad, mask in adapters.values():
+        dev_mask = mask.to(DEV)
+        ad.draw_mask = (lambda mk: (lambda training: mk))(dev_mask)
+    model_utils.register_deep_spec_augment_hooks(m, time_mask_param=100, freq_mask_param=43, p=1.0)
+
+    # SpecAugment on the device with the YAML's parameters; the drawn spans are replayed into the oracle's restatement
+    fe = GpuFrontend(dims.n_mels, DEV, True, {"time_mask_param": 100, "freq_mask_param": 43, "time_warp_w": 80, "p": 1.0})
+    torch.manual_seed(1234)
+    sa_params, sa_ext = fe.draw(1)
+    mel_plain = fe.log_mel(audio.to(DEV))
+    mel = K.specaug(mel_plain, sa_params.to(DEV), sa_ext.to(DEV))
+    _, wp, wd, t0, t1, f0, f1, _ = sa_params[0].tolist()
+    mel_ref = O.spec_augment(O.log_mel_spectrogram(audio, dims.n_mels)[0], (wp, wd), (t0, t1), (f0, f1))[None]
+    assert (mel.cpu() - mel_ref).abs().max() < 5e-3
+
+    # replay of the model's host draws: per encoder block [skip?] then, for kept blocks but the last, the two mask spans;
+    # per decoder block [skip?]  (model/model_utils.py:239,402-417; torchaudio draw order)
+    torch.manual_seed(4242)
+    state = torch.get_rng_state()
+    enc_skips, ln_masks = [], {}
+    for i in range(dims.n_audio_layer):
+        s = torch.rand(1).item() < 0.1
+        enc_skips.append(s)
+        if not s and i < dims.n_audio_layer - 1:
+            ln_masks[i] = O.draw_mask_span(100, dims.n_audio_ctx) + O.draw_mask_span(43, dims.n_audio_state)
+    dec_skips = [torch.rand(1).item() < 0.1 for _ in range(dims.n_text_layer)]
+    torch.set_rng_state(state)
+    loss = m(mel, y_in.to(DEV), targets=y_out.to(DEV), label_smoothing=0.1)
+    loss.backward()
+    named = dict(m.named_parameters())
+    assert all(p.grad is None for n, p in named.items() if "lora" not in n)  # base stays frozen
+
+    fwd_kw = dict(enc_sd_p=0.1, enc_training=True, enc_skips=enc_skips, enc_ln_masks=ln_masks,
+                  dec_sd_p=0.1, dec_training=True, dec_skips=dec_skips)
+    for emulate, tmax, tmed, ltol in ((True, EMU_MAX, EMU_MED, 1e-3), (False, 1e-1, 3e-2, 2e-3)):
+        cfg = {n: (ad.lora_A.detach().cpu().clone().requires_grad_(True), ad.lora_B.detach().cpu().clone().requires_grad_(True),
+                   ad.scaling, mask) for n, (ad, mask) in adapters.items()}
+        loss_ref = _oracle_grads(dims, params, mel.cpu() if emulate else mel_ref, y_in, y_out, emulate, lora=cfg, **fwd_kw)
+        assert abs(loss.item() - loss_ref) < ltol * loss_ref, (emulate, loss.item(), loss_ref)
+        errs = {}
+        skipped = set()
+        for n, (A, Bm, _, _) in cfg.items():
+            ad = adapters[n][0]
+            if A.grad is None:  # a block dropped by stochastic depth: no gradient on either side
+                assert ad.lora_A.grad is None and ad.lora_B.grad is None, n
+                skipped.add(n)
+                continue
+            errs[n + ".lora_A"] = rel(ad.lora_A.grad, A.grad)
+            errs[n + ".lora_B"] = rel(ad.lora_B.grad, Bm.grad)
+        worst = _report(errs, "LoRA emulated" if emulate else "LoRA fp32")
+        assert worst[0][1] < tmax, worst
+        assert float(np.median(list(errs.values()))) < tmed
+    n_skipped_blocks = sum(enc_skips) + sum(dec_skips)
+    assert (len(skipped) > 0) == (n_skipped_blocks > 0)
+
+    # ---- one optimizer step with the YAML's Muon + auxiliary-Adam block, on the ENGINE's gradients (isolates the update)
+    opt_conf = {"type": "adamw", "muon": True, "8bit": False, "muon_ndim_threshold": 2,
+                "muon_params": {"lr": 2e-5, "momentum": 0.95, "weight_decay": 0.01},
+                "params": {"lr": 2e-5, "weight_decay": 0.01, "betas": [0.9, 0.98], "eps": 1e-6, "amsgrad": False}}
+    opt = get_optimizer(m, opt_conf, is_lora_run=True)
+    before = {n: p.detach().cpu().clone() for n, p in named.items() if p.requires_grad}
+    ref_groups, ref_p = [], {}
+    names_of = {id(p): n for n, p in named.items()}
+    for group in opt.param_groups:
+        pairs = []
+        for p in group["params"]:
+            n = names_of[id(p)]
+            ref_p[n] = before[n].clone()
+            pairs.append((ref_p[n], None if p.grad is None else p.grad.detach().cpu().clone()))
+        ref_groups.append({**{k: v for k, v in group.items() if k != "params"}, "params": pairs})
+    opt.step()
+    O.muon_with_aux_adam_step(ref_groups, {})
+    errs = {}
+    for n, want in ref_p.items():
+        d_got, d_want = named[n].detach().cpu() - before[n], want - before[n]
+        if d_want.norm() == 0:
+            assert d_got.norm() == 0, n
+            continue
+        errs[n] = ((d_got - d_want).norm() / d_want.norm()).item()
+    worst = _report(errs, "Muon step (update relative error)")
+    assert worst[0][1] < 6e-2, worst  # 15 chained bf16 GEMMs per Newton-Schulz orthogonalisation on both sides

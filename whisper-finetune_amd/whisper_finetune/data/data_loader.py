@@ -287,28 +287,75 @@ def get_dataset_boundary_indices(dataset_sizes: List[int]) -> List[Tuple[int, in
 
 
 class GpuMelLoader:
-    """Wraps the raw-audio DataLoader: one pinned H2D copy of the clips per batch, then log-mel + SpecAugment on the device."""
+    """Wraps the raw-audio DataLoader: pinned, double-buffered H2D of the raw clips (1.92 MB per clip instead of the
+    1.54 MB mel plus its CPU cost), then log-mel + SpecAugment on the device.
 
-    def __init__(self, loader: DataLoader, frontend: GpuFrontend, training_aug: bool):
+    With DataLoader workers (num_workers > 0) batch i+1 is fetched and its host-to-device copies are issued on a side
+    stream while batch i is being consumed; the compute stream waits on the copy's event only when it starts using the
+    batch.  With num_workers == 0 the dataset's augmentation draws share the default generator with the model's own draws
+    (stochastic depth, deep SpecAugment): fetching ahead would reorder them against the reference, so that case stays
+    strictly sequential.  Yields (mel f32 [B, n_mels, 3000], y_in, y_out), all on the device."""
+
+    def __init__(self, loader, frontend: GpuFrontend, training_aug: bool):
         self.loader, self.frontend, self.training_aug = loader, frontend, training_aug
-        self.sampler = loader.sampler  # infinite_iter() calls sampler.set_epoch(...)
-        self.batch_size = loader.batch_size
+        self.sampler = getattr(loader, "sampler", None)  # infinite_iter() calls sampler.set_epoch(...)
+        self.batch_size = getattr(loader, "batch_size", None)
+        self.prefetch = getattr(loader, "num_workers", 0) > 0
+        self._copy_stream = None
 
     def __len__(self):
         return len(self.loader)
 
-    def __iter__(self):
+    def _stage(self, batch):
+        """Issue the batch's H2D copies on the side stream; returns the device tensors and the event that orders them."""
+        dev = self.frontend.device
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=dev)
+        audio, y_in, y_out, params, ext, cut = batch
+        need_aug = bool(params[:, 0].any() or ext.any())  # decided on the host copies: no device sync
+        with torch.cuda.stream(self._copy_stream):
+            staged = [t.to(dev, non_blocking=True) for t in (audio, y_in, y_out, params, ext)]
+            ev = torch.cuda.Event()
+            ev.record(self._copy_stream)
+        return staged, cut, ev, need_aug
+
+    def _to_mel(self, staged, cut, ev, need_aug):
         from whisper_finetune.engine import kernels as K
 
+        cur = torch.cuda.current_stream(self.frontend.device)
+        if ev is not None:
+            cur.wait_event(ev)
+            for t in staged:
+                t.record_stream(cur)  # allocated on the copy stream, consumed on the compute stream
+        audio, y_in, y_out, params, ext = staged
+        mel = self.frontend.log_mel(audio)
+        for b in (cut < N_FRAMES).nonzero().flatten().tolist():  # rare: cut at a partial segment, pad with the min value
+            c = int(cut[b])
+            mel[b, :, c:] = mel[b, :, :c].min() if c > 0 else mel[b].min()
+        if self.training_aug and need_aug:
+            mel = K.specaug(mel, params, ext)
+        return mel, y_in, y_out
+
+    def __iter__(self):
         dev = self.frontend.device
-        for audio, y_in, y_out, params, ext, cut in self.loader:
-            mel = self.frontend.log_mel(audio.to(dev, non_blocking=True))
-            for b in (cut < N_FRAMES).nonzero().flatten().tolist():  # rare: cut at a partial segment, pad with the min value
-                c = int(cut[b])
-                mel[b, :, c:] = mel[b, :, :c].min() if c > 0 else mel[b].min()
-            if self.training_aug and (params[:, 0].any() or ext.any()):
-                mel = K.specaug(mel, params.to(dev, non_blocking=True), ext.to(dev, non_blocking=True))
-            yield mel, y_in, y_out
+        if not self.prefetch:
+            for audio, y_in, y_out, params, ext, cut in self.loader:
+                need_aug = bool(params[:, 0].any() or ext.any())
+                staged = [t.to(dev, non_blocking=True) for t in (audio, y_in, y_out, params, ext)]
+                yield self._to_mel(staged, cut, None, need_aug)
+            return
+        it = iter(self.loader)
+        try:
+            nxt = self._stage(next(it))
+        except StopIteration:
+            return
+        while nxt is not None:
+            cur = nxt
+            try:
+                nxt = self._stage(next(it))  # copies of batch i+1 run beside the kernels of batch i
+            except StopIteration:
+                nxt = None
+            yield self._to_mel(*cur)
 
 
 def get_dataloader(hu_dataset, tokenizer, batch_size: int = 1, n_mels: int = 80, sampler=None, device=None,

@@ -526,12 +526,19 @@ NS_COEFFS = (3.4445, -4.7750, 2.0315)  # muon.py zeropower_via_newtonschulz5
 
 
 def muon_group_step(params, grads, bufs, lr, wd, momentum, nesterov=True, ns_steps=5, sumsq=None, max_norm=0.0,
-                    return_update=False):
+                    return_update=False, shard=None):
     """One Muon step for a list of same-shape 2-D f32 parameters (muon.py muon_update + the p update of
     SingleDeviceMuonWithAuxAdam.step): momentum/nesterov -> bf16 -> Frobenius normalisation -> 5 Newton-Schulz
-    iterations as batched MFMA GEMMs -> p = p(1 - lr wd) - lr sqrt(max(1, rows/cols)) X."""
+    iterations as batched MFMA GEMMs -> p = p(1 - lr wd) - lr sqrt(max(1, rows/cols)) X.
+
+    shard = (rank, world, all_gather): the distributed variant (muon.MuonWithAuxAdam, reference model/optimizer.py:227-228,
+    SURVEY.md §2.2 C6).  The matrices of the group are dealt to the ranks in contiguous chunks of ceil(n / world); a rank
+    runs momentum + Newton-Schulz for ITS chunk only (`grads` / `bufs` then hold that chunk: bufs[i] belongs to
+    params[lo + i]), the orthogonalised updates — a bf16 quantity — are all-gathered (half the bytes of gathering the fp32
+    parameters, the package's form) and every rank applies all n updates in fp32, so parameters stay bit-identical across
+    ranks.  `all_gather(out, inp)` fills out [world * chunk, ...] from every rank's inp [chunk, ...]."""
     lib = L.load()
-    n = len(params)
+    n_all = len(params)
     rows, cols = params[0].shape
     dev = params[0].device
     tall = rows > cols
@@ -539,39 +546,57 @@ def muon_group_step(params, grads, bufs, lr, wd, momentum, nesterov=True, ns_ste
     Rp, Cp = round_up(R, 128), round_up(Cc, 128)
     numel = rows * cols
     chunks = (numel + MT_CHUNK - 1) // MT_CHUNK
-    flat = []
+    if shard is None:
+        lo, hi, per = 0, n_all, n_all
+    else:
+        rank, world, all_gather = shard
+        per = (n_all + world - 1) // world
+        lo, hi = min(rank * per, n_all), min((rank + 1) * per, n_all)
+    n = hi - lo
+    if len(grads) != n or len(bufs) != n:
+        raise L.WftError(f"muon_group_step: {n} owned matrices but {len(grads)} gradients / {len(bufs)} momentum buffers")
     for row in (params, grads, bufs):
         for t in row:
             if t.dtype != F32 or not t.is_contiguous() or t.shape != (rows, cols) or not t.is_cuda:
                 raise L.WftError("muon_group_step needs contiguous f32 HIP tensors of one shape (there is no CPU path)")
-            flat.append(t.data_ptr())
-    tab = torch.tensor(flat, dtype=torch.int64, device=dev)
-    U = torch.empty((n, rows, cols), dtype=BF16, device=dev)
-    partial = torch.empty((n, chunks), dtype=F32, device=dev)
-    L.check(lib.wft_muon_momentum_mt(_p(tab), n, numel, momentum, int(nesterov), _p(U), _p(partial), _p(sumsq),
-                                     float(max_norm), L.stream_ptr()), "wft_muon_momentum_mt")
-    X = torch.empty((n, Rp, Cp), dtype=BF16, device=dev)
-    Xt = torch.empty((n, Cp, Rp), dtype=BF16, device=dev)
-    L.check(lib.wft_muon_prepare(_p(U), rows, cols, _p(partial), chunks, _p(X), _p(Xt), Rp, Cp, n, L.stream_ptr()),
-            "wft_muon_prepare")
-    del U
-    A = torch.empty((n, Rp, Rp), dtype=BF16, device=dev)
-    Bm = torch.empty((n, Rp, Rp), dtype=BF16, device=dev)
-    Xt2 = torch.empty((n, Cp, Rp), dtype=BF16, device=dev)
-    a, b, c = NS_COEFFS
-    for it in range(ns_steps):
-        gemm_nt(X, X, M=Rp, N=Rp, K=Cp, lda=Cp, ldb=Cp, out=A, ldc=Rp, batch=n, strideA=Rp * Cp, strideB=Rp * Cp,
-                strideC=Rp * Rp)                                                        # A = X X^T
-        gemm_nt(A, A, M=Rp, N=Rp, K=Rp, lda=Rp, ldb=Rp, out=Bm, ldc=Rp, batch=n, strideA=Rp * Rp, strideB=Rp * Rp,
-                strideC=Rp * Rp, alpha=c, residual=A, ldr=Rp, strideR=Rp * Rp, beta=b)  # B = b A + c A A   (A = A^T)
-        gemm_nt(Xt, Bm, M=Cp, N=Rp, K=Rp, lda=Rp, ldb=Rp, out=Xt2, ldc=Rp, batch=n, strideA=Cp * Rp, strideB=Rp * Rp,
-                strideC=Cp * Rp, residual=Xt, ldr=Rp, strideR=Cp * Rp, beta=a)          # X'^T = a X^T + X^T B (B = B^T)
-        Xt, Xt2 = Xt2, Xt
-        if it + 1 < ns_steps or not tall:
-            transpose_bf16(Xt, X)
-    O, ldo, so = (Xt, Rp, Cp * Rp) if tall else (X, Cp, Rp * Cp)
+    O = None
+    ldo, so = (Rp, Cp * Rp) if tall else (Cp, Rp * Cp)
+    if n > 0:
+        flat = [t.data_ptr() for t in params[lo:hi]] + [t.data_ptr() for t in grads] + [t.data_ptr() for t in bufs]
+        tab = torch.tensor(flat, dtype=torch.int64, device=dev)
+        U = torch.empty((n, rows, cols), dtype=BF16, device=dev)
+        partial = torch.empty((n, chunks), dtype=F32, device=dev)
+        L.check(lib.wft_muon_momentum_mt(_p(tab), n, numel, momentum, int(nesterov), _p(U), _p(partial), _p(sumsq),
+                                         float(max_norm), L.stream_ptr()), "wft_muon_momentum_mt")
+        X = torch.empty((n, Rp, Cp), dtype=BF16, device=dev)
+        Xt = torch.empty((n, Cp, Rp), dtype=BF16, device=dev)
+        L.check(lib.wft_muon_prepare(_p(U), rows, cols, _p(partial), chunks, _p(X), _p(Xt), Rp, Cp, n, L.stream_ptr()),
+                "wft_muon_prepare")
+        del U
+        A = torch.empty((n, Rp, Rp), dtype=BF16, device=dev)
+        Bm = torch.empty((n, Rp, Rp), dtype=BF16, device=dev)
+        Xt2 = torch.empty((n, Cp, Rp), dtype=BF16, device=dev)
+        a, b, c = NS_COEFFS
+        for it in range(ns_steps):
+            gemm_nt(X, X, M=Rp, N=Rp, K=Cp, lda=Cp, ldb=Cp, out=A, ldc=Rp, batch=n, strideA=Rp * Cp, strideB=Rp * Cp,
+                    strideC=Rp * Rp)                                                        # A = X X^T
+            gemm_nt(A, A, M=Rp, N=Rp, K=Rp, lda=Rp, ldb=Rp, out=Bm, ldc=Rp, batch=n, strideA=Rp * Rp, strideB=Rp * Rp,
+                    strideC=Rp * Rp, alpha=c, residual=A, ldr=Rp, strideR=Rp * Rp, beta=b)  # B = b A + c A A   (A = A^T)
+            gemm_nt(Xt, Bm, M=Cp, N=Rp, K=Rp, lda=Rp, ldb=Rp, out=Xt2, ldc=Rp, batch=n, strideA=Cp * Rp, strideB=Rp * Rp,
+                    strideC=Cp * Rp, residual=Xt, ldr=Rp, strideR=Cp * Rp, beta=a)          # X'^T = a X^T + X^T B (B = B^T)
+            Xt, Xt2 = Xt2, Xt
+            if it + 1 < ns_steps or not tall:
+                transpose_bf16(Xt, X)
+        O = Xt if tall else X
+    if shard is not None:
+        mine = torch.zeros((per,) + ((Cp, Rp) if tall else (Rp, Cp)), dtype=BF16, device=dev)
+        if n > 0:
+            mine[:n].copy_(O)
+        O = torch.empty((world * per,) + tuple(mine.shape[1:]), dtype=BF16, device=dev)
+        all_gather(O, mine)
     scale = max(1.0, rows / cols) ** 0.5
-    L.check(lib.wft_muon_apply_mt(_p(tab), n, rows, cols, _p(O), ldo, so, lr, wd, scale, L.stream_ptr()), "wft_muon_apply_mt")
+    ptab = torch.tensor([t.data_ptr() for t in params], dtype=torch.int64, device=dev)
+    L.check(lib.wft_muon_apply_mt(_p(ptab), n_all, rows, cols, _p(O), ldo, so, lr, wd, scale, L.stream_ptr()), "wft_muon_apply_mt")
     if return_update:
-        return O[:, :rows, :cols].float() * scale
+        return O[:n_all, :rows, :cols].float() * scale
     return None

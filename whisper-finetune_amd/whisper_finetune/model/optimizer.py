@@ -103,9 +103,13 @@ class WftMuonWithAuxAdam(_FusedClipMixin, torch.optim.Optimizer):
     Param groups are the reference's: {"params", "lr", "momentum", "weight_decay", "use_muon": True} and
     {"params", "lr", "betas", "eps", "weight_decay", "use_muon": False}.  Muon parameters of one shape are stepped
     together: momentum/nesterov, bf16 cast, Frobenius normalisation, five Newton-Schulz iterations as BATCHED bf16
-    MFMA GEMMs, update.  Under DDP every rank holds identical (all-reduced) gradients, so every rank computes the
-    identical update locally; the reference's distributed variant shards that work and all-gathers the result,
-    which is numerically the same update."""
+    MFMA GEMMs, update.  In a multi-process job (torch.distributed initialised, world > 1: what selects
+    `muon.MuonWithAuxAdam` in the reference, model/optimizer.py:227-228) the Newton-Schulz work is SHARDED: every
+    same-shape bucket is dealt to the ranks in contiguous chunks, a rank keeps momentum and orthogonalises only its own
+    matrices, the bf16 updates are all-gathered over RCCL and every rank applies all of them in fp32 — parameters stay
+    bit-identical across ranks and 8 ranks no longer repeat 8x the same GEMMs (the package gathers the
+    updated fp32 parameters instead: twice the bytes for the same result).  The auxiliary-Adam groups are element-wise
+    and stay replicated."""
 
     def __init__(self, param_groups):
         for group in param_groups:
@@ -135,6 +139,7 @@ class WftMuonWithAuxAdam(_FusedClipMixin, torch.optim.Optimizer):
                         p.grad = torch.zeros_like(p)  # muon.py: "force synchronization"
         with_grad = [p for g in self.param_groups for p in g["params"] if p.grad is not None]
         sumsq, max_norm = self._take_clip(with_grad)
+        shard = _muon_shard()
         for group in self.param_groups:
             if not group["use_muon"]:
                 continue
@@ -142,17 +147,39 @@ class WftMuonWithAuxAdam(_FusedClipMixin, torch.optim.Optimizer):
             for p in group["params"]:
                 if p.ndim < 2:
                     raise ValueError("Muon parameters must have ndim >= 2")
-                st = self.state[p]
-                if not st:
-                    st["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 buckets.setdefault((p.shape[0], p[0].numel()), []).append(p)
             for (rows, cols), ps in buckets.items():
-                grads = [(p.grad if p.grad.is_contiguous() else p.grad.contiguous()).view(rows, cols) for p in ps]
+                if shard is None:
+                    own = ps
+                else:
+                    per = (len(ps) + shard[1] - 1) // shard[1]
+                    own = ps[shard[0] * per:(shard[0] + 1) * per]
+                for p in own:  # momentum lives on the owning rank only
+                    if not self.state[p]:
+                        self.state[p]["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                grads = [(p.grad if p.grad.is_contiguous() else p.grad.contiguous()).view(rows, cols) for p in own]
                 K.muon_group_step([p.data.view(rows, cols) for p in ps], grads,
-                                  [self.state[p]["momentum_buffer"].view(rows, cols) for p in ps], group["lr"],
-                                  group["weight_decay"], group["momentum"], sumsq=sumsq, max_norm=max_norm)
+                                  [self.state[p]["momentum_buffer"].view(rows, cols) for p in own], group["lr"],
+                                  group["weight_decay"], group["momentum"], sumsq=sumsq, max_norm=max_norm, shard=shard)
         _adamw_groups_step(self, [g for g in self.param_groups if not g["use_muon"]], sumsq, max_norm)
         return loss
+
+
+def _muon_shard():
+    """(rank, world, all_gather) when the Newton-Schulz work is sharded over the process group, else None."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() < 2:
+        return None
+    world = dist.get_world_size()
+
+    def all_gather(out, inp):
+        if dist.get_backend() == "nccl":
+            dist.all_gather_into_tensor(out, inp)  # one RCCL all-gather per same-shape bucket
+        else:  # gloo (tests): list form
+            dist.all_gather(list(out.chunk(world, dim=0)), inp)
+
+    return dist.get_rank(), world, all_gather
 
 
 def _partition_muon_params(model, ndim_threshold: int = 2):
