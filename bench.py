@@ -8,7 +8,8 @@
 One "step" = one optimizer step of the hot path on every rank: synthetic 30 s clips already
 resident in HBM -> log-mel -> SpecAugment -> encoder/decoder forward -> label-smoothed CE ->
 backward -> (DDP gradient all-reduce over RCCL, overlapped with backward) -> grad-norm clip folded
-into the libwft multi-tensor AdamW.  68 clips per GPU per step by default (180 GiB of the 288 GB HBM).
+into the libwft multi-tensor AdamW — driven by the product's own `model_utils.train_step` (per-micro-batch loss.item(),
+scheduler step included).  68 clips per GPU per step by default (180 GiB of the 288 GB HBM).
 Weights: random init of the whisper-large-v3 architecture; data: synthetic (no network).
 Rank 0 prints ONE JSON line (contract in the task statement); it also carries
   "roofline":     the dominant kernel (gemm_nt256_kernel: the Linear / logits forward and
@@ -16,7 +17,12 @@ Rank 0 prints ONE JSON line (contract in the task statement); it also carries
                   during one instrumented step that follows the timed region; "traffic" = HBM-side
                   bytes per launch from the committed rocprofv3 PMC passes of this command (profiles/);
   "cpu_baseline": the CPU oracle (oracle/whisper_oracle.py, torch fp32) forward+backward on a
-                  bounded sample, timed on this box's host cores (N=1 only).
+                  bounded sample, timed on this box's host cores (N=1 only);
+and, on the default (headline) invocation, extra keys measured in the same process after the headline:
+  "hand_rolled_ms_per_step": round 1's hand-written loop on the same state (cross-check of the product loop),
+  "reference_yaml_shapes":   the reference YAML's batch 32 at S = 128 and at the S = 448 stress length,
+  "configs2_lora_muon":      BASELINE configs[2] (LoRA r16 + Muon + stochastic depth + deep SpecAugment, B = 32) with
+                             its own roofline object.  `--no-extras` prints the headline only.
 """
 from __future__ import annotations
 
@@ -60,15 +66,18 @@ def lora_flops_per_clip(d, S: int, r: int) -> float:
     return enc + dec
 
 
-def pmc_traffic_per_launch(batch: int):
+def pmc_traffic_per_launch(batch: int, lora: bool = False):
     """HBM bytes per gemm_nt256_kernel launch from the committed rocprofv3 PMC passes of THIS command
     (profiles/collect_r01.sh: --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, the only tracing next to them
     being --kernel-trace).  FETCH_SIZE is in KiB and counts 64 B per 128-B request on gfx950 for 16-B/lane streaming
     reads, so it is doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE (KiB) is exact.  Counters cannot be
     collected inside the timed run, so the value is only reported when the committed pass used the same batch."""
-    path = ROOT / "profiles" / "r01_f_pmc_summary.json"
-    if not path.exists():
+    if lora:
+        return None, "no PMC pass committed for this configuration"
+    cands = sorted((ROOT / "profiles").glob("r0*_pmc_summary.json"))
+    if not cands:
         return None, "no PMC summary committed"
+    path = cands[-1]  # the latest round's pass
     d = json.loads(path.read_text())
     if d.get("batch", 68) != batch:
         return None, f"PMC pass was collected at batch {d.get('batch', 68)}"
@@ -80,7 +89,7 @@ def pmc_traffic_per_launch(batch: int):
             n += v["launches"]
     if n == 0:
         return None, "kernel not in the PMC summary"
-    return round(tot / n), "profiles/r01_f_pmc_summary.json: (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch, separate --pmc passes"
+    return round(tot / n), f"profiles/{path.name}: (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch, separate --pmc passes"
 
 
 def build_model(name: str, device, sd_p: float = 0.0):
@@ -144,6 +153,159 @@ def cpu_baseline(model_name: str, S: int, budget_s: float = 30.0):
     }
 
 
+class Case:
+    """One model configuration resident on the device (model, optimizer, optional DDP wrapper, GPU front end) that can be
+    timed at several (clips, S) shapes.  A step is the product loop: `model_utils.train_step` (the reference's
+    model/model_utils.py:23-127 — micro-batch fetch, forward, label-smoothed CE, backward, per-micro-batch loss.item(),
+    clip folded into the libwft optimizer, optimizer + scheduler step, zero_grad) pulling its micro-batch from an iterator
+    that runs log-mel + SpecAugment on clips already resident in HBM."""
+
+    def __init__(self, args, device, rank, local_rank, world, ddp, lora=False, muon=False, sd=0.0, dsa=False):
+        from whisper_finetune.data.gpu_frontend import GpuFrontend
+        from whisper_finetune.model.optimizer import WftAdamW, get_optimizer
+
+        self.args, self.device, self.rank, self.local_rank, self.world, self.ddp = args, device, rank, local_rank, world, ddp
+        self.lora, self.muon, self.sd, self.dsa = lora, muon, sd, dsa
+        self.model, self.dims = build_model(args.model, device, sd)
+        if lora:
+            from whisper_finetune.model.lora import apply_lora
+
+            apply_lora(self.model, {"rank": 16, "lora_alpha": 32, "lora_dropout": 0.1})
+        if dsa:
+            from whisper_finetune.model.model_utils import register_deep_spec_augment_hooks
+
+            register_deep_spec_augment_hooks(self.model, 100, 43)
+        self.model.train()
+        self.frontend = GpuFrontend(self.dims.n_mels, device, spec_augment=True,
+                                    spec_augment_params={"time_mask_param": 100, "freq_mask_param": 43, "time_warp_w": 80, "p": 1.0})
+        if muon:
+            self.opt = get_optimizer(self.model, {"type": "adamw", "muon": True, "8bit": False,
+                                                  "muon_params": {"lr": 2e-5, "momentum": 0.95, "weight_decay": 0.01},
+                                                  "params": {"lr": 2e-5, "weight_decay": 0.01, "betas": [0.9, 0.98], "eps": 1e-6}},
+                                     is_lora_run=lora)
+        else:
+            # one wft_mt_sumsq + one wft_mt_adamw launch per step: clip_grad_norm_(1.0) folded into the AdamW pass
+            self.opt = WftAdamW([p for p in self.model.parameters() if p.requires_grad], lr=1e-5, betas=(0.9, 0.98), eps=1e-6,
+                                weight_decay=0.1)
+        self.sched = torch.optim.lr_scheduler.LambdaLR(self.opt, lambda s: 1.0)
+        self.net = self.model
+        if ddp:
+            from torch.nn.parallel import DistributedDataParallel as DDP
+
+            self.net = DDP(self.model, device_ids=[local_rank], output_device=local_rank, broadcast_buffers=False,
+                           gradient_as_bucket_view=True, bucket_cap_mb=64, find_unused_parameters=sd > 0)
+        self.t_cfg = {"mixed_precision_training": True, "mp_dtype": "bf16", "accum_grad_steps": 1, "max_grad_norm": 1.0,
+                      "label_smoothing": 0.1, "is_lora_run": False}
+
+    def mode(self):
+        return (("LoRA r=16 alpha=32 p=0.1" if self.lora else "full fine-tune") + (", Muon+AuxAdam" if self.muon else ", AdamW")
+                + (f", stochastic depth {self.sd}" if self.sd > 0 else "") + (", deep SpecAugment" if self.dsa else ""))
+
+    def fence(self):
+        if self.ddp:
+            dist.barrier(device_ids=[self.local_rank])
+        torch.cuda.synchronize()
+
+    def step_flops(self, B, S):
+        f_fwd, f_att = fwd_flops_per_clip(self.dims, S), attn_core_flops_per_clip(self.dims, S)
+        if self.lora:  # frozen base weights: no dW GEMMs (SURVEY.md §8d)
+            return (2.0 * (f_fwd - f_att) + 3.0 * f_att + 3.0 * lora_flops_per_clip(self.dims, S, 16)) * B
+        return 3.0 * f_fwd * B
+
+    def measure(self, B, S, steps, warmup, roofline=True, hand_rolled_steps=0):
+        """-> dict(value, ms_per_step, ...) for `B` clips per GPU and decoder length S; max over ranks of the wall time of
+        exactly `steps` optimizer steps between barrier + synchronize."""
+        import whisper_finetune.runtime as rt
+        from whisper_finetune.engine import kernels as K
+        from whisper_finetune.model.model_utils import train_step
+
+        dev, rank = self.device, self.rank
+        torch.manual_seed(1234 + rank)  # per-rank host RNG (finetune.py:325)
+        gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+        audio = torch.randn(B, 480000, device=dev, generator=gen) * 0.1  # resident in HBM
+        y_in, y_out = synthetic_tokens(B, S, dev, rank)
+        frontend, net, opt, sched = self.frontend, self.net, self.opt, self.sched
+
+        def batches():
+            while True:
+                yield frontend(audio, training=True), y_in, y_out
+
+        it = batches()
+        rt.IS_DISTRIBUTED = self.world > 1
+
+        def step():
+            return train_step(net, it, opt, sched, self.t_cfg)
+
+        def hand_rolled():  # round 1's loop: same kernels, no per-micro-batch loss.item(), no scheduler
+            mel = frontend(audio, training=True)
+            loss = net(mel, y_in, targets=y_out, label_smoothing=0.1)
+            loss.backward()
+            opt.fuse_clip_grad_norm(1.0)
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            return loss
+
+        for _ in range(warmup):
+            step()
+        self.fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        self.fence()
+        dt = time.perf_counter() - t0
+        if self.ddp:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        res = {"batch": B, "seq_len": S, "ms_per_step": round(dt / steps * 1e3, 2),
+               "value": round(B * self.world * steps * 30.0 / dt, 1), "final_loss": round(float(loss), 4)}
+        tf = self.step_flops(B, S) / (dt / steps) / 1e12
+        res["step_tflops_per_gpu"] = round(tf, 1)
+        res["step_frac_of_bf16_peak"] = round(tf / PEAK_BF16_TFLOPS, 4)
+        if hand_rolled_steps > 0:
+            self.fence()
+            t0 = time.perf_counter()
+            for _ in range(hand_rolled_steps):
+                hand_rolled()
+            self.fence()
+            res["hand_rolled_ms_per_step"] = round((time.perf_counter() - t0) / hand_rolled_steps * 1e3, 2)
+        if roofline:
+            # one more step with HIP events around every gemm_nt launch (on the launch stream).  EVERY rank runs the step (its
+            # gradient all-reduce is a collective); only rank 0 records.
+            if rank == 0:
+                K.PROFILE_NT = []
+            step()
+            torch.cuda.synchronize()
+            if rank == 0:
+                recs, K.PROFILE_NT = K.PROFILE_NT, None
+                big = [(s_.elapsed_time(e_), f, nb) for s_, e_, f, v, nb in recs if v == 256]  # gemm_nt256_kernel launches
+                ms = sum(t for t, _, _ in big)
+                flops = sum(f for _, f, _ in big)
+                all_ms = sum(s_.elapsed_time(e_) for s_, e_, _, _, _ in recs)
+                all_fl = sum(f for _, _, f, _, _ in recs)
+                ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+                traffic, traffic_note = pmc_traffic_per_launch(B, self.lora)
+                res["roofline"] = {
+                    "kernel": "gemm_nt256_kernel", "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
+                    "algorithmic_bytes_per_launch_avg": round(sum(nb for _, _, nb in big) / max(len(big), 1)),
+                    "launches": len(big), "avg_launch_us": round(ms * 1e3 / max(len(big), 1), 2),
+                    "flops_per_launch_avg": round(flops / max(len(big), 1)),
+                    "all_nt_gemm_launches": len(recs),
+                    "all_nt_gemm_tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 1) if all_ms > 0 else 0.0,
+                }
+        rt.IS_DISTRIBUTED = False
+        del audio
+        return res
+
+    def release(self):
+        self.net = self.model = self.opt = self.sched = None
+        import gc
+
+        gc.collect()
+        torch.cuda.empty_cache()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -158,6 +320,9 @@ def main():
     ap.add_argument("--deep-spec-augment", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the headline line: skip the reference-YAML shapes (B=32 at S=128 / S=448), the hand-rolled-loop "
+                         "cross-check and the LoRA+Muon (configs[2]) sub-bench")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -171,7 +336,8 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     force_ddp = os.environ.get("WFT_BENCH_FORCE_DDP") == "1"  # exercise the DDP wrapper on one GPU (1-rank RCCL group)
-    if world > 1 or force_ddp:
+    ddp = world > 1 or force_ddp
+    if ddp:
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
@@ -179,124 +345,58 @@ def main():
         else:
             dist.init_process_group(backend="nccl")  # RCCL over xGMI
 
-    from whisper_finetune.data.gpu_frontend import GpuFrontend
-    from whisper_finetune.engine import kernels as K
     from whisper_finetune.engine import lib as L
 
     L.load()
-    model, dims = build_model(args.model, device, args.stochastic_depth)
-    if args.lora:
-        from whisper_finetune.model.lora import apply_lora
-
-        apply_lora(model, {"rank": 16, "lora_alpha": 32, "lora_dropout": 0.1})
-    if args.deep_spec_augment:
-        from whisper_finetune.model.model_utils import register_deep_spec_augment_hooks
-
-        register_deep_spec_augment_hooks(model, 100, 43)
-    model.train()
     B, S = args.batch, args.seq
-    torch.manual_seed(1234 + rank)  # per-rank host RNG (finetune.py:325)
-    gen = torch.Generator(device=device).manual_seed(1234 + rank)
-    audio = torch.randn(B, 480000, device=device, generator=gen) * 0.1  # resident in HBM
-    y_in, y_out = synthetic_tokens(B, S, device, rank)
-    frontend = GpuFrontend(dims.n_mels, device, spec_augment=True,
-                           spec_augment_params={"time_mask_param": 100, "freq_mask_param": 43, "time_warp_w": 80, "p": 1.0})
-    from whisper_finetune.model.optimizer import WftAdamW, get_optimizer
-
-    if args.muon:
-        opt = get_optimizer(model, {"type": "adamw", "muon": True, "8bit": False, "muon_params": {"lr": 2e-5, "momentum": 0.95, "weight_decay": 0.01},
-                                    "params": {"lr": 2e-5, "weight_decay": 0.01, "betas": [0.9, 0.98], "eps": 1e-6}}, is_lora_run=args.lora)
+    headline_default = args.model == "large-v3" and not (args.lora or args.muon or args.stochastic_depth > 0 or args.deep_spec_augment)
+    extras = headline_default and not args.no_extras
+    case = Case(args, device, rank, local_rank, world, ddp, lora=args.lora, muon=args.muon, sd=args.stochastic_depth,
+                dsa=args.deep_spec_augment)
+    head = case.measure(B, S, args.steps, args.warmup, roofline=not args.no_roofline, hand_rolled_steps=3 if extras else 0)
+    hbm_peak = round(torch.cuda.max_memory_allocated() / 2**30, 1)
+    other = []
+    lora_line = None
+    if extras:
+        # the shapes a user of the reference's YAML runs (configs/config_large_v3_best_muon.yaml:56 batch_size 32): the primary
+        # S = 128 and the max-context stress S = 448; same model / optimizer state, 2 + 4 steps each
+        for b2, s2 in ((32, 128), (32, 448)):
+            other.append(case.measure(b2, s2, 4, 2, roofline=False))
+        mode = case.mode()
+        dims = case.dims
+        case.release()
+        # BASELINE configs[2]: large-v3 LoRA r16 + Muon/AuxAdam + stochastic depth 0.1 + deep SpecAugment at the YAML's B = 32
+        c2 = Case(args, device, rank, local_rank, world, ddp, lora=True, muon=True, sd=0.1, dsa=True)
+        lora_line = c2.measure(32, 128, 4, 2, roofline=not args.no_roofline)
+        lora_line["workload"] = f"whisper-large-v3 {c2.mode()}, 32 clips per GPU per step, S=128 (BASELINE configs[2] shape)"
+        c2.release()
     else:
-        # one wft_mt_sumsq + one wft_mt_adamw launch per step: clip_grad_norm_(1.0) folded into the AdamW pass
-        opt = WftAdamW([p for p in model.parameters() if p.requires_grad], lr=1e-5, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.1)
-    net = model
-    if world > 1 or force_ddp:
-        from torch.nn.parallel import DistributedDataParallel as DDP
-
-        net = DDP(model, device_ids=[local_rank], output_device=local_rank, broadcast_buffers=False,
-                  gradient_as_bucket_view=True, bucket_cap_mb=64, find_unused_parameters=args.stochastic_depth > 0)
-
-    def step():
-        mel = frontend(audio, training=True)
-        loss = net(mel, y_in, targets=y_out, label_smoothing=0.1)
-        loss.backward()
-        opt.fuse_clip_grad_norm(1.0)
-        opt.step()
-        opt.zero_grad(set_to_none=True)
-        return loss
-
-    def fence():
-        if world > 1 or force_ddp:
-            dist.barrier(device_ids=[local_rank])
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1 or force_ddp:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
-    final_loss = loss.item()
-
-    roofline = None
-    if not args.no_roofline:
-        # one more step with HIP events around every gemm_nt launch (on the launch stream).  EVERY rank runs the step (its
-        # gradient all-reduce is a collective); only rank 0 records.
-        if rank == 0:
-            K.PROFILE_NT = []
-        step()
-        torch.cuda.synchronize()
-    if rank == 0 and not args.no_roofline:
-        recs, K.PROFILE_NT = K.PROFILE_NT, None
-        big = [(s_.elapsed_time(e_), f, nb) for s_, e_, f, v, nb in recs if v == 256]  # gemm_nt256_kernel launches
-        ms = sum(t for t, _, _ in big)
-        flops = sum(f for _, f, _ in big)
-        all_ms = sum(s_.elapsed_time(e_) for s_, e_, _, _, _ in recs)
-        all_fl = sum(f for _, _, f, _, _ in recs)
-        ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        traffic, traffic_note = pmc_traffic_per_launch(B)
-        roofline = {
-            "kernel": "gemm_nt256_kernel", "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
-            "algorithmic_bytes_per_launch_avg": round(sum(nb for _, _, nb in big) / max(len(big), 1)),
-            "launches": len(big), "avg_launch_us": round(ms * 1e3 / max(len(big), 1), 2),
-            "flops_per_launch_avg": round(flops / max(len(big), 1)),
-            "all_nt_gemm_launches": len(recs), "all_nt_gemm_tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 1) if all_ms > 0 else 0.0,
-        }
+        mode, dims = case.mode(), case.dims
 
     if rank == 0:
-        clips = B * world * args.steps
-        value = clips * 30.0 / dt
-        f_fwd, f_att = fwd_flops_per_clip(dims, S), attn_core_flops_per_clip(dims, S)
-        if args.lora:  # frozen base weights: no dW GEMMs
-            step_flops = (2.0 * (f_fwd - f_att) + 3.0 * f_att + 3.0 * lora_flops_per_clip(dims, S, 16)) * B * world
-        else:
-            step_flops = 3.0 * f_fwd * B * world
-        mode = ("LoRA r=16 alpha=32 p=0.1" if args.lora else "full fine-tune") + (", Muon+AuxAdam" if args.muon else ", AdamW") + \
-               (f", stochastic depth {args.stochastic_depth}" if args.stochastic_depth > 0 else "") + (", deep SpecAugment" if args.deep_spec_augment else "")
         out = {
             "metric": "audio-seconds/sec training throughput, whisper-large-v3 bf16",
-            "value": round(value, 1), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "value": head["value"], "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {
                 "workload": f"whisper-{args.model} {mode}, bf16 MFMA / fp32 master weights, {B} synthetic 30 s clips per GPU "
                             f"per step, decoder S={S}, log-mel + SpecAugment on GPU, label smoothing 0.1, clip 1.0, "
-                            f"local accumulation 1 (global window = {world})",
+                            f"local accumulation 1 (global window = {world}); timed loop = model_utils.train_step",
                 "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world}",
             },
-            "step_tflops_per_gpu": round(step_flops / world / (dt / args.steps) / 1e12, 1),
-            "step_frac_of_bf16_peak": round(step_flops / world / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
-            "final_loss": round(final_loss, 4),
-            "hbm_peak_gib": round(torch.cuda.max_memory_allocated() / 2**30, 1),
-            "roofline": roofline,
+            "step_tflops_per_gpu": head["step_tflops_per_gpu"],
+            "step_frac_of_bf16_peak": head["step_frac_of_bf16_peak"],
+            "final_loss": head["final_loss"],
+            "hbm_peak_gib": hbm_peak,
+            "roofline": head.get("roofline"),
         }
+        if "hand_rolled_ms_per_step" in head:
+            out["hand_rolled_ms_per_step"] = head["hand_rolled_ms_per_step"]  # round 1's loop, 3 steps: cross-check of the product loop
+        if other:
+            out["reference_yaml_shapes"] = other
+        if lora_line is not None:
+            out["configs2_lora_muon"] = lora_line
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.model if args.model in ("tiny", "base", "small", "large-v3", "large-v3-turbo") else "large-v3", S)
@@ -305,7 +405,7 @@ def main():
                                        "sample": f"failed: {exc!r}"}
         else:
             out["cpu_baseline"] = None
-    if world > 1 or force_ddp:
+    if ddp:
         dist.destroy_process_group()
     if rank == 0:
         # RCCL writes version / path banners through C stdio (flushed only at exit): push them out first so that the JSON

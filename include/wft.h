@@ -323,6 +323,56 @@ int wft_transpose_bf16(const wft_bf16* src, int rows, int cols, wft_bf16* dst, i
 int wft_muon_apply_mt(const void* tab, int n_mats, int rows, int cols, const wft_bf16* O, int64_t ldo,
                       int64_t stride_o, float lr, float weight_decay, float scale, void* stream);
 
+/* ------------------------------------------------------------ fp32 compute mode */
+/* The reference runs TRUE fp32 when AMP is off (`training.mixed_precision_training: False`: autocast disabled at
+ * model/model_utils.py:64, eval/evaluator.py:69), and the north star asks for parity within 1e-3 relative in that mode.
+ * These entry points are that mode (csrc/f32.hip): fp32 tensors, v_mfma_f32_32x32x2_f32 products, fp32 everywhere else,
+ * fixed summation orders.  It is the parity mode of the small configurations, not a throughput path.
+ *
+ * C[b][m, n] = alpha * sum_k A(b; m, k) * B(b; k, n) (+ beta * C[b][m, n]) (+ bias[n]);
+ *   A(b; m, k) = A[b * a_bs + m * a_rs + k * a_cs],  B(b; k, n) = B[b * b_bs + k * b_rs + n * b_cs]  (element strides:
+ *   NT / TN / NN products and the conv stem's overlapping-window rows — lda < K — are all stride choices);
+ *   C row-major with row stride ldc.  Replaces F.linear / F.conv1d / the attention matmuls / the tied logits matmul of
+ *   whisper.model in fp32 (model/model_utils.py:276-281,316-325).                                   */
+typedef struct {
+  const float* A; int64_t a_rs; int64_t a_cs; int64_t a_bs;
+  const float* B; int64_t b_rs; int64_t b_cs; int64_t b_bs;
+  float* C; int64_t ldc; int64_t c_bs;
+  const float* bias;          /* f32 [N] or NULL */
+  int64_t M; int64_t N; int64_t K; int batch;
+  float alpha; float beta;
+} wft_gemm_f32_args;
+int wft_gemm_f32(const wft_gemm_f32_args* args, void* stream);
+/* In place: row r of s [nrows, cols] (row stride ld) <- softmax(scale * s[r, :]); with causal != 0 the row belongs to
+ * query r % rows_per_mat and columns beyond it are masked (the decoder's -inf upper-triangular mask buffer).
+ * qkv_attention's softmax(qk.float()).                                                             */
+int wft_softmax_fwd_f32(float* s, int64_t nrows, int64_t cols, int64_t ld, float scale, int causal,
+                        int64_t rows_per_mat, void* stream);
+/* dp <- scale * p * (dp - sum_c p[r, c] * dp[r, c])  (gradient w.r.t. the un-scaled scores). */
+int wft_softmax_bwd_f32(const float* p, float* dp, int64_t nrows, int64_t cols, int64_t ld, float scale, void* stream);
+/* whisper.model.LayerNorm in fp32 (+ the deep-SpecAugment mask, model/model_utils.py:409-417):
+ * mask = int32 {rows_per_batch, t0, t1, c0, c1} in HOST memory or NULL.                                                 */
+int wft_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                          int64_t rows, int cols, float eps, const int32_t* mask, void* stream);
+int wft_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                          float* dx, float* dgamma, float* dbeta, int64_t rows, int cols, const int32_t* mask, void* stream);
+int wft_gelu_fwd_f32(const float* x, float* y, int64_t n, void* stream);                 /* exact-erf GELU             */
+int wft_gelu_bwd_f32(const float* dy, const float* x, float* dx, int64_t n, void* stream);
+int wft_axpby_f32(float a, const float* x, float b, const float* y, float* out, int64_t n, void* stream); /* y may be NULL */
+int wft_colsum_f32(const float* x, int64_t rows, int64_t cols, int64_t ld, float* out, void* stream);     /* bias grads   */
+/* out[b, s, :] = emb[tokens[b, s], :] + pos[s, :]  (model/model_utils.py:316-318); the backward needs demb zero-filled. */
+int wft_embed_fwd_f32(const int64_t* tokens, const float* emb, const float* pos, float* out, int64_t B, int64_t S, int d,
+                      void* stream);
+int wft_embed_bwd_f32(const int64_t* tokens, const float* dout, float* demb, float* dpos, int64_t B, int64_t S, int d,
+                      void* stream);
+/* F.cross_entropy(logits.transpose(1, 2), y_out, label_smoothing) on fp32 logits (model/model_utils.py:66): row losses,
+ * row logsumexp, stats = {sum of row losses, number of non-ignored rows}; the backward overwrites the logits with
+ * gscale / n_valid * (softmax - (1 - eps) onehot - eps / V).                                                            */
+int wft_ce_fwd_f32(const float* logits, int64_t ld, const int64_t* targets, int64_t rows, int64_t V, float label_smoothing,
+                   float* row_loss, float* row_lse, float* stats, void* stream);
+int wft_ce_bwd_f32(float* logits, int64_t ld, const int64_t* targets, int64_t rows, int64_t V, float label_smoothing,
+                   const float* row_lse, const float* stats, const float* gscale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

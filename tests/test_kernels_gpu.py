@@ -346,6 +346,25 @@ def test_gemm_tn_split_k_is_bitwise_reproducible():
     close(acc, c1 + 1, 1e-6)
 
 
+@pytest.mark.parametrize("R,P,Q", [(48000, 128, 1280), (3000, 384, 1536), (24000, 1280, 128)])
+def test_gemm_tn_128_tile_split_k_is_bitwise_reproducible(R, P, Q):
+    """The 128x128 weight-gradient kernel (rank-r LoRA gradients, small models) splits the reduction up to 64 ways; its
+    partial tiles go through the workspace + fixed-order reduce as well, so repeated launches agree bit for bit, with and
+    without accumulation into C."""
+    g = torch.Generator(device=DEV).manual_seed(R + P)
+    a = bf(torch.randn(R, P, device=DEV, generator=g)); b = bf(torch.randn(R, Q, device=DEV, generator=g))
+    outs = [K.gemm_tn(a, b) for _ in range(4)]
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    close(outs[0], a.float().t() @ b.float(), 2e-5)
+    accs = []
+    for _ in range(2):
+        acc = torch.full((P, Q), 0.5, device=DEV)
+        K.gemm_tn(a, b, out=acc, accumulate=True)
+        accs.append(acc)
+    assert torch.equal(accs[0], accs[1])
+    close(accs[0], outs[0] + 0.5, 1e-6)
+
+
 @pytest.mark.parametrize("rows,cols,r,masked", [(384, 384, 16, True), (1536, 384, 4, False), (100, 200, 64, True)])
 def test_lora_merge_matches_minlora_parametrization(rows, cols, r, masked):
     """wft_lora_merge: W + s*B@(A*mask) as f32 (merge_lora) and as padded bf16 shadows (+T) for the GEMMs."""

@@ -734,7 +734,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmP p) {
     // stage the wave's 64(p) x 64(q) fp32 tile through LDS (two halves of 32 p-rows, row pitch 68
     // floats) so that every atomic wave-instruction adds one contiguous 256-byte row of C
     float* lds = (float*)(smem + wave * 16384);
-    float* cbase = (float*)p.C + (long)(p0 + wp * 64) * p.ldc + q0 + wq * 64 + lane;
+    // with a workspace (the default: wft_gemm_tn_workspace_bytes) the partial tile of split blockIdx.y is STORED to
+    // ws[split][P][Q] and tn_splitk_reduce_kernel adds the splits in index order: bitwise reproducible.  Without one the
+    // partial tiles are added into C with fp32 atomics (order, hence rounding, varies run to run).
+    float* cbase = p.ws ? p.ws + ((long)blockIdx.y * P + p0 + wp * 64) * Q + q0 + wq * 64 + lane
+                        : (float*)p.C + (long)(p0 + wp * 64) * p.ldc + q0 + wq * 64 + lane;
+    const long cld = p.ws ? (long)Q : p.ldc;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -743,8 +748,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmP p) {
         for (int i = 0; i < 4; ++i)
           *(f32x4*)(lds + (jj * 16 + li) * 68 + i * 16 + 4 * g) = acc[i][half * 2 + jj] * p.alpha;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (p.ws) {
 #pragma unroll 8
-      for (int r = 0; r < 32; ++r) atomicAdd(cbase + (long)(half * 32 + r) * p.ldc, lds[r * 68 + lane]);
+        for (int r = 0; r < 32; ++r) cbase[(long)(half * 32 + r) * cld] = lds[r * 68 + lane];
+      } else {
+#pragma unroll 8
+        for (int r = 0; r < 32; ++r) atomicAdd(cbase + (long)(half * 32 + r) * cld, lds[r * 68 + lane]);
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     return;
@@ -1038,16 +1048,36 @@ static int fill_params(const wft_gemm_args* a, GemmP& p) {
   return 0;
 }
 
-static int wft_num_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-    if (n <= 0) n = 256;
-  }
-  return n;
+#define WFT_MAX_DEVICES 64
+static int wft_cur_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= WFT_MAX_DEVICES) dev = 0;
+  return dev;
 }
+// CU count of the CURRENT device (cached per device id: a process may drive several GPUs)
+static int wft_num_cus() {
+  static int n[WFT_MAX_DEVICES] = {0};
+  const int dev = wft_cur_device();
+  if (n[dev] == 0) {
+    hipDeviceProp_t prop;
+    int v = 0;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) v = prop.multiProcessorCount;
+    n[dev] = v > 0 ? v : 256;
+  }
+  return n[dev];
+}
+// hipFuncSetAttribute is per device: remember, per kernel call site, which devices have it
+struct DynLdsOnce {
+  bool done[WFT_MAX_DEVICES] = {false};
+  template <class K>
+  void set(K kfn, int bytes) {
+    const int dev = wft_cur_device();
+    if (!done[dev]) {
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+      done[dev] = true;
+    }
+  }
+};
 // out[col] = sum over `nrows` partial rows (fixed order): finishes the fused bias-gradient column sums of gemm_nt256_kernel
 __global__ __launch_bounds__(256) void nt_colsum_reduce_kernel(const float* partial, int nrows, int n, float* out) {
   __shared__ float red[8][33];
@@ -1115,8 +1145,8 @@ extern "C" int wft_gemm_nt_bf16(const wft_gemm_args* a, void* stream) {
 #define LAUNCH_256(E, F)                                                                                   \
   do {                                                                                                    \
     auto kfn = gemm_nt256_kernel<E, F>;                                                                   \
-    static bool done = false;                                                                             \
-    if (!done) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 163840); done = true; } \
+    static DynLdsOnce once;                                                                               \
+    once.set(kfn, 163840);                                                                                \
     hipLaunchKernelGGL(kfn, grid, block, 163840, s, p);                                                   \
   } while (0)
     switch (a->epilogue) {
@@ -1173,11 +1203,31 @@ static int tn256_nsplit(const wft_gemm_args* a) {
     const double eff = waves / (double)((long)(waves + 0.999999));
     if (eff > best + 0.02) { best = eff; nsplit = sp; }
   }
-  return nsplit;
+  // the kernel gives split y the slab range [y * per, (y + 1) * per), per = ceil(nslabs / nsplit): drop the splits that range
+  // leaves EMPTY (they would return before storing their workspace tile, and the reduce kernel would add garbage)
+  const long per = (nslabs + nsplit - 1) / nsplit;
+  return (int)((nslabs + per - 1) / per);
+}
+// 128x128 path: split-K factor that fills the 512 resident-block slots (256 CUs x 2) in whole waves
+static int tn128_nsplit(const wft_gemm_args* a) {
+  if (!a->c_is_f32) return 1;
+  const long tiles = (a->M / 128) * (a->N / 128);
+  const long nsteps = ((a->K + 63) / 64) * a->batch;
+  int nsplit = 1;
+  double best = 0.0;
+  // up to 64 splits: rank-r LoRA gradients are ONE 128-wide tile row (10-40 tiles) over a 48 000+ row reduction
+  for (int sp = 1; sp <= 64; ++sp) {
+    if (sp > 1 && nsteps / sp < (sp <= 8 ? 16 : 12)) break;
+    const double waves = (double)(tiles * sp) / 512.0;
+    const double eff = waves / (double)((long)(waves + 0.999999));
+    if (eff > best + 0.03) { best = eff; nsplit = sp; }
+  }
+  const long per = (nsteps + nsplit - 1) / nsplit;  // no empty split (see tn256_nsplit)
+  return (int)((nsteps + per - 1) / per);
 }
 extern "C" int64_t wft_gemm_tn_workspace_bytes(const wft_gemm_args* a) {
-  if (!a || !tn_uses_256(a)) return 0;
-  const int nsplit = tn256_nsplit(a);
+  if (!a) return 0;
+  const int nsplit = tn_uses_256(a) ? tn256_nsplit(a) : tn128_nsplit(a);
   return nsplit > 1 ? (int64_t)nsplit * a->M * a->N * 4 : 0;
 }
 
@@ -1203,9 +1253,9 @@ extern "C" int wft_gemm_tn_bf16(const wft_gemm_args* a, void* stream) {
     if (use_ws) p.ws = (float*)a->workspace;
     if (nsplit > 1 && !use_ws && !a->accumulate)
       (void)hipMemset2DAsync(a->C, (size_t)a->ldc * 4, 0, (size_t)a->N * 4, (size_t)a->M, s);
-    static bool done = false;
+    static DynLdsOnce once;
     auto kfn = gemm_tn256_kernel<true>;
-    if (!done) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); done = true; }
+    once.set(kfn, 131072);
     hipLaunchKernelGGL(kfn, dim3((unsigned)t256, (unsigned)nsplit), dim3(512), 131072, s, p);
     if (use_ws) {
       const long total = a->M * (a->N / 4);
@@ -1218,23 +1268,22 @@ extern "C" int wft_gemm_tn_bf16(const wft_gemm_args* a, void* stream) {
     return WFT_OK;
   }
   const long tiles = (a->M / 128) * (a->N / 128);
-  // split-K factor: fill the 512 resident-block slots (256 CUs x 2) in whole waves
-  int nsplit = 1;
-  if (a->c_is_f32) {
-    double best = 0.0;
-    // up to 64 splits: rank-r LoRA gradients are ONE 128-wide tile row (10-40 tiles) over a 48 000+ row reduction
-    for (int sp = 1; sp <= 64; ++sp) {
-      if (sp > 1 && nsteps / sp < (sp <= 8 ? 16 : 12)) break;
-      const double waves = (double)(tiles * sp) / 512.0;
-      const double eff = waves / (double)((long)(waves + 0.999999));
-      if (eff > best + 0.03) { best = eff; nsplit = sp; }
-    }
-  }
-  if (nsplit > 1 && !a->accumulate)
+  const int nsplit = tn128_nsplit(a);
+  const bool use_ws = nsplit > 1 && a->workspace && a->workspace_bytes >= (int64_t)nsplit * a->M * a->N * 4 &&
+                      (((uintptr_t)a->workspace) & 15) == 0;
+  if (use_ws) p.ws = (float*)a->workspace;
+  if (nsplit > 1 && !use_ws && !a->accumulate)
     (void)hipMemset2DAsync(a->C, (size_t)a->ldc * 4, 0, (size_t)a->N * 4, (size_t)a->M, s);
   dim3 grid((unsigned)tiles, (unsigned)nsplit), block(256);
   if (a->c_is_f32) hipLaunchKernelGGL((gemm_tn_kernel<true>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((gemm_tn_kernel<false>), grid, block, 0, s, p);
+  if (use_ws) {
+    const long total = a->M * (a->N / 4);
+    long g = (total + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(tn_splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, (const float*)a->workspace, (float*)a->C,
+                       (long)a->ldc, (int)a->M, (int)a->N, nsplit, a->accumulate);
+  }
   WFT_CHECK_LAUNCH();
   return WFT_OK;
 }

@@ -318,18 +318,18 @@ extern "C" int wft_dgelu_mul_bf16(const wft_bf16* dy, const wft_bf16* pre, wft_b
 }
 
 // ----------------------------------------------------------------------------- column sums
-// grid (cols/8 chunks per 16-thread group ...): block = 16 column-threads (8 cols each = 128 cols) x 16 row-lanes
+// out[c] (+)= sum_r x[r, c] without atomics (bitwise reproducible): a workgroup owns 32 columns for ALL rows — 4 column
+// threads (16 bytes = 8 columns each, 64-byte row segments) x 64 row lanes — and folds its 64 partial rows in a fixed tree.
+// Only reached where no producer kernel has formed the sums already (small models, the conv stem): the bf16 hot path gets
+// its bias gradients from the LayerNorm-backward / GEMM / attention epilogues.
 __global__ __launch_bounds__(256) void colsum_kernel(const unsigned short* x, long rows, long cols, long ld, float* out,
-                                                      int rows_per_split) {
-  __shared__ float red[16][128];
-  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
-  const long c0 = (long)blockIdx.x * 128 + cx * 8;
-  const long rbeg = (long)blockIdx.y * rows_per_split;
-  long rend = rbeg + rows_per_split;
-  if (rend > rows) rend = rows;
+                                                      int accumulate) {
+  __shared__ float red[64][33];
+  const int cx = threadIdx.x & 3, ry = threadIdx.x >> 2;
+  const long c0 = (long)blockIdx.x * 32 + cx * 8;
   float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (c0 < cols) {
-    for (long r = rbeg + ry; r < rend; r += 16) {
+    for (long r = ry; r < rows; r += 64) {
       const u32x4 v = *(const u32x4*)(x + r * ld + c0);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -341,12 +341,16 @@ __global__ __launch_bounds__(256) void colsum_kernel(const unsigned short* x, lo
 #pragma unroll
   for (int e = 0; e < 8; ++e) red[ry][cx * 8 + e] = s[e];
   __syncthreads();
-  if (threadIdx.x < 128) {
-    float t = 0.f;
+  for (int o = 32; o > 0; o >>= 1) {
+    if (ry < o) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
-    const long c = (long)blockIdx.x * 128 + threadIdx.x;
-    if (c < cols) atomicAdd(out + c, t);
+      for (int e = 0; e < 8; ++e) red[ry][cx * 8 + e] += red[ry + o][cx * 8 + e];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 32) {
+    const long c = (long)blockIdx.x * 32 + threadIdx.x;
+    if (c < cols) out[c] = accumulate ? out[c] + red[0][threadIdx.x] : red[0][threadIdx.x];
   }
 }
 extern "C" int wft_colsum_bf16(const wft_bf16* x, int64_t rows, int64_t cols, int64_t ld, float* out, int accumulate,
@@ -354,13 +358,8 @@ extern "C" int wft_colsum_bf16(const wft_bf16* x, int64_t rows, int64_t cols, in
   WFT_CHECK_ARG(x && out, "null pointer");
   WFT_CHECK_ARG(rows >= 1 && cols >= 8 && cols % 8 == 0 && ld % 8 == 0, "cols/ld must be multiples of 8");
   WFT_CHECK_ARG((((uintptr_t)x) & 15) == 0, "16-byte alignment");
-  hipStream_t s = (hipStream_t)stream;
-  if (!accumulate) (void)hipMemsetAsync(out, 0, cols * sizeof(float), s);
-  int nsplit = (int)((rows + 511) / 512);
-  if (nsplit > 64) nsplit = 64;
-  const int rps = (int)((rows + nsplit - 1) / nsplit);
-  dim3 grid((unsigned)((cols + 127) / 128), (unsigned)nsplit);
-  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, x, (long)rows, (long)cols, (long)ld, out, rps);
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((cols + 31) / 32)), dim3(256), 0, (hipStream_t)stream, x, (long)rows, (long)cols,
+                     (long)ld, out, accumulate);
   WFT_CHECK_LAUNCH();
   return WFT_OK;
 }
@@ -395,14 +394,30 @@ extern "C" int wft_embed_fwd(const int64_t* tokens, const float* emb, const floa
   return WFT_OK;
 }
 
+// demb[tok] += dout[position] for every position holding `tok`, WITHOUT atomics (a token id usually occurs at several
+// positions — the special tokens at every clip's start — and fp32 atomics would add them in a run-dependent order): a
+// workgroup owns 16 consecutive vocabulary rows, scans the token list in chunks of 256 and adds the positions that fall
+// into its rows in position order (read-modify-write of rows nobody else touches).  ~V/16 blocks x n_tok/256 chunk scans of
+// an L2-resident list.
 __global__ __launch_bounds__(256) void embed_bwd_tok_kernel(const long* tokens, const unsigned short* dout, float* demb,
                                                              long n_tok, int d, long V) {
-  const long total = n_tok * d;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long t = i / d;
-    const int c = (int)(i - t * d);
-    const long tok = tokens[t];
-    if (tok >= 0 && tok < V) atomicAdd(demb + tok * d + c, bf2f(dout[i]));
+  __shared__ int hit[256];
+  const long row0 = (long)blockIdx.x * 16;
+  for (long base = 0; base < n_tok; base += 256) {
+    const long j = base + threadIdx.x;
+    const long tok = j < n_tok ? tokens[j] : -1;
+    const bool mine = tok >= row0 && tok < row0 + 16 && tok < V;
+    if (!__syncthreads_or(mine)) continue;  // block-uniform
+    hit[threadIdx.x] = mine ? (int)(tok - row0) : -1;
+    __syncthreads();
+    for (int t = 0; t < 256; ++t) {
+      const int r = hit[t];  // LDS broadcast: uniform
+      if (r < 0) continue;
+      const unsigned short* src = dout + (base + t) * d;
+      float* dst = demb + (row0 + r) * d;
+      for (int c = threadIdx.x; c < d; c += 256) dst[c] += bf2f(src[c]);
+    }
+    __syncthreads();
   }
 }
 __global__ __launch_bounds__(256) void embed_bwd_pos_kernel(const unsigned short* dout, float* dpos, long B, long S, int d) {
@@ -418,7 +433,7 @@ extern "C" int wft_embed_bwd(const int64_t* tokens, const wft_bf16* dout, float*
   WFT_CHECK_ARG(tokens && dout && demb && dpos, "null pointer");
   WFT_CHECK_ARG(B >= 1 && S >= 1 && d >= 1 && V >= 1, "bad shape");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(embed_bwd_tok_kernel, dim3(ew_grid(B * S * d)), dim3(256), 0, s, (const long*)tokens, dout, demb,
+  hipLaunchKernelGGL(embed_bwd_tok_kernel, dim3((unsigned)((V + 15) / 16)), dim3(256), 0, s, (const long*)tokens, dout, demb,
                      (long)(B * S), d, (long)V);
   hipLaunchKernelGGL(embed_bwd_pos_kernel, dim3(ew_grid(S * d)), dim3(256), 0, s, dout, dpos, (long)B, (long)S, d);
   WFT_CHECK_LAUNCH();

@@ -57,6 +57,19 @@ class AttnArgs(C.Structure):
     ]
 
 
+class GemmF32Args(C.Structure):
+    """Mirror of wft_gemm_f32_args (include/wft.h): the fp32 compute mode's strided GEMM."""
+
+    _fields_ = [
+        ("A", c_vp), ("a_rs", c_i64), ("a_cs", c_i64), ("a_bs", c_i64),
+        ("B", c_vp), ("b_rs", c_i64), ("b_cs", c_i64), ("b_bs", c_i64),
+        ("C", c_vp), ("ldc", c_i64), ("c_bs", c_i64),
+        ("bias", c_vp),
+        ("M", c_i64), ("N", c_i64), ("K", c_i64), ("batch", C.c_int),
+        ("alpha", C.c_float), ("beta", C.c_float),
+    ]
+
+
 EPI_NONE, EPI_GELU, EPI_DGELU, EPI_GELU_GRAD, EPI_MUL_AUX = 0, 1, 2, 3, 4
 
 # name -> argtypes (restype is int unless listed in _RESTYPES); this table is also what
@@ -100,6 +113,19 @@ SIGNATURES = {
     "wft_muon_prepare": [c_vp, C.c_int, C.c_int, c_vp, C.c_int, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp],
     "wft_transpose_bf16": [c_vp, C.c_int, C.c_int, c_vp, C.c_int, c_vp],
     "wft_muon_apply_mt": [c_vp, C.c_int, C.c_int, C.c_int, c_vp, c_i64, c_i64, C.c_float, C.c_float, C.c_float, c_vp],
+    "wft_gemm_f32": [C.POINTER(GemmF32Args), c_vp],
+    "wft_softmax_fwd_f32": [c_vp, c_i64, c_i64, c_i64, C.c_float, C.c_int, c_i64, c_vp],
+    "wft_softmax_bwd_f32": [c_vp, c_vp, c_i64, c_i64, c_i64, C.c_float, c_vp],
+    "wft_layernorm_fwd_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_float, c_vp, c_vp],
+    "wft_layernorm_bwd_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, c_vp, c_vp],
+    "wft_gelu_fwd_f32": [c_vp, c_vp, c_i64, c_vp],
+    "wft_gelu_bwd_f32": [c_vp, c_vp, c_vp, c_i64, c_vp],
+    "wft_axpby_f32": [C.c_float, c_vp, C.c_float, c_vp, c_vp, c_i64, c_vp],
+    "wft_colsum_f32": [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp],
+    "wft_embed_fwd_f32": [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, C.c_int, c_vp],
+    "wft_embed_bwd_f32": [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, C.c_int, c_vp],
+    "wft_ce_fwd_f32": [c_vp, c_i64, c_vp, c_i64, c_i64, C.c_float, c_vp, c_vp, c_vp, c_vp],
+    "wft_ce_bwd_f32": [c_vp, c_i64, c_vp, c_i64, c_i64, C.c_float, c_vp, c_vp, c_vp, c_vp],
     "wft_last_error": [],
     "wft_version": [],
 }

@@ -25,6 +25,7 @@ from torch import Tensor, nn
 
 from . import kernels as K
 from . import ops
+from . import ops32
 
 BF16 = torch.bfloat16
 
@@ -82,6 +83,7 @@ class LayerNorm(nn.LayerNorm):
     forward; the mask is applied inside the same kernel."""
 
     deep_spec_augment = None
+    wft_fp32 = False  # Whisper.set_compute_dtype("fp32"): the fp32 compute mode (engine/ops32.py)
 
     def forward(self, x: Tensor) -> Tensor:
         mask = None
@@ -89,17 +91,19 @@ class LayerNorm(nn.LayerNorm):
             m = self.deep_spec_augment()
             if m is not None:
                 mask = (x.shape[1],) + tuple(m)
+        if self.wft_fp32:
+            return ops32.LayerNormFn.apply(x, self.weight, self.bias, self.eps, mask)
         return ops.LayerNormFn.apply(_to_bf16(x), self.weight, self.bias, self.eps, mask)
 
     def fork(self, x: Tensor):
         """(ln(x), residual alias of x) with the residual-gradient add fused in the backward."""
+        if self.wft_fp32 or self._forward_hooks or self._forward_pre_hooks:
+            return self(x), x  # fp32 mode: nothing fused; hooks: honour user hooks (the reference registers them on attn_ln)
         mask = None
         if self.deep_spec_augment is not None and self.training and x.dim() == 3:
             m = self.deep_spec_augment()
             if m is not None:
                 mask = (x.shape[1],) + tuple(m)
-        if self._forward_hooks or self._forward_pre_hooks:
-            return self(x), x  # honour user hooks (the reference registers hooks on attn_ln)
         return ops.LayerNormForkFn.apply(_to_bf16(x), self.weight, self.bias, self.eps, mask)
 
 
@@ -124,8 +128,13 @@ class Linear(nn.Linear):
             return None
         return self.parametrizations.weight[0].spec(self.training)
 
+    wft_fp32 = False
+
     def forward(self, x: Tensor, residual: Optional[Tensor] = None) -> Tensor:
         shape = x.shape
+        if self.wft_fp32:
+            y = ops32.linear(x, self.base_weight(), self.bias, self.lora_spec())
+            return y if residual is None else ops32.add(y, residual.view(y.shape))
         y = ops.linear(_as2d(_to_bf16(x)), self._group(), [self.base_weight()], [self.bias], [self.lora_spec()],
                        residual=None if residual is None else _as2d(residual))
         return y.view(*shape[:-1], y.shape[-1])
@@ -146,6 +155,7 @@ class MultiHeadAttention(nn.Module):
         self.out = Linear(n_state, n_state)
         self._qkv_group = ops.LinearGroup()
         self._kv_group = ops.LinearGroup()
+        self.wft_fp32 = False
 
     def forward(self, x: Tensor, xa: Optional[Tensor] = None, mask: Optional[Tensor] = None, kv_cache: Optional[dict] = None,
                 residual: Optional[Tensor] = None):
@@ -155,6 +165,10 @@ class MultiHeadAttention(nn.Module):
         if kv_cache:
             raise NotImplementedError("kv_cache is an inference feature; the training/eval path is teacher-forced")
         B, T, d = x.shape
+        if self.wft_fp32:  # fp32 mode: separate projections, strided per-head GEMMs, materialised probabilities
+            src = x if xa is None else xa
+            o = ops32.AttentionFn.apply(self.query(x), self.key(src), self.value(src), self.n_head, xa is None and mask is not None)
+            return self.out(o, residual=residual), None
         x2 = _as2d(_to_bf16(x))
         if xa is None:
             lin = [self.query, self.key, self.value]
@@ -176,9 +190,13 @@ class MLP(nn.Sequential):
     """Sequential(Linear(d,4d), GELU(), Linear(4d,d)) — keys mlp.0 / mlp.2 — evaluated as two GEMMs
     with GELU fused in the first epilogue and gelu' fused in the backward-data epilogue."""
 
+    wft_fp32 = False
+
     def forward(self, x: Tensor, residual: Optional[Tensor] = None) -> Tensor:
         fc1, fc2 = self[0], self[2]
         shape = x.shape
+        if self.wft_fp32:
+            return fc2(ops32.GeluFn.apply(fc1(x)), residual=residual)
         x2 = _as2d(_to_bf16(x))
         pre, act = ops.linear(x2, fc1._group(), [fc1.base_weight()], [fc1.bias], [fc1.lora_spec()], gelu_out=True)
         y = ops.linear(act, fc2._group(), [fc2.base_weight()], [fc2.bias], [fc2.lora_spec()],
@@ -219,12 +237,16 @@ class AudioEncoder(nn.Module):
         )
         self.ln_post = LayerNorm(n_state)
         self._stem_cache: dict = {}
+        self.wft_fp32 = False
 
     def stem(self, x: Tensor) -> Tensor:
         """gelu(conv1) -> gelu(conv2) -> permute -> + positional_embedding; x f32 [B, n_mels, 2*n_ctx]."""
         if x.dim() != 3 or x.shape[1] != self.conv1.in_channels:
             raise ValueError(f"expected mel [B, {self.conv1.in_channels}, T], got {tuple(x.shape)}")
         assert x.shape[2] // 2 == self.positional_embedding.shape[0] and x.shape[2] % 2 == 0, "incorrect audio shape"
+        if self.wft_fp32:
+            return ops32.ConvStemFn.apply(x.float(), self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias,
+                                          self.positional_embedding)
         c_pad = K.round_up(self.conv1.in_channels, 128)
         mel_t = K.mel_to_tmajor(x.float(), c_pad)
         return ops.ConvStemFn.apply(mel_t, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias,
@@ -249,8 +271,11 @@ class TextDecoder(nn.Module):
         mask = torch.empty(n_ctx, n_ctx).fill_(-np.inf).triu_(1)
         self.register_buffer("mask", mask, persistent=False)
         self._logit_group = ops.LinearGroup()
+        self.wft_fp32 = False
 
     def embed(self, tokens: Tensor) -> Tensor:
+        if self.wft_fp32:
+            return ops32.EmbedFn.apply(tokens, self.token_embedding.weight, self.positional_embedding)
         return ops.EmbedFn.apply(tokens, self.token_embedding.weight, self.positional_embedding)
 
     def hidden(self, x: Tensor, xa: Tensor, kv_cache: Optional[dict] = None) -> Tensor:
@@ -260,12 +285,16 @@ class TextDecoder(nn.Module):
         return self.ln(x)
 
     def padded_logits(self, h: Tensor) -> Tensor:
-        """bf16 [B*S, V rounded up to 128] (columns >= V are zero-weight padding)."""
+        """bf16 [B*S, V rounded up to 128] (columns >= V are zero-weight padding); fp32 mode: f32 [B*S, V]."""
+        if self.wft_fp32:
+            return ops32.TiedLogitsFn.apply(h, self.token_embedding.weight)
         return ops.TiedLogitsFn.apply(_as2d(h), self.token_embedding.weight, self._logit_group)
 
     def logits_from_hidden(self, h: Tensor) -> Tensor:
         B, S, _ = h.shape
         V = self.token_embedding.weight.shape[0]
+        if self.wft_fp32:
+            return self.padded_logits(h).view(B, S, V)
         return self.padded_logits(h)[:, :V].float().view(B, S, V)
 
     def forward(self, x: Tensor, xa: Tensor, kv_cache: Optional[dict] = None):
@@ -273,16 +302,21 @@ class TextDecoder(nn.Module):
 
 
 def check_amp_request(model, mixed_precision: bool, mp_dtype: str) -> None:
-    """The engine computes with bf16 MFMA inputs, fp32 accumulation and fp32 master weights — the arithmetic of the reference's
-    `autocast(dtype=bfloat16)` (model/model_utils.py:37-48,64).  A caller that asks an engine model for true fp32
-    (`mixed_precision_training: False`) or for fp16 autocast gets an error instead of silently different numerics; other
-    modules (the reference's tests drive train_step with plain nn.Modules) are not concerned."""
+    """The engine has two compute modes: bf16 (MFMA inputs bf16, fp32 accumulation, fp32 master weights — the arithmetic of the
+    reference's `autocast(dtype=bfloat16)`, model/model_utils.py:37-48,64) and fp32 (engine/ops32.py — the reference with AMP
+    off).  A request that does not match the model's mode, or fp16 autocast, raises instead of silently computing with
+    different numerics; other modules (the reference's tests drive train_step with plain nn.Modules) are not concerned."""
     if not isinstance(model, Whisper):
         return
     if not mixed_precision:
-        raise ValueError("training.mixed_precision_training: False asks for fp32 compute, which the libwft engine does not build "
-                         "(bf16 MFMA inputs, fp32 accumulation, fp32 master weights); set mixed_precision_training: True and "
-                         "mp_dtype: bf16")
+        if model.compute_dtype != "fp32":
+            raise ValueError("training.mixed_precision_training: False asks for fp32 compute but this model is in its bf16 mode: "
+                             "call model.set_compute_dtype('fp32') first (scripts/finetune.py does) — the engine never computes "
+                             "bf16 silently where the reference computes fp32")
+        return
+    if model.compute_dtype == "fp32":
+        raise ValueError("the model is in its fp32 compute mode but mixed_precision_training: True asks for 16-bit autocast: "
+                         "call model.set_compute_dtype('bf16')")
     if mp_dtype == "fp16":
         raise ValueError("training.mp_dtype: fp16 asks for fp16 autocast + loss scaling; the libwft engine computes in bf16 "
                          "(same 16-bit storage, 8-bit exponent, no GradScaler needed): set mp_dtype: bf16 "
@@ -290,7 +324,18 @@ def check_amp_request(model, mixed_precision: bool, mp_dtype: str) -> None:
 
 
 class Whisper(nn.Module):
-    wft_compute_dtype = "bf16"
+    compute_dtype = "bf16"
+
+    def set_compute_dtype(self, dtype: str) -> "Whisper":
+        """"bf16" (default: the throughput path) or "fp32" (parity mode, engine/ops32.py).  Call again after swapping in
+        new sub-modules (scripts/finetune.py does, after the checkpointed encoder / decoder classes and layer resizing)."""
+        if dtype not in ("bf16", "fp32"):
+            raise ValueError(f"compute dtype must be 'bf16' or 'fp32', got {dtype!r}")
+        self.compute_dtype = dtype
+        for m in self.modules():
+            if hasattr(m, "wft_fp32"):
+                m.wft_fp32 = dtype == "fp32"
+        return self
 
     def __init__(self, dims: ModelDimensions):
         super().__init__()
@@ -331,6 +376,8 @@ class Whisper(nn.Module):
         """Fused equivalent of F.cross_entropy(model(mel, tokens).transpose(1, 2), targets, label_smoothing)
         (model/model_utils.py:65-66) that never materialises fp32 logits."""
         h = self.decoder.hidden(tokens, self.encoder(mel))
+        if self.compute_dtype == "fp32":
+            return ops32.CrossEntropyFn.apply(self.decoder.padded_logits(h), targets.reshape(-1).contiguous(), float(label_smoothing))
         return ops.FusedCEFn.apply(self.decoder.padded_logits(h), targets.reshape(-1), self.dims.n_vocab, float(label_smoothing))
 
 

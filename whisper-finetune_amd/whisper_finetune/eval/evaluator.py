@@ -29,7 +29,7 @@ def _default_tokenizer():
 def _batch_token_stats(model, x, y_in, y_out):
     """-> (argmax i64 [B,S], stats f32 [B,S,4]) on the host; fused kernel when the model is the engine's."""
     core = rt.unwrap_model(model)
-    if hasattr(core, "decoder") and hasattr(core.decoder, "padded_logits") and x.is_cuda:
+    if hasattr(core, "decoder") and hasattr(core.decoder, "padded_logits") and x.is_cuda and getattr(core, "compute_dtype", "bf16") == "bf16":
         from whisper_finetune.engine import kernels as K
 
         h = core.decoder.hidden(y_in, core.encoder(x))

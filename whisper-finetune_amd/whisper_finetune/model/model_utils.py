@@ -204,6 +204,10 @@ class StochasticDepthMixin:
                 from whisper_finetune.engine.ops import SdRescaleFn
 
                 return SdRescaleFn.apply(x, out, keep)  # one fused pass
+            if x.is_cuda and x.dtype == torch.float32 and getattr(self, "wft_fp32", False):
+                from whisper_finetune.engine.ops32 import sd_rescale
+
+                return sd_rescale(x, out, keep)  # the fp32 compute mode
             return x + (out - x) / keep  # block(x) already contains the skip connection
         return out
 

@@ -157,14 +157,15 @@ def main_loop(model, train_loader, dev_loaders, optimizer, scheduler, save_dir, 
     return losses
 
 
-def resolve_precision(t_cfg: dict) -> None:
-    """Map the YAML's precision request onto what the engine computes (bf16 MFMA inputs, fp32 accumulate, fp32 masters).
-    Every shipped reference YAML says `mp_dtype: fp16`; on MI355X that becomes bf16 autocast without a GradScaler — said
-    loudly, once, and recorded in the config dump — while a request for pure fp32 is refused (engine/whisper_model.py:
-    check_amp_request)."""
+def resolve_precision(t_cfg: dict) -> str:
+    """Map the YAML's precision request onto the engine's two compute modes -> "bf16" | "fp32".
+    mixed_precision_training: False is the reference's true-fp32 path (model/model_utils.py:37-48,64) = the engine's fp32
+    mode (engine/ops32.py, fp32 MFMA).  Every shipped reference YAML says `mp_dtype: fp16`; on MI355X that becomes bf16
+    autocast (bf16 MFMA inputs, fp32 accumulation and master weights) without a GradScaler — said loudly, once, and recorded
+    in the config dump."""
     if not t_cfg["mixed_precision_training"]:
-        raise ValueError("training.mixed_precision_training: False (fp32 compute) is not built on the libwft engine; use "
-                         "mixed_precision_training: True with mp_dtype: bf16")
+        rt.print_once("mixed_precision_training: False -> fp32 compute mode (parity mode: fp32 MFMA kernels, nothing fused)")
+        return "fp32"
     if t_cfg["mp_dtype"] == "fp16":
         import warnings
 
@@ -174,13 +175,14 @@ def resolve_precision(t_cfg: dict) -> None:
         rt.print_once("WARNING: " + msg)
         t_cfg["wft_requested_mp_dtype"] = "fp16"
         t_cfg["mp_dtype"] = "bf16"
+    return "bf16"
 
 
 def main(config: dict):
     device = rt.setup_distributed()
     set_seed(config["seed"] + rt.RANK)
     t_cfg, d_cfg = config["training"], config["dataset"]
-    resolve_precision(t_cfg)
+    compute_dtype = resolve_precision(t_cfg)
     if config.get("model", {}).get("bfloat16", False):
         print("WARNING: config['model']['bfloat16'] is deprecated and will be ignored!")
     config["training"]["global_accum_grad_steps"] = t_cfg["accum_grad_steps"]
@@ -191,6 +193,7 @@ def main(config: dict):
     rt.barrier()
 
     model = build_model(config).to(device)
+    model.set_compute_dtype(compute_dtype)  # after every module swap (checkpointed classes, resizing, LoRA)
     aug = config.get("augmentation", {})
     dsa = aug.get("deep_spec_augment", {})
     if dsa.get("apply", False):
