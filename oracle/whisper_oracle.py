@@ -538,11 +538,13 @@ def synthetic_batch(dims: ModelDimensions, B: int, S: int, seed: int = 1234, n_s
 NS_COEFFS = (3.4445, -4.7750, 2.0315)
 
 
-def zeropower_via_newtonschulz5(G: Tensor, steps: int = 5) -> Tensor:
-    """Quintic Newton-Schulz iteration towards the orthogonal polar factor of G, in bf16 (muon.py)."""
+def zeropower_via_newtonschulz5(G: Tensor, steps: int = 5, dtype=torch.bfloat16) -> Tensor:
+    """Quintic Newton-Schulz iteration towards the orthogonal polar factor of G, in bf16 (muon.py).  `dtype=float32`
+    evaluates the same iteration in fp32: tests use the distance between the two as the update's measured sensitivity to
+    bf16 rounding (weak singular directions are amplified ~3.4x per iteration, rounding noise with them)."""
     assert G.ndim >= 2
     a, b, c = NS_COEFFS
-    X = G.bfloat16()
+    X = G.to(dtype)
     if G.size(-2) > G.size(-1):
         X = X.mT
     X = X / (X.norm(dim=(-2, -1), keepdim=True) + 1e-7)
@@ -555,13 +557,14 @@ def zeropower_via_newtonschulz5(G: Tensor, steps: int = 5) -> Tensor:
     return X
 
 
-def muon_update(grad: Tensor, momentum: Tensor, beta: float = 0.95, ns_steps: int = 5, nesterov: bool = True) -> Tensor:
+def muon_update(grad: Tensor, momentum: Tensor, beta: float = 0.95, ns_steps: int = 5, nesterov: bool = True,
+                ns_dtype=torch.bfloat16) -> Tensor:
     """In place on grad and momentum, as the package does (muon.py muon_update)."""
     momentum.lerp_(grad, 1 - beta)
     update = grad.lerp_(momentum, beta) if nesterov else momentum
     if update.ndim == 4:
         update = update.view(len(update), -1)
-    update = zeropower_via_newtonschulz5(update, steps=ns_steps)
+    update = zeropower_via_newtonschulz5(update, steps=ns_steps, dtype=ns_dtype)
     update *= max(1, grad.size(-2) / grad.size(-1)) ** 0.5
     return update
 
@@ -574,7 +577,7 @@ def adam_update(grad: Tensor, buf1: Tensor, buf2: Tensor, step: int, betas, eps:
     return buf1c / (buf2c.sqrt() + eps)
 
 
-def muon_with_aux_adam_step(param_groups, state: dict) -> None:
+def muon_with_aux_adam_step(param_groups, state: dict, ns_dtype=torch.bfloat16) -> None:
     """One SingleDeviceMuonWithAuxAdam.step() over plain tensors: param_groups are the reference's dicts (use_muon, lr,
     momentum | betas/eps, weight_decay) whose "params" are (p, grad) pairs; `state` maps id(p) -> dict."""
     with torch.no_grad():
@@ -586,7 +589,7 @@ def muon_with_aux_adam_step(param_groups, state: dict) -> None:
                         g = torch.zeros_like(p)
                     if not st:
                         st["momentum_buffer"] = torch.zeros_like(p)
-                    update = muon_update(g, st["momentum_buffer"], beta=group["momentum"])
+                    update = muon_update(g, st["momentum_buffer"], beta=group["momentum"], ns_dtype=ns_dtype)
                     p.mul_(1 - group["lr"] * group["weight_decay"])
                     p.add_(update.reshape(p.shape).to(p.dtype), alpha=-group["lr"])
                 else:

@@ -209,23 +209,43 @@ def test_large_v3_lora_muon_config_step_matches_oracle():
                 "params": {"lr": 2e-5, "weight_decay": 0.01, "betas": [0.9, 0.98], "eps": 1e-6, "amsgrad": False}}
     opt = get_optimizer(m, opt_conf, is_lora_run=True)
     before = {n: p.detach().cpu().clone() for n, p in named.items() if p.requires_grad}
-    ref_groups, ref_p = [], {}
     names_of = {id(p): n for n, p in named.items()}
-    for group in opt.param_groups:
-        pairs = []
-        for p in group["params"]:
-            n = names_of[id(p)]
-            ref_p[n] = before[n].clone()
-            pairs.append((ref_p[n], None if p.grad is None else p.grad.detach().cpu().clone()))
-        ref_groups.append({**{k: v for k, v in group.items() if k != "params"}, "params": pairs})
+
+    def oracle_groups():
+        groups, ref_p = [], {}
+        for group in opt.param_groups:
+            pairs = []
+            for p in group["params"]:
+                n = names_of[id(p)]
+                ref_p[n] = before[n].clone()
+                pairs.append((ref_p[n], None if p.grad is None else p.grad.detach().cpu().clone()))
+            groups.append({**{k: v for k, v in group.items() if k != "params"}, "params": pairs})
+        return groups, ref_p
+
+    g_bf16, ref_bf16 = oracle_groups()
+    g_f32, ref_f32 = oracle_groups()
     opt.step()
-    O.muon_with_aux_adam_step(ref_groups, {})
-    errs = {}
-    for n, want in ref_p.items():
-        d_got, d_want = named[n].detach().cpu() - before[n], want - before[n]
+    O.muon_with_aux_adam_step(g_bf16, {})                          # the package's arithmetic: Newton-Schulz in bf16
+    O.muon_with_aux_adam_step(g_f32, {}, ns_dtype=torch.float32)   # same iteration in fp32: measures the bf16 sensitivity
+    errs, cond = {}, {}
+    for n, want in ref_bf16.items():
+        d_got, d_want, d_f32 = named[n].detach().cpu() - before[n], want - before[n], ref_f32[n] - before[n]
         if d_want.norm() == 0:
             assert d_got.norm() == 0, n
             continue
         errs[n] = ((d_got - d_want).norm() / d_want.norm()).item()
-    worst = _report(errs, "Muon step (update relative error)")
-    assert worst[0][1] < 6e-2, worst  # 15 chained bf16 GEMMs per Newton-Schulz orthogonalisation on both sides
+        cond[n] = ((d_want - d_f32).norm() / d_f32.norm()).item()
+    _report(cond, "Muon step: bf16 vs fp32 Newton-Schulz in the oracle (sensitivity)")
+    worst = _report(errs, "Muon step: gpu vs oracle (update relative error)")
+    # The orthogonalised update of a rank-16 gradient is dominated by its weak singular directions, which five bf16
+    # Newton-Schulz iterations amplify together with their rounding noise: two bf16 evaluations differ by about what bf16
+    # differs from fp32.  Bound = 6e-2 (the well-conditioned case, tests/test_scheduler_optimizer.py) + 2x that sensitivity.
+    import re
+    from collections import defaultdict
+    roles = defaultdict(list)
+    for n, c in cond.items():
+        roles[re.sub(r"blocks\.\d+\.", "blocks.*.", n)].append(c)
+    bad = [(n, e, cond[n]) for n, e in errs.items()
+           if e > 6e-2 + 2 * max(cond[n], float(np.median(roles[re.sub(r"blocks\.\d+\.", "blocks.*.", n)])))]
+    assert not bad, sorted(bad, key=lambda t: -t[1])[:8]
+    assert float(np.median(list(errs.values()))) < 6e-2 + 2 * float(np.median(list(cond.values())))
