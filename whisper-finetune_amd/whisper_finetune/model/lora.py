@@ -42,8 +42,17 @@ class LoRAParametrization(nn.Module):
         self.register_buffer("lora_dropout_mask", torch.ones(1, fan_in, dtype=self.lora_A.dtype, device=device))
         self.enabled = True
 
+    _pool = None  # LoraMaskPool of the model this adapter belongs to (apply_lora), or None
+
     def draw_mask(self, training: bool) -> Optional[torch.Tensor]:
+        """Dropout(p)(ones[1, in]): a fresh mask per forward of the Linear.  Adapters attached by
+        apply_lora take their mask from the model's pool — ONE Bernoulli launch per model forward for all (512) adapters
+        instead of one per Linear — anything else draws its own."""
         if self.lora_dropout_p > 0.0 and training:
+            if self._pool is not None:
+                m = self._pool.mask_of(self)
+                if m is not None:
+                    return m
             return torch.nn.functional.dropout(self.lora_dropout_mask, self.lora_dropout_p, True)
         return None
 
@@ -65,6 +74,44 @@ class LoRAParametrization(nn.Module):
             return out
         A = self.lora_A if m is None else self.lora_A * m
         return W + (self.lora_B @ A).view(W.shape) * self.scaling
+
+
+class LoraMaskPool:
+    """All dropout masks of a model's adapters as slices of one buffer, redrawn once per forward of the root module (a
+    forward pre-hook): `bernoulli_(1 - p) / (1 - p)` over the concatenated input widths — the distribution of minLoRA's
+    per-adapter `Dropout(p)(ones[1, in])`, 2 launches instead of 512.  A checkpoint recompute inside the same forward sees the
+    same masks (they change only when the root forward starts)."""
+
+    def __init__(self, root: nn.Module):
+        self.adapters = []
+        self.offsets = {}
+        self.buf = None
+        self.total = 0
+        self.handle = root.register_forward_pre_hook(self._on_forward)
+        self.root = root
+
+    def add(self, adapter: "LoRAParametrization") -> None:
+        self.offsets[id(adapter)] = (self.total, adapter.lora_A.shape[1])
+        self.total += adapter.lora_A.shape[1]
+        self.adapters.append(adapter)
+        adapter.__dict__["_pool"] = self
+
+    def _on_forward(self, module, inputs):
+        if not module.training or not self.adapters:
+            self.buf = None
+            return
+        p = self.adapters[0].lora_dropout_p
+        if p <= 0.0 or any(a.lora_dropout_p != p for a in self.adapters):
+            self.buf = None  # mixed rates: every adapter draws its own
+            return
+        dev = self.adapters[0].lora_A.device
+        self.buf = torch.empty(self.total, device=dev, dtype=self.adapters[0].lora_A.dtype).bernoulli_(1.0 - p).mul_(1.0 / (1.0 - p))
+
+    def mask_of(self, adapter) -> Optional[torch.Tensor]:
+        if self.buf is None:
+            return None
+        off, n = self.offsets[id(adapter)]
+        return self.buf[off:off + n].view(1, n)
 
 
 class ParametrizationList(nn.ModuleList):
@@ -108,9 +155,13 @@ def apply_lora(model: nn.Module, lora_config: dict, train_only_decoder: bool = F
     rank = int(cfg.pop("rank", 4))
     alpha = cfg.pop("lora_alpha", 1)
     root = model.decoder if train_only_decoder else model.encoder if train_only_encoder else model
+    pool = model.__dict__.get("_wft_lora_pool")
+    if pool is None:
+        pool = model.__dict__["_wft_lora_pool"] = LoraMaskPool(model)
     for m in root.modules():
-        if isinstance(m, WLinear):
+        if isinstance(m, WLinear) and "parametrizations" not in m._modules:
             add_lora_to_linear(m, rank, alpha, p_drop)
+            pool.add(m.parametrizations.weight[0])
     disable_all_but_parametrized_grads(model)
 
 
@@ -134,14 +185,22 @@ def _strip(layer: nn.Module, merge: bool) -> None:
     layer.__dict__.pop("_wft_group", None)
 
 
+def _drop_pool(model: nn.Module) -> None:
+    pool = model.__dict__.pop("_wft_lora_pool", None)
+    if pool is not None:
+        pool.handle.remove()
+
+
 def remove_lora(model: nn.Module) -> None:
     """Drop the adapters and restore the original base weights (model/lora.py:74-80)."""
     model.apply(lambda m: _strip(m, merge=False))
+    _drop_pool(model)
 
 
 def merge_lora(model: nn.Module) -> None:
     """Fold W + s*B@A into the base weights (model/lora.py:83-89)."""
     model.apply(lambda m: _strip(m, merge=True))
+    _drop_pool(model)
 
 
 def print_lora_info(model: nn.Module) -> None:
