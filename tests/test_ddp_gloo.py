@@ -1,6 +1,8 @@
 """The N>1 path on CPU: two processes, gloo backend, 127.0.0.1 rendezvous.  Covers what the reference
 does around the hot path: runtime.setup_distributed from torchrun-style env,
-DistributedSampler sharding (finetune.py:620-627), DDP + train_step with no_sync() accumulation,
+DistributedSampler sharding (finetune.py:620-627), DDP(find_unused_parameters=True) + train_step with no_sync()
+accumulation over a model whose layers are single autograd nodes returning several gradients at once (the shape of
+engine/ops.LinearFn) and whose middle block is skipped in different micro-batches on different ranks (stochastic depth),
 rank-local loss, identical parameters on every rank after the step, barrier and cleanup."""
 import os
 import socket
@@ -17,14 +19,38 @@ def _free_port():
         return s.getsockname()[1]
 
 
+class _FusedLinearFn(torch.autograd.Function):
+    """CPU stand-in for engine/ops.LinearFn: ONE autograd node that returns the input gradient and BOTH parameter gradients
+    at once (the DDP reducer then sees several gradient-ready hooks fire from a single node, in this order)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return x @ w.t() + b
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        return dy @ w, dy.t() @ x, dy.sum(0)
+
+
 class _Toy(torch.nn.Module):
+    """a -> [c: a residual block that stochastic depth may skip] -> b, every layer through _FusedLinearFn.  `skip_c` is
+    set per micro-batch by the test (different ranks skip in different micro-batches: the per-rank unused-parameter case of
+    the reference's DDP(find_unused_parameters=True), scripts/finetune.py:694-705)."""
+
     def __init__(self):
         super().__init__()
         self.a = torch.nn.Linear(5, 8)
+        self.c = torch.nn.Linear(8, 8)
         self.b = torch.nn.Linear(8, 7)
+        self.skip_c = False
 
     def forward(self, x, y_in):
-        h = self.b(torch.tanh(self.a(x)))  # [B, 7]
+        h = torch.tanh(_FusedLinearFn.apply(x, self.a.weight, self.a.bias))
+        if not self.skip_c:
+            h = h + torch.tanh(_FusedLinearFn.apply(h, self.c.weight, self.c.bias))
+        h = _FusedLinearFn.apply(h, self.b.weight, self.b.bias)  # [B, 7]
         return h.unsqueeze(1).expand(-1, y_in.shape[1], -1)
 
 
@@ -68,7 +94,7 @@ def _worker(rank, world, port, out):
     torch.manual_seed(0)
     model = _Toy()
     ref = _Toy(); ref.load_state_dict(model.state_dict())
-    ddp = DDP(model, broadcast_buffers=False, gradient_as_bucket_view=True)
+    ddp = DDP(model, broadcast_buffers=False, gradient_as_bucket_view=True, find_unused_parameters=True)
     assert rt.unwrap_model(ddp) is model
 
     ds = _DS(16)
@@ -91,7 +117,16 @@ def _worker(rank, world, port, out):
         return orig()
 
     ddp.no_sync = counting
-    loss = model_utils.train_step(ddp, model_utils.infinite_iter(loader), opt, Sch(), t_cfg)
+
+    def skips(r, mb):  # which micro-batches of rank r drop block c (rank 0: the first, rank 1: the second)
+        return (r + mb) % 2 == 0
+
+    def batches():
+        for mb, batch in enumerate(model_utils.infinite_iter(loader)):
+            model.skip_c = skips(rank, mb)
+            yield batch
+
+    loss = model_utils.train_step(ddp, batches(), opt, Sch(), t_cfg)
     assert entries["n"] == local_accum - 1
 
     # expected indices of this rank: r::world of the seeded permutation (epoch 0)
@@ -107,10 +142,12 @@ def _worker(rank, world, port, out):
         for mb in range(local_accum):
             ii = idx[2 * mb: 2 * mb + 2]
             x = ds.x[ii]; y = ds.y[ii]
+            ref.skip_c = skips(r, mb)
             l = torch.nn.functional.cross_entropy(ref(x, y).transpose(1, 2), y, label_smoothing=0.1) / local_accum
-            gs = torch.autograd.grad(l, list(ref.parameters()))
+            gs = torch.autograd.grad(l, list(ref.parameters()), allow_unused=True)
             for g, gi in zip(grads, gs):
-                g += gi / world
+                if gi is not None:
+                    g += gi / world
             if r == rank:
                 losses.append(l.item())
     with torch.no_grad():
