@@ -164,6 +164,8 @@ class _LinearCfg:
         self.gelu_out, self.gelu_in, self.out_features = gelu_out, gelu_in, out_features
 
 
+# WFT_LORA_SKINNY=0: rank-r LoRA products through the 128-wide tile kernel instead of wft_gemm_nt_skinny_bf16 (A/B runs)
+_LORA_SKINNY = os.environ.get("WFT_LORA_SKINNY", "1") != "0"
 # WFT_GELU_PAIR=0: keep the pre-activation and evaluate gelu' in the backward-data GEMM's epilogue (A/B runs)
 _GELU_PAIR = os.environ.get("WFT_GELU_PAIR", "1") != "0"
 
@@ -275,11 +277,15 @@ class LinearFn(torch.autograd.Function):
             b2_need = [ctx.needs_input_grad[base + n_l + i] for i in range(n_l)]
             Am, AmT, Bb, BbT = cfg.group.lora_shadows(weights, cfg.loras)
             dA_full = dB_full = None
+            rtot = sum(s.A.shape[0] for s in cfg.loras if s is not None)
+            rc = K.round_up(rtot, 16)
+            skinny = _LORA_SKINNY and rc <= 64  # rank-r products stream their activation operand once, no LDS staging
             if any(a_need):
-                du = K.gemm_nt(dy, BbT)        # [M, Rpad] = dy @ (s*B)
+                du = K.gemm_nt_skinny(dy, BbT, rc) if skinny else K.gemm_nt(dy, BbT)  # [M, Rpad] = dy @ (s*B)
                 dA_full = K.gemm_tn(du, x)     # [Rpad, Kpad]
             if any(b2_need):
-                u = K.gemm_nt(x, Am)           # [M, Rpad] = x @ (A*mask)^T, recomputed here instead of saved by the forward
+                # [M, Rpad] = x @ (A*mask)^T, recomputed here instead of saved by the forward
+                u = K.gemm_nt_skinny(x, Am, rc) if skinny else K.gemm_nt(x, Am)
                 dB_full = K.gemm_tn(dy, u)     # [Npad, Rpad]
             dAs, dBs = [], []
             ro = no = li = 0
