@@ -350,7 +350,8 @@ def main():
     L.load()
     B, S = args.batch, args.seq
     headline_default = args.model == "large-v3" and not (args.lora or args.muon or args.stochastic_depth > 0 or args.deep_spec_augment)
-    extras = headline_default and not args.no_extras
+    # the extra lines are single-GPU measurements (the driver's N > 1 runs time the headline only: weak scaling of ONE workload)
+    extras = headline_default and not args.no_extras and world == 1
     case = Case(args, device, rank, local_rank, world, ddp, lora=args.lora, muon=args.muon, sd=args.stochastic_depth,
                 dsa=args.deep_spec_augment)
     head = case.measure(B, S, args.steps, args.warmup, roofline=not args.no_roofline, hand_rolled_steps=3 if extras else 0)

@@ -485,3 +485,40 @@ def test_per_clip_mel_path_equals_the_batched_front_end():
         mel = ds._calculate_mel(audio, seg, True)
         assert mel.shape == (80, 3000)
         assert torch.equal(mel, batched[i]), i
+
+
+def test_two_engine_models_interleaved():
+    """A student / teacher (or EMA) setup: two engine models and two optimizers in one process, forwards interleaved.  The
+    bf16 weight shadows are per module, the shadow epoch is bumped by ANY optimizer step (conservative: at worst a rebuild),
+    and the fused bias-gradient column sums are keyed by tensors that stay alive until consumed: the student's step must equal
+    the same step run alone, bit for bit."""
+    dims, params, audio, y_in, y_out = _tiny_case(B=2, S=12)
+    mel = O.log_mel_spectrogram(audio, dims.n_mels).to(DEV)
+    yi, yo = y_in.to(DEV), y_out.to(DEV)
+
+    def run(with_teacher):
+        student = _engine(dims, params).train()
+        opt = torch.optim.AdamW(student.parameters(), lr=1e-3, fused=True)
+        teacher = t_opt = None
+        if with_teacher:
+            teacher = _engine(dims, {k: v * 1.01 for k, v in params.items()}).train()
+            t_opt = torch.optim.SGD(teacher.parameters(), lr=1e-3)
+        out = []
+        for _ in range(2):
+            if with_teacher:
+                with torch.no_grad():
+                    teacher(mel, yi)  # a forward of the other model before the student's
+            loss = student(mel, yi, targets=yo, label_smoothing=0.1)
+            if with_teacher:
+                t_loss = teacher(mel, yi, targets=yo, label_smoothing=0.0)  # ... and one between its forward and backward
+                t_loss.backward()
+                t_opt.step(); t_opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step(); opt.zero_grad(set_to_none=True)
+            out.append(loss.item())
+        return out, {n: p.detach().clone() for n, p in student.named_parameters()}
+
+    l0, p0 = run(False)
+    l1, p1 = run(True)
+    assert l0 == l1
+    assert all(torch.equal(p0[n], p1[n]) for n in p0)
