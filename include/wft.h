@@ -66,6 +66,13 @@ int wft_cast_pad_transpose_f32_bf16(const float* src, int64_t rows, int64_t cols
 int wft_lora_merge(const float* W, int64_t rows, int64_t cols, const float* B, const float* A, const float* mask,
                    int rank, float scaling, wft_bf16* dst, wft_bf16* dst_t, int64_t rows_pad, int64_t cols_pad,
                    int64_t ld_dst, int64_t ld_dst_t, float* dst_f32, void* stream);
+/* Operands of the rank-r adapter-gradient GEMMs (du = dy (sB), u = x (s A*mask)^T; minLoRA parametrization, model/lora.py:30-71)
+ * of ONE adapter, written into its Linear group's zero-initialised padded bf16 buffers: Am [rpad, K] rows ro..ro+rank (and
+ * AmT [K, rpad]) = scaling * A * mask; Bb [npad, rpad] block (no..no+n, ro..ro+rank) (and BbT [rpad, npad]) = scaling * B.
+ * A f32 [rank, K], B f32 [n, rank], mask f32 [K] or NULL.                                                                */
+int wft_lora_pack(const float* A, const float* mask, const float* B, int rank, int64_t K, int64_t n, float scaling,
+                  wft_bf16* Am, wft_bf16* AmT, wft_bf16* Bb, wft_bf16* BbT, int64_t rpad, int64_t npad, int64_t ro,
+                  int64_t no, void* stream);
 /* y[i] = a[i] + b[i] (bf16) — gradient accumulation on the residual stream. */
 int wft_add_bf16(const wft_bf16* a, const wft_bf16* b, wft_bf16* y, int64_t n, void* stream);
 /* out = a*x + b*y over n bf16 elements (y may be NULL).  StochasticDepthMixin's train-time rescale
@@ -149,7 +156,10 @@ typedef struct {
   /* wft_gemm_nt_bf16 only: scale of the residual term, C = alpha*acc (+bias)(epilogue) + beta*residual.
    * 0 is read as 1 so that zero-initialised structs keep the plain residual add.  (Newton-Schulz steps of the
    * Muon optimizer: B = b*A + c*A@A, X' = a*X + B@X — muon.py zeropower_via_newtonschulz5.)            */
-  float beta; int reserved0;
+  float beta;
+  /* wft_gemm_tn_bf16 only (P = 128, f32 C): if 0 < p_valid <= 64, columns >= p_valid of A are known to be zero (a rank-r LoRA
+   * operand in its 128-wide padded buffer): the kernel skips the MFMA work on them; rows >= p_valid of C are written as zero. */
+  int p_valid;
   /* wft_gemm_nt_bf16 only: if != NULL (bf16 C, batch == 1), colsum[n] = sum over rows of the C just written — the bias
    * gradient of the Linear that consumes C as its dy (C = d(pre-activation) from the DGELU epilogue).  With `workspace`
    * of wft_gemm_nt_colsum_workspace_bytes(args) bytes the sums are formed in the epilogue of the 256x256 kernel (no

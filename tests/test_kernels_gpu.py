@@ -462,3 +462,19 @@ def test_gemm_nt_skinny_matches_the_tile_kernel(M, Kd, rc):
     if M >= 128:
         close(got, K.gemm_nt(a, b), 4e-3)
     assert torch.equal(got, K.gemm_nt_skinny(a, b, rc))
+
+
+@pytest.mark.parametrize("R,Q,rc", [(48000, 1280, 16), (5000, 5120, 48), (3001, 384, 64)])
+def test_gemm_tn_p_valid_skips_only_zero_columns(R, Q, rc):
+    """Weight-gradient GEMM with a rank-r operand in its 128-wide zero-padded buffer (dA = du^T x, dB^T = u^T dy): p_valid skips
+    the MFMA work on the zero columns and gives exactly the result of the full kernel (same products, same order)."""
+    g = torch.Generator().manual_seed(R + rc)
+    a = torch.zeros(R, 128)
+    a[:, :rc - 5] = torch.randn(R, rc - 5, generator=g)
+    a = bf(a).to(DEV)
+    b = bf(torch.randn(R, Q, generator=g)).to(DEV)
+    full = K.gemm_tn(a, b)
+    fast = K.gemm_tn(a, b, p_valid=rc)
+    assert torch.equal(full, fast)
+    assert torch.count_nonzero(fast[rc:]) == 0
+    close(fast, a.float().t() @ b.float(), 2e-5)

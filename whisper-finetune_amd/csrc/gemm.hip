@@ -619,7 +619,9 @@ __device__ __forceinline__ s16x4 tn_tr_asm(unsigned lds_byte_addr) {
 // MFMA operands are column reads of those tiles -> ds_read_b64_tr_b16.
 __device__ __forceinline__ int tn_f(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
 
-template <bool C_F32>
+// PB > 0: only the first 16*PB (<= 64) columns of A are non-zero (a rank-r LoRA operand in its 128-wide padded buffer): the
+// wave column wp = 1 and the p-blocks >= PB of wp = 0 skip their fragment reads and MFMAs (their part of C is written as zero).
+template <bool C_F32, int PB = 0>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmP p) {
   __shared__ __attribute__((aligned(16))) char smem[65536];  // [buf 2][A 16K | B 16K]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -691,14 +693,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmP p) {
   const int fsw = (r_in | ((g & 1) << 2)) << 1;  // tn_f(r) << 1 for r = 32s + 8g + 4t + r_in
   const int colq = wq * 64 + 4 * (li & 3);  // + iq*16
   const int colp = wp * 64 + 4 * (li & 3);  // + jp*16
+  constexpr int NPB = PB > 0 ? PB : 4;      // p-blocks this wave multiplies
+  const bool idle = PB > 0 && wp == 1;      // wave-uniform
   for (int step = 0; step < nsteps; ++step) {
     const int cur = step & 1;
     if (step + 1 < nsteps) stage(cur ^ 1, s_begin + step + 1);
     const char* sa = smem + cur * 32768;
     const char* sb = sa + 16384;
+    if (!idle) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      s16x8 qf[4], pf[4];
+      s16x8 qf[4], pf[NPB];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int r = 32 * s + 8 * g + 4 * t + r_in;
@@ -707,22 +712,24 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmP p) {
           const int cq = colq + i * 16;
           const int aq = r * 256 + (((cq >> 3) ^ fsw) << 4) + ((cq & 7) << 1);
           const s16x4 x = lds_read_tr16(sb + aq);
-          const int cpp = colp + i * 16;
-          const int ap = r * 256 + (((cpp >> 3) ^ fsw) << 4) + ((cpp & 7) << 1);
-          const s16x4 y = lds_read_tr16(sa + ap);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            qf[i][4 * t + e] = x[e];
-            pf[i][4 * t + e] = y[e];
+          for (int e = 0; e < 4; ++e) qf[i][4 * t + e] = x[e];
+          if (i < NPB) {
+            const int cpp = colp + i * 16;
+            const int ap = r * 256 + (((cpp >> 3) ^ fsw) << 4) + ((cpp & 7) << 1);
+            const s16x4 y = lds_read_tr16(sa + ap);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pf[i][4 * t + e] = y[e];
           }
         }
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NPB; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
               __builtin_bit_cast(bf16x8, qf[i]), __builtin_bit_cast(bf16x8, pf[j]), acc[i][j], 0, 0, 0);
+    }
     }
     __syncthreads();
     if (step + 1 < nsteps) {
@@ -1357,8 +1364,14 @@ extern "C" int wft_gemm_tn_bf16(const wft_gemm_args* a, void* stream) {
   if (nsplit > 1 && !use_ws && !a->accumulate)
     (void)hipMemset2DAsync(a->C, (size_t)a->ldc * 4, 0, (size_t)a->N * 4, (size_t)a->M, s);
   dim3 grid((unsigned)tiles, (unsigned)nsplit), block(256);
-  if (a->c_is_f32) hipLaunchKernelGGL((gemm_tn_kernel<true>), grid, block, 0, s, p);
-  else hipLaunchKernelGGL((gemm_tn_kernel<false>), grid, block, 0, s, p);
+  // p_valid: A is a rank-r operand in a 128-wide zero-padded buffer — skip the MFMA work on its zero columns
+  const int pb = (a->c_is_f32 && a->M == 128 && a->p_valid > 0 && a->p_valid <= 64) ? (a->p_valid + 15) / 16 : 0;
+  if (!a->c_is_f32) hipLaunchKernelGGL((gemm_tn_kernel<false>), grid, block, 0, s, p);
+  else if (pb == 1) hipLaunchKernelGGL((gemm_tn_kernel<true, 1>), grid, block, 0, s, p);
+  else if (pb == 2) hipLaunchKernelGGL((gemm_tn_kernel<true, 2>), grid, block, 0, s, p);
+  else if (pb == 3) hipLaunchKernelGGL((gemm_tn_kernel<true, 3>), grid, block, 0, s, p);
+  else if (pb == 4) hipLaunchKernelGGL((gemm_tn_kernel<true, 4>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((gemm_tn_kernel<true>), grid, block, 0, s, p);
   if (use_ws) {
     const long total = a->M * (a->N / 4);
     long g = (total + 255) / 256;

@@ -229,6 +229,42 @@ extern "C" int wft_lora_merge(const float* W, int64_t rows, int64_t cols, const 
   return WFT_OK;
 }
 
+// Operands of the rank-r adapter-gradient GEMMs of ONE adapter inside its Linear group's padded buffers (zero-initialised by
+// the caller once; only this adapter's blocks are written):
+//   Am [Rpad, K]  rows ro..ro+r  = bf16(scaling * A * mask)      AmT [K, Rpad] its transpose        (u = x Am^T carries s)
+//   Bb [Npad, Rpad] block (no..no+n, ro..ro+r) = bf16(scaling * B)   BbT [Rpad, Npad] its transpose (du = dy Bb carries s)
+// so dA = (du^T x) * mask and dB = dy^T u need no further scaling.  One launch instead of two element-wise multiplies and two
+// cast/transposes per group; the data is a few tens of KB.
+__global__ __launch_bounds__(256) void lora_pack_kernel(const float* A, const float* mask, const float* B, int r, long K, long n,
+                                                         float scaling, unsigned short* Am, unsigned short* AmT, unsigned short* Bb,
+                                                         unsigned short* BbT, long rpad, long npad, long ro, long no) {
+  const long na = (long)r * K, nb = n * r;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < na + nb; i += (long)gridDim.x * 256) {
+    if (i < na) {
+      const long q = i / K, c = i - q * K;
+      const unsigned short v = f2bf(scaling * A[i] * (mask ? mask[c] : 1.f));
+      Am[(ro + q) * K + c] = v;
+      AmT[c * rpad + ro + q] = v;
+    } else {
+      const long j = i - na, row = j / r, q = j - row * r;
+      const unsigned short v = f2bf(scaling * B[j]);
+      Bb[(no + row) * rpad + ro + q] = v;
+      BbT[(ro + q) * npad + no + row] = v;
+    }
+  }
+}
+extern "C" int wft_lora_pack(const float* A, const float* mask, const float* B, int rank, int64_t K, int64_t n, float scaling,
+                             wft_bf16* Am, wft_bf16* AmT, wft_bf16* Bb, wft_bf16* BbT, int64_t rpad, int64_t npad, int64_t ro,
+                             int64_t no, void* stream) {
+  WFT_CHECK_ARG(A && B && Am && AmT && Bb && BbT, "null pointer");
+  WFT_CHECK_ARG(rank >= 1 && K >= 1 && n >= 1 && ro >= 0 && no >= 0 && ro + rank <= rpad && no + n <= npad, "bad shape");
+  const int64_t total = (int64_t)rank * K + n * rank;
+  hipLaunchKernelGGL(lora_pack_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, A, mask, B, rank, (long)K, (long)n,
+                     scaling, Am, AmT, Bb, BbT, (long)rpad, (long)npad, (long)ro, (long)no);
+  WFT_CHECK_LAUNCH();
+  return WFT_OK;
+}
+
 __global__ __launch_bounds__(256) void add_bf16_kernel(const unsigned short* a, const unsigned short* b,
                                                         unsigned short* y, long n) {
   const long nv = n >> 3;

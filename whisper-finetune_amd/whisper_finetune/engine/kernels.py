@@ -96,6 +96,21 @@ def lora_merge(w, B, A, mask, scaling: float, rows_pad=None, cols_pad=None, out=
     return out, out_t, out_f32
 
 
+def lora_pack(A, mask, B, scaling: float, Am, AmT, Bb, BbT, ro: int, no: int) -> None:
+    """One adapter's blocks of the rank-r gradient-GEMM operands (see wft_lora_pack): A f32 [r, K], mask f32 [1, K] or None,
+    B f32 [n, r] -> Am [Rpad, K] / AmT, Bb [Npad, Rpad] / BbT (bf16, zero-initialised by the caller)."""
+    _chk(A, F32, "A"); _chk(B, F32, "B")
+    for t, nme in ((Am, "Am"), (AmT, "AmT"), (Bb, "Bb"), (BbT, "BbT")):
+        _chk(t, BF16, nme)
+    r, Kd = A.shape
+    n = B.shape[0]
+    assert A.is_contiguous() and B.is_contiguous() and B.shape[1] == r and Am.shape[1] == Kd
+    rpad, npad = Am.shape[0], Bb.shape[0]
+    m = None if mask is None else mask.contiguous()
+    L.check(L.load().wft_lora_pack(_p(A), _p(m), _p(B), r, Kd, n, float(scaling), _p(Am), _p(AmT), _p(Bb), _p(BbT), rpad, npad, ro, no,
+                                   L.stream_ptr()), "wft_lora_pack")
+
+
 def add_bf16(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     _chk(a, BF16, "a"); _chk(b, BF16, "b")
     a = a.contiguous(); b = b.contiguous()
@@ -259,8 +274,9 @@ def gemm_nt_skinny(a: torch.Tensor, b: torch.Tensor, n_valid: int) -> torch.Tens
 
 
 def gemm_tn(a, b, *, P=None, Q=None, R=None, lda=None, ldb=None, out=None, out_f32=True, accumulate=False,
-            alpha=1.0, batch=1, strideA=0, strideB=0):
-    """C[P,Q] (+)= alpha * A[R,P]^T @ B[R,Q]  (weight gradients)."""
+            alpha=1.0, batch=1, strideA=0, strideB=0, p_valid=0):
+    """C[P,Q] (+)= alpha * A[R,P]^T @ B[R,Q]  (weight gradients).  p_valid (P = 128 only): columns >= p_valid of A are zero
+    padding (a rank-r LoRA operand): their MFMA work is skipped."""
     _chk(a, BF16, "A"); _chk(b, BF16, "B")
     if R is None:
         R = a.shape[0]
@@ -282,6 +298,7 @@ def gemm_tn(a, b, *, P=None, Q=None, R=None, lda=None, ldb=None, out=None, out_f
     args.c_is_f32, args.accumulate = int(out.dtype == F32), int(accumulate)
     args.epilogue, args.alpha = L.EPI_NONE, alpha
     args.M, args.N, args.K, args.batch = P, Q, R, batch
+    args.p_valid = int(p_valid)
     lib = L.load()
     need = lib.wft_gemm_tn_workspace_bytes(C.byref(args))
     if need > 0:

@@ -33,7 +33,7 @@ class GemmArgs(C.Structure):
         ("valid_rows_period", C.c_int), ("valid_rows", C.c_int),
         ("residual_first", C.c_int),
         ("workspace", c_vp), ("workspace_bytes", c_i64),
-        ("beta", C.c_float), ("reserved0", C.c_int),
+        ("beta", C.c_float), ("p_valid", C.c_int),
         ("colsum", c_vp),
     ]
 
@@ -79,6 +79,7 @@ SIGNATURES = {
     "wft_cast_bf16_f32": [c_vp, c_vp, c_i64, c_vp],
     "wft_cast_pad_transpose_f32_bf16": [c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp],
     "wft_lora_merge": [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, C.c_int, C.c_float, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp],
+    "wft_lora_pack": [c_vp, c_vp, c_vp, C.c_int, c_i64, c_i64, C.c_float, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp],
     "wft_add_bf16": [c_vp, c_vp, c_vp, c_i64, c_vp],
     "wft_axpby_bf16": [C.c_float, c_vp, C.c_float, c_vp, c_vp, c_i64, c_vp],
     "wft_dgelu_mul_bf16": [c_vp, c_vp, c_vp, c_i64, c_vp],

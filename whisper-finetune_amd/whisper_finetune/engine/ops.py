@@ -71,7 +71,6 @@ class LinearGroup:
         self.W = self.WT = self.bias = None
         self.lkey = None
         self.Am = self.AmT = self.Bb = self.BbT = None
-        self._Am32 = self._Bb32 = None
 
     @staticmethod
     def dims(weights: Sequence[torch.Tensor]):
@@ -128,30 +127,27 @@ class LinearGroup:
         return self.W, self.WT, self.bias
 
     def lora_shadows(self, weights, loras: Sequence[Optional[LoraSpec]]):
-        """(A*mask) stacked [Rpad, K] and block-diagonal scaling*B [Npad, Rpad], both (+T) in bf16: the operands of the
-        rank-r gradient GEMMs (backward only)."""
+        """scaling*(A*mask) stacked [Rpad, K] and block-diagonal scaling*B [Npad, Rpad], both (+T) in bf16: the operands of the
+        rank-r gradient GEMMs (backward only); one wft_lora_pack launch per adapter."""
         key = tuple(None if s is None else s.key() for s in loras) + (_SHADOW_EPOCH[0],)
         if key != self.lkey:
             n, k, npad = self.dims(weights)
             dev = weights[0].device
             rtot = sum(s.A.shape[0] for s in loras if s is not None)
             rpad = K.round_up(rtot, 128)
-            if self._Am32 is None or self._Am32.shape != (rpad, k):
-                self._Am32 = torch.zeros((rpad, k), dtype=F32, device=dev)   # rows >= rtot and the off-diagonal of Bb stay zero
-                self._Bb32 = torch.zeros((n, rpad), dtype=F32, device=dev)
+            if self.Am is None or self.Am.shape != (rpad, k) or self.Bb.shape != (npad, rpad):
+                # rows >= rtot of Am and the off-diagonal blocks of Bb stay zero
+                self.Am = torch.zeros((rpad, k), dtype=BF16, device=dev)
+                self.AmT = torch.zeros((k, rpad), dtype=BF16, device=dev)
+                self.Bb = torch.zeros((npad, rpad), dtype=BF16, device=dev)
+                self.BbT = torch.zeros((rpad, npad), dtype=BF16, device=dev)
             ro = no = 0
             for w, s in zip(weights, loras):
                 if s is not None:
-                    r = s.A.shape[0]
-                    if s.mask is None:
-                        self._Am32[ro:ro + r].copy_(s.A.detach())
-                    else:
-                        torch.mul(s.A.detach(), s.mask, out=self._Am32[ro:ro + r])
-                    torch.mul(s.B.detach(), s.scaling, out=self._Bb32[no:no + w.shape[0], ro:ro + r])
-                    ro += r
+                    K.lora_pack(s.A.detach(), None if s.mask is None else s.mask.detach(), s.B.detach(), s.scaling,
+                                self.Am, self.AmT, self.Bb, self.BbT, ro, no)
+                    ro += s.A.shape[0]
                 no += w.shape[0]
-            self.Am, self.AmT = K.weight_shadow(self._Am32, rpad, k, True, out=self.Am, out_t=self.AmT)
-            self.Bb, self.BbT = K.weight_shadow(self._Bb32, npad, rpad, True, out=self.Bb, out_t=self.BbT)
             self.lkey = key
         return self.Am, self.AmT, self.Bb, self.BbT
 
@@ -282,11 +278,12 @@ class LinearFn(torch.autograd.Function):
             skinny = _LORA_SKINNY and rc <= 64  # rank-r products stream their activation operand once, no LDS staging
             if any(a_need):
                 du = K.gemm_nt_skinny(dy, BbT, rc) if skinny else K.gemm_nt(dy, BbT)  # [M, Rpad] = dy @ (s*B)
-                dA_full = K.gemm_tn(du, x)     # [Rpad, Kpad]
+                dA_full = K.gemm_tn(du, x, p_valid=rc if skinny else 0)               # [Rpad, Kpad]
             if any(b2_need):
-                # [M, Rpad] = x @ (A*mask)^T, recomputed here instead of saved by the forward
+                # [M, Rpad] = x @ (s*A*mask)^T, recomputed here instead of saved by the forward
                 u = K.gemm_nt_skinny(x, Am, rc) if skinny else K.gemm_nt(x, Am)
-                dB_full = K.gemm_tn(dy, u)     # [Npad, Rpad]
+                # rank-r operand first (its zero-padded columns are skipped): [Rpad, Npad], read through its transpose
+                dB_full = K.gemm_tn(u, dy, p_valid=rc if skinny else 0).t()           # [Npad, Rpad]
             dAs, dBs = [], []
             ro = no = li = 0
             for w, s in zip(weights, cfg.loras):
@@ -297,7 +294,8 @@ class LinearFn(torch.autograd.Function):
                         dAs.append(g * s.mask if s.mask is not None else g)
                     else:
                         dAs.append(None)
-                    dBs.append(dB_full[no:no + w.shape[0], ro:ro + r] * s.scaling if b2_need[li] else None)
+                    # u = x (s A*m)^T already carries the scaling (wft_lora_pack): dB is the slice itself
+                    dBs.append(dB_full[no:no + w.shape[0], ro:ro + r] if b2_need[li] else None)
                     ro += r
                     li += 1
                 no += w.shape[0]
