@@ -33,3 +33,6 @@ json.dump(out, open("$OUT/pmc_summary.json", "w"), indent=1)
 print(json.dumps({k: {kk: round(vv["mean"]) for kk, vv in v.items()} for k, v in out.items() if k != "batch"})[:1500])
 PY
 ls $OUT/stats/*/ | head
+# the raw per-dispatch traces are tens of MiB each: gpurun only copies back 64 MiB, keep the summaries
+find $OUT -name "*kernel_trace.csv" -delete
+find $OUT -name "*counter_collection.csv" -delete

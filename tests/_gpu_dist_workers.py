@@ -139,3 +139,90 @@ def ddp_engine_worker(rank, world, port, out):
     dist.barrier(device_ids=[0])
     dist.destroy_process_group()
     out.put((rank, l_plain, l_ddp, worst, n_nosync))
+
+
+def ddp_engine_two_rank_worker(rank, world, port, out):
+    """TWO processes on one GPU over gloo (RCCL refuses two ranks per device; gloo reduces HIP tensors through the host): the
+    engine under a real 2-rank DDP reducer — per-rank seeds, so stochastic depth drops DIFFERENT blocks on the two ranks
+    (find_unused_parameters=True: the used-parameter bitmap exchange), local accumulation 2 with no_sync()
+    on the first micro-batch, gradient_as_bucket_view.  Checked against a hand-made reduction: every rank replays its own
+    micro-batches on a plain copy of the model, the gradients are averaged with explicit all_reduce calls (a parameter unused
+    on BOTH ranks keeps grad None, as DDP leaves it), and the same optimizer step must give the same parameters."""
+    _setup(rank, world, port, "gloo")
+    os.environ["WFT_NT256_PERSISTENT"] = "0"
+    import torch
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    import whisper_finetune.runtime as rt
+    from oracle import whisper_oracle as O
+    from whisper_finetune.engine.whisper_model import ModelDimensions, Whisper
+    from whisper_finetune.model import model_utils
+    from whisper_finetune.model.model_utils import CheckpointedStochasticAudioEncoder, CheckpointedStochasticTextDecoder
+    from whisper_finetune.model.optimizer import WftAdamW
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    dims = O.DIMS["tiny"]
+    params = O.init_params(dims, seed=2)
+
+    def build():
+        m = Whisper(ModelDimensions(**vars(dims)))
+        m.encoder = CheckpointedStochasticAudioEncoder(dims.n_mels, dims.n_audio_ctx, dims.n_audio_state, dims.n_audio_head,
+                                                       dims.n_audio_layer, 0.4)
+        m.decoder = CheckpointedStochasticTextDecoder(dims.n_vocab, dims.n_text_ctx, dims.n_text_state, dims.n_text_head,
+                                                      dims.n_text_layer, 0.4)
+        m.load_state_dict(params)
+        return m.to(dev).train()
+
+    audio, y_in, y_out = O.synthetic_batch(dims, 2, 16, seed=50 + rank)  # every rank its own shard
+    mel = O.log_mel_spectrogram(audio, dims.n_mels).to(dev)
+    y_in, y_out = y_in.to(dev), y_out.to(dev)
+    kw = dict(lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.1)
+    accum = 2
+    t_cfg = {"mixed_precision_training": True, "accum_grad_steps": accum, "max_grad_norm": 1.0, "mp_dtype": "bf16", "label_smoothing": 0.1}
+
+    # ---- DDP run
+    m = build()
+    ddp = DDP(m, device_ids=[0], output_device=0, find_unused_parameters=True, broadcast_buffers=False, gradient_as_bucket_view=True,
+              bucket_cap_mb=64)
+    opt = WftAdamW(m.parameters(), **kw)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: 1.0)
+    rt.IS_DISTRIBUTED, rt.WORLD_SIZE, rt.RANK = True, world, rank
+
+    def batches():
+        while True:
+            yield mel, y_in, y_out
+
+    torch.manual_seed(100 + rank)  # per-rank host RNG (scripts/finetune.py:325): different blocks dropped per rank
+    loss = model_utils.train_step(ddp, batches(), opt, sched, dict(t_cfg))
+    rt.IS_DISTRIBUTED = False
+
+    # ---- hand-made reduction on a plain copy
+    ref = build()
+    ropt = WftAdamW(ref.parameters(), **kw)
+    torch.manual_seed(100 + rank)
+    rloss = 0.0
+    for _ in range(accum):
+        l = ref(mel, y_in, targets=y_out, label_smoothing=0.1) / accum
+        l.backward()
+        rloss += l.item()
+    n_local_unused = 0
+    for p in ref.parameters():
+        used = torch.tensor([0.0 if p.grad is None else 1.0])
+        n_local_unused += int(p.grad is None)
+        dist.all_reduce(used)
+        g = torch.zeros_like(p) if p.grad is None else p.grad.clone()
+        g_host = g.cpu()
+        dist.all_reduce(g_host)
+        p.grad = (g_host / world).to(dev) if used.item() > 0 else None
+    ropt.fuse_clip_grad_norm(1.0)
+    ropt.step()
+    worst = max((a.detach() - b.detach()).abs().max().item() for a, b in zip(m.parameters(), ref.parameters()))
+    flat = torch.cat([p.detach().flatten() for p in m.parameters()]).cpu()
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    same = all(torch.equal(gathered[0], t) for t in gathered)
+    dist.barrier()
+    dist.destroy_process_group()
+    out.put((rank, loss, rloss, worst, same, n_local_unused))

@@ -51,3 +51,16 @@ def test_sharded_muon_equals_the_single_process_step():
         assert same                               # every rank ends with the same parameters
         assert 0 < n_state < n_muon               # momentum only for the matrices this rank owns
     assert sum(r[2] for r in res) == res[0][3]    # every Muon matrix has exactly one owner
+
+
+@pytest.mark.timeout(600)
+def test_engine_under_a_two_rank_reducer_matches_a_hand_made_all_reduce():
+    from tests._gpu_dist_workers import ddp_engine_two_rank_worker
+
+    res = _spawn(ddp_engine_two_rank_worker, 2)
+    for rank, loss, rloss, worst, same, n_unused in res:
+        assert loss == pytest.approx(rloss, rel=1e-6)   # rank-local loss, not all-reduced
+        assert same                                     # identical parameters on both ranks after the step
+        assert worst <= 1e-6, (rank, worst)             # == explicit average of the two ranks' gradients + the same optimizer step
+    assert res[0][1] != res[1][1]                       # different shards, different dropped blocks
+    assert any(r[5] > 0 for r in res)                   # stochastic depth did leave parameters unused on a rank
