@@ -180,12 +180,6 @@ int64_t wft_gemm_nt_colsum_workspace_bytes(const wft_gemm_args* args);
  *  batch > 1 sums over the batch as extra reduction (conv weight grads).     */
 int wft_gemm_tn_bf16(const wft_gemm_args* args, void* stream);
 int64_t wft_gemm_tn_workspace_bytes(const wft_gemm_args* args);
-/* Skinny-N product of the LoRA adapter gradients (du = dy (sB), u = x (A*mask)^T; minLoRA parametrization, model/lora.py:30-71):
- * C[M, 0:n_valid] = A[M, K] . B[n_valid, K]^T, columns n_valid .. n_pad-1 of C are written as zeros (C keeps the padded
- * layout the weight-gradient GEMM reads).  n_valid in {16, 32, 48, 64}; K % 128 == 0; bf16 in / out, fp32 accumulation.
- * Streams A once at the HBM rate (no LDS staging).                                                                       */
-int wft_gemm_nt_skinny_bf16(const wft_bf16* A, int64_t lda, const wft_bf16* B, int64_t ldb, wft_bf16* C, int64_t ldc,
-                            int64_t M, int n_valid, int n_pad, int64_t K, void* stream);
 
 /* -------------------------------------------------------------- Attention */
 /* whisper.model.MultiHeadAttention.qkv_attention:

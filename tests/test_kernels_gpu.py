@@ -445,25 +445,6 @@ def test_attention_backward_fused_projection_bias_sums(B, H, Tq, Tk, causal):
         assert (got - want).abs().max() < 2e-4 * want.abs().max() + 1e-3
 
 
-@pytest.mark.parametrize("M,Kd,rc", [(48000, 1280, 16), (3001, 5120, 48), (130, 384, 64), (17, 128, 32)])
-def test_gemm_nt_skinny_matches_the_tile_kernel(M, Kd, rc):
-    """wft_gemm_nt_skinny_bf16 (rank-r LoRA products du = dy (sB), u = x (A*mask)^T): same result as the 128-wide tile kernel
-    on the zero-padded operand (both accumulate the same bf16 products in fp32; the k order differs), zero columns beyond
-    n_valid, ragged M."""
-    g = torch.Generator().manual_seed(M + rc)
-    a = bf(torch.randn(M, Kd, generator=g)).to(DEV)
-    b = torch.zeros(128, Kd)
-    b[:rc - 3] = torch.randn(rc - 3, Kd, generator=g)  # a rank that is not a multiple of 16: padded with zero rows
-    b = bf(b).to(DEV)
-    got = K.gemm_nt_skinny(a, b, rc)
-    assert got.shape == (M, 128) and torch.count_nonzero(got[:, rc:]) == 0
-    ref = a.float() @ b.float().t()
-    close(got, ref, 1e-2)
-    if M >= 128:
-        close(got, K.gemm_nt(a, b), 4e-3)
-    assert torch.equal(got, K.gemm_nt_skinny(a, b, rc))
-
-
 @pytest.mark.parametrize("R,Q,rc", [(48000, 1280, 16), (5000, 5120, 48), (3001, 384, 64)])
 def test_gemm_tn_p_valid_skips_only_zero_columns(R, Q, rc):
     """Weight-gradient GEMM with a rank-r operand in its 128-wide zero-padded buffer (dA = du^T x, dB^T = u^T dy): p_valid skips

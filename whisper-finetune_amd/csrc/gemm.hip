@@ -1027,88 +1027,6 @@ __global__ __launch_bounds__(256) void tn_splitk_reduce_kernel(const float* ws, 
   }
 }
 
-// ---------------------------------------------------------------------------------- NT, skinny N (rank-r LoRA products)
-// C[M, 0:16*RB] = A[M, K] . B[16*RB, K]^T, columns 16*RB .. n_pad-1 of C written as zeros.  The adapter gradients need
-// du = dy (sB) and u = x (A*mask)^T with r = 16 (48 for a fused q/k/v group): through the 128-wide tile kernel those run 8x
-// the useful MFMA work at 2.8 TB/s of their activation stream.  Here nothing is staged through LDS: a wave streams 32 rows
-// of A straight into MFMA A-operand registers (16-byte loads, 64 contiguous bytes per row and k-step, the neighbouring k-step
-// completes the 128-byte line out of L1), B (<= 64 x K, L1/L2-resident) likewise; HBM-bound by construction.
-template <int RB>
-__global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(const unsigned short* A, long lda, const unsigned short* B, long ldb,
-                                                             unsigned short* C, long ldc, int M, int K, int n_pad) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int frow = lane & 15, fg = lane >> 4;
-  const int m_base = blockIdx.x * 128 + wave * 32;
-  if (m_base >= M) return;
-  const unsigned short* ap[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    int m = m_base + 16 * i + frow;
-    m = m < M ? m : M - 1;
-    ap[i] = A + (long)m * lda + 8 * fg;
-  }
-  const unsigned short* bp = B + (long)frow * ldb + 8 * fg;
-  f32x4 acc[2][RB];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < RB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < K; k0 += 128) {  // four 32-deep k-steps per trip: all their loads are issued before the first MFMA
-    bf16x8 af[4][2], bfr[4][RB];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) af[kk][i] = *(const bf16x8*)(ap[i] + k0 + 32 * kk);
-#pragma unroll
-      for (int j = 0; j < RB; ++j) bfr[kk][j] = *(const bf16x8*)(bp + (long)(16 * j) * ldb + k0 + 32 * kk);
-    }
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < RB; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
-  }
-  // lane (frow, fg) holds C[m = 16 i + frow][n = 16 j + 4 fg .. + 3]
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = m_base + 16 * i + frow;
-    if (m >= M) continue;
-    unsigned short* crow = C + (long)m * ldc + 4 * fg;
-#pragma unroll
-    for (int j = 0; j < RB; ++j) {
-      u32x2 pk = {pack2bf(acc[i][j][0], acc[i][j][1]), pack2bf(acc[i][j][2], acc[i][j][3])};
-      *(u32x2*)(crow + 16 * j) = pk;
-    }
-#pragma nounroll
-    for (int n = 16 * RB; n < n_pad; n += 16) *(u32x2*)(crow + n) = u32x2{0u, 0u};
-  }
-}
-extern "C" int wft_gemm_nt_skinny_bf16(const wft_bf16* A, int64_t lda, const wft_bf16* B, int64_t ldb, wft_bf16* C, int64_t ldc,
-                                       int64_t M, int n_valid, int n_pad, int64_t K, void* stream) {
-  WFT_CHECK_ARG(A && B && C, "null pointer");
-  WFT_CHECK_ARG(M >= 1 && K >= 128 && K % 128 == 0, "K must be a multiple of 128");
-  WFT_CHECK_ARG(n_valid >= 16 && n_valid <= 64 && n_valid % 16 == 0 && n_pad >= n_valid && n_pad % 16 == 0 && ldc >= n_pad,
-                "n_valid must be 16, 32, 48 or 64 and n_pad a multiple of 16 >= n_valid");
-  WFT_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "ld alignment");
-  WFT_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && ((uintptr_t)C & 7) == 0, "base pointer alignment");
-  WFT_CHECK_ARG(M < (1ll << 31) && K < (1ll << 31), "dims exceed int32");
-  dim3 grid((unsigned)((M + 127) / 128)), block(256);
-  hipStream_t s = (hipStream_t)stream;
-#define LAUNCH_SK(RB) hipLaunchKernelGGL((gemm_nt_skinny_kernel<RB>), grid, block, 0, s, (const unsigned short*)A, (long)lda, \
-                                         (const unsigned short*)B, (long)ldb, (unsigned short*)C, (long)ldc, (int)M, (int)K, n_pad)
-  switch (n_valid / 16) {
-    case 1: LAUNCH_SK(1); break;
-    case 2: LAUNCH_SK(2); break;
-    case 3: LAUNCH_SK(3); break;
-    default: LAUNCH_SK(4); break;
-  }
-#undef LAUNCH_SK
-  WFT_CHECK_LAUNCH();
-  return WFT_OK;
-}
-
 // ---------------------------------------------------------------------------------- host
 static int g_diag = 0;
 // dispatch thresholds, measured at M = R = 4096 and 8704 (decoder-sized problems; tests/dev_small_gemm.py): the 256x256 kernels win once

@@ -260,19 +260,6 @@ def gemm_nt(a, b, *, M=None, N=None, K=None, lda=None, ldb=None, out=None, out_f
     return out
 
 
-def gemm_nt_skinny(a: torch.Tensor, b: torch.Tensor, n_valid: int) -> torch.Tensor:
-    """a bf16 [M, K] @ b[:n_valid] bf16 [n_pad, K]^T -> bf16 [M, n_pad] with columns >= n_valid zero (rows >= n_valid of b are
-    zero padding: the rank-r LoRA operands).  n_valid in {16, 32, 48, 64}."""
-    _chk(a, BF16, "A"); _chk(b, BF16, "B")
-    assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1 and a.shape[1] == b.shape[1]
-    M, Kd = a.shape
-    n_pad = b.shape[0]
-    out = torch.empty((M, n_pad), dtype=BF16, device=a.device)
-    L.check(L.load().wft_gemm_nt_skinny_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), n_pad, M, n_valid, n_pad, Kd,
-                                             L.stream_ptr()), "wft_gemm_nt_skinny_bf16")
-    return out
-
-
 def gemm_tn(a, b, *, P=None, Q=None, R=None, lda=None, ldb=None, out=None, out_f32=True, accumulate=False,
             alpha=1.0, batch=1, strideA=0, strideB=0, p_valid=0):
     """C[P,Q] (+)= alpha * A[R,P]^T @ B[R,Q]  (weight gradients).  p_valid (P = 128 only): columns >= p_valid of A are zero

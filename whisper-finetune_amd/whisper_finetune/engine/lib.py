@@ -94,7 +94,6 @@ SIGNATURES = {
     "wft_gemm_nt_colsum_workspace_bytes": [C.POINTER(GemmArgs)],
     "wft_gemm_tn_bf16": [C.POINTER(GemmArgs), c_vp],
     "wft_gemm_tn_workspace_bytes": [C.POINTER(GemmArgs)],
-    "wft_gemm_nt_skinny_bf16": [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, C.c_int, C.c_int, c_i64, c_vp],
     "wft_attn_fwd_bf16": [C.POINTER(AttnArgs), c_vp],
     "wft_attn_bwd_bf16": [C.POINTER(AttnArgs), c_vp],
     "wft_attn_bwd_colsum_workspace_bytes": [C.POINTER(AttnArgs)],

@@ -160,8 +160,8 @@ class _LinearCfg:
         self.gelu_out, self.gelu_in, self.out_features = gelu_out, gelu_in, out_features
 
 
-# WFT_LORA_SKINNY=0: rank-r LoRA products through the 128-wide tile kernel instead of wft_gemm_nt_skinny_bf16 (A/B runs)
-_LORA_SKINNY = os.environ.get("WFT_LORA_SKINNY", "1") != "0"
+# WFT_LORA_PVALID=0: rank-r weight-gradient GEMMs without the p_valid shortcut (A/B runs)
+_LORA_PVALID = os.environ.get("WFT_LORA_PVALID", "1") != "0"
 # WFT_GELU_PAIR=0: keep the pre-activation and evaluate gelu' in the backward-data GEMM's epilogue (A/B runs)
 _GELU_PAIR = os.environ.get("WFT_GELU_PAIR", "1") != "0"
 
@@ -274,16 +274,17 @@ class LinearFn(torch.autograd.Function):
             Am, AmT, Bb, BbT = cfg.group.lora_shadows(weights, cfg.loras)
             dA_full = dB_full = None
             rtot = sum(s.A.shape[0] for s in cfg.loras if s is not None)
-            rc = K.round_up(rtot, 16)
-            skinny = _LORA_SKINNY and rc <= 64  # rank-r products stream their activation operand once, no LDS staging
+            # the rank-r operand of the weight-gradient GEMMs sits in a 128-wide zero-padded buffer: p_valid lets the kernel skip
+            # the MFMA work on the padding (the two NT products below already run at the HBM rate of their activation operand
+            # through the 128-wide tile kernel: 27 us for 123 MB, measured — a dedicated skinny kernel was slower)
+            pv = rtot if (_LORA_PVALID and rtot <= 64) else 0
             if any(a_need):
-                du = K.gemm_nt_skinny(dy, BbT, rc) if skinny else K.gemm_nt(dy, BbT)  # [M, Rpad] = dy @ (s*B)
-                dA_full = K.gemm_tn(du, x, p_valid=rc if skinny else 0)               # [Rpad, Kpad]
+                du = K.gemm_nt(dy, BbT)                       # [M, Rpad] = dy @ (s*B)
+                dA_full = K.gemm_tn(du, x, p_valid=pv)        # [Rpad, Kpad]
             if any(b2_need):
-                # [M, Rpad] = x @ (s*A*mask)^T, recomputed here instead of saved by the forward
-                u = K.gemm_nt_skinny(x, Am, rc) if skinny else K.gemm_nt(x, Am)
+                u = K.gemm_nt(x, Am)                          # [M, Rpad] = x @ (s*A*mask)^T, recomputed here, not saved by the forward
                 # rank-r operand first (its zero-padded columns are skipped): [Rpad, Npad], read through its transpose
-                dB_full = K.gemm_tn(u, dy, p_valid=rc if skinny else 0).t()           # [Npad, Rpad]
+                dB_full = K.gemm_tn(u, dy, p_valid=pv).t()    # [Npad, Rpad]
             dAs, dBs = [], []
             ro = no = li = 0
             for w, s in zip(weights, cfg.loras):
