@@ -1,7 +1,10 @@
 """Whole-path GPU parity: the libwft engine (through whisper_finetune's reference-shaped interface) against the
 golden fixture (HF transformers), the CPU oracle, and the reference's training-time extras.
 bf16 tolerance (stated per check): activations are rounded to bf16 between kernels (8 mantissa bits), so
-logits agree to ~1e-2 relative L2, the mean loss to 2e-3 relative, gradients to 5e-2 relative L2."""
+logits agree to ~1e-2 relative L2, the mean loss to 5e-4 relative, gradients per tensor to 3e-2 relative L2 (8e-2 for the
+ill-conditioned q / k projections of the decoder's causal self-attention; `assert_grad_errors`)."""
+import re
+
 import numpy as np
 import pytest
 import torch
@@ -21,6 +24,33 @@ DEV = torch.device("cuda:0")
 def rel(a, b):
     a, b = a.detach().float().cpu(), b.detach().float().cpu()
     return ((a - b).norm() / (b.norm() + 1e-20)).item()
+
+
+_ILL = re.compile(r"decoder\.blocks\.\d+\.attn\.(query|key)\.")
+
+
+def assert_lora_grad_errors(errs):
+    """Rank-r adapter gradients (two extra bf16 roundings: du = dy sB and u = x (sA*m)^T are bf16 GEMM outputs): every adapter
+    but those of the decoder's causal self-attention q / k within 5e-2, those within 0.12, median 2e-2."""
+    worst_ill = sorted(((n, e) for n, e in errs.items() if _ILL.search(n)), key=lambda kv: -kv[1])[:3]
+    worst = sorted(((n, e) for n, e in errs.items() if not _ILL.search(n)), key=lambda kv: -kv[1])[:3]
+    print("LoRA grad errors: worst", worst, "worst ill-conditioned", worst_ill, "median", float(np.median(list(errs.values()))))
+    assert worst[0][1] < 5e-2, worst
+    assert not worst_ill or worst_ill[0][1] < 0.12, worst_ill
+    assert float(np.median(list(errs.values()))) < 2e-2
+
+
+def assert_grad_errors(errs, tag=""):
+    """Per-tensor relative-L2 gradient errors of a bf16 engine step against the oracle (fp32 or bf16-emulating).
+    Calibrated on the GPU (tools/dev_emu_tol.py, tiny and base): every tensor but the q / k projections of the decoder's causal
+    self-attention sits at 0.9-1.6 % (bound 3e-2 — a mis-scaled term moves a tensor by tens of per cent); those q / k tensors
+    are small differences of large terms under near-uniform attention and reach 3.5-6.8 % for ANY two bf16 evaluations
+    (bound 8e-2); median 0.5-0.9 % (bound 1.5e-2)."""
+    worst_ill = sorted(((n, e) for n, e in errs.items() if _ILL.search(n)), key=lambda kv: -kv[1])[:3]
+    worst = sorted(((n, e) for n, e in errs.items() if not _ILL.search(n)), key=lambda kv: -kv[1])[:3]
+    assert worst[0][1] < 3e-2, (tag, worst)
+    assert not worst_ill or worst_ill[0][1] < 8e-2, (tag, worst_ill)
+    assert float(np.median(list(errs.values()))) < 1.5e-2, tag
 
 
 def _engine(dims: O.ModelDimensions, params):
@@ -78,10 +108,14 @@ def test_tiny_training_step_matches_oracle():
     assert (mel.cpu() - mel_ref).abs().max() < 2e-3
     loss = m(mel, y_in.to(DEV), targets=y_out.to(DEV), label_smoothing=0.1)
     loss.backward()
-    assert abs(loss.item() - loss_ref.item()) < 2e-3 * loss_ref.item()
-    errs = {n: rel(p.grad, p_req[n].grad) for n, p in m.named_parameters()}
-    assert max(errs.values()) < 8e-2, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
-    assert float(np.median(list(errs.values()))) < 2e-2
+    assert abs(loss.item() - loss_ref.item()) < 5e-4 * loss_ref.item()
+    assert_grad_errors({n: rel(p.grad, p_req[n].grad) for n, p in m.named_parameters()}, "vs fp32 oracle")
+    # ... and against the oracle's bf16-emulation mode (rounds where the kernels round)
+    p_emu = {k: v.clone().requires_grad_(k != "encoder.positional_embedding") for k, v in params.items()}
+    loss_emu = O.cross_entropy(O.Oracle(dims, p_emu, emulate_bf16=True).forward(mel.cpu(), y_in), y_out, 0.1)
+    loss_emu.backward()
+    assert abs(loss.item() - loss_emu.item()) < 5e-4 * loss_emu.item()
+    assert_grad_errors({n: rel(p.grad, p_emu[n].grad) for n, p in m.named_parameters()}, "vs bf16-emulating oracle")
     # fused loss == the reference's two-step form on the same logits
     m.eval()
     with torch.no_grad():
@@ -129,11 +163,11 @@ def test_lora_low_rank_path_matches_oracle_parametrization():
     loss.backward()
     assert abs(loss.item() - loss_ref.item()) < 2e-3 * loss_ref.item()
     mods = dict(m.named_modules())
-    errs = []
+    errs = {}
     for n, (A, Bm, _, _) in cfg.items():
         ad = mods[n].parametrizations.weight[0]
-        errs += [rel(ad.lora_A.grad, A.grad), rel(ad.lora_B.grad, Bm.grad)]
-    assert max(errs) < 0.12 and float(np.median(errs)) < 3e-2, (max(errs), np.median(errs))
+        errs[n + ".lora_A"], errs[n + ".lora_B"] = rel(ad.lora_A.grad, A.grad), rel(ad.lora_B.grad, Bm.grad)
+    assert_lora_grad_errors(errs)
     assert all(p.grad is None for n, p in m.named_parameters() if "lora" not in n)  # base stays frozen
 
 
@@ -289,10 +323,9 @@ def test_fused_adamw_update_reaches_the_bf16_weight_shadows():
     assert torch.equal(after, want)  # same kernels, same fp32 masters -> identical logits
 
 
-def _grad_check(m, p_req, tol_max, tol_med):
+def _grad_check(m, p_req, tag=""):
     errs = {n: rel(p.grad, p_req[n].grad) for n, p in m.named_parameters() if p.grad is not None and p_req[n].grad is not None}
-    assert max(errs.values()) < tol_max, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
-    assert float(np.median(list(errs.values()))) < tol_med
+    assert_grad_errors(errs, tag)
     return errs
 
 
@@ -310,8 +343,8 @@ def test_base_full_finetune_step_matches_oracle():
     mel = K.logmel(audio.to(DEV), O.mel_filters(dims.n_mels).to(DEV))
     loss = m(mel, y_in.to(DEV), targets=y_out.to(DEV), label_smoothing=0.1)
     loss.backward()
-    assert abs(loss.item() - loss_ref.item()) < 2e-3 * loss_ref.item()
-    _grad_check(m, p_req, 8e-2, 2e-2)
+    assert abs(loss.item() - loss_ref.item()) < 5e-4 * loss_ref.item()
+    _grad_check(m, p_req, "base vs fp32 oracle")
 
 
 def test_turbo_lora_prompt_and_timestamp_targets_match_oracle():
@@ -355,9 +388,7 @@ def test_turbo_lora_prompt_and_timestamp_targets_match_oracle():
     assert abs(loss.item() - loss_ref.item()) < 2e-3 * loss_ref.item()
     named = dict(m.named_parameters())
     assert all(p.grad is None for n, p in named.items() if "lora" not in n)  # base weights frozen
-    errs = {n: rel(named[n].grad, req[n].grad) for n in req}
-    assert max(errs.values()) < 1e-1, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
-    assert float(np.median(list(errs.values()))) < 3e-2
+    assert_lora_grad_errors({n: rel(named[n].grad, req[n].grad) for n in req})
 
 
 def test_lora_dropout_masks_are_redrawn_per_micro_batch():
