@@ -553,3 +553,32 @@ def test_two_engine_models_interleaved():
     l1, p1 = run(True)
     assert l0 == l1
     assert all(torch.equal(p0[n], p1[n]) for n in p0)
+
+
+@pytest.mark.parametrize("B,S", [(1, 448), (1, 1), (3, 5)])
+def test_decoder_length_edge_cases_match_oracle(B, S):
+    """Maximum decoder context (S = 448 = n_text_ctx, the reference truncates prompts to reach it: data_loader.py:331-338), a single
+    token, and an odd ragged shape — bf16 engine and fp32 mode against the oracle."""
+    dims, params, _, _, _ = _tiny_case()
+    audio, y_in, y_out = O.synthetic_batch(dims, B, max(S, 5))
+    y_in, y_out = y_in[:, :S].contiguous(), y_out[:, :S].contiguous()
+    if S > 8:
+        y_out[0, :4] = -100
+    mel = O.log_mel_spectrogram(audio, dims.n_mels)
+    p_req = {k: v.clone().requires_grad_(k != "encoder.positional_embedding") for k, v in params.items()}
+    logits_ref = O.Oracle(dims, p_req).forward(mel, y_in)
+    loss_ref = O.cross_entropy(logits_ref, y_out, 0.1)
+    loss_ref.backward()
+    for mode, ltol, gtol in (("bf16", 1e-3, 0.12), ("fp32", 1e-4, 3e-3)):
+        m = _engine(dims, params).set_compute_dtype(mode).train()
+        loss = m(mel.to(DEV), y_in.to(DEV), targets=y_out.to(DEV), label_smoothing=0.1)
+        loss.backward()
+        assert abs(loss.item() - loss_ref.item()) < ltol * loss_ref.item(), (mode, loss.item(), loss_ref.item())
+        errs = {n: rel(p.grad, p_req[n].grad) for n, p in m.named_parameters()}
+        assert float(np.median(list(errs.values()))) < gtol / 4, mode
+        if S > 1:  # with a single token the causal q / k gradients are exactly zero on both sides
+            assert max(errs.values()) < gtol, (mode, sorted(errs.items(), key=lambda kv: -kv[1])[:3])
+        m.eval()
+        with torch.no_grad():
+            logits = m(mel.to(DEV), y_in.to(DEV))
+        assert logits.shape == (B, S, dims.n_vocab) and rel(logits, logits_ref) < (2e-2 if mode == "bf16" else 1e-3)
