@@ -270,3 +270,32 @@ def test_any_torch_optimizer_step_invalidates_bf16_shadows():
         before = ops._SHADOW_EPOCH[0]
         opt.step()
         assert ops._SHADOW_EPOCH[0] == before + 1
+
+
+def test_lora_mask_pool_draws_once_per_forward_and_is_dropped_on_merge():
+    """apply_lora attaches every adapter to ONE mask pool: a forward pre-hook on the model redraws all dropout masks with one
+    Bernoulli call, an adapter's mask is its slice ({0, 1/(1-p)} values, [1, in] shape), eval mode and merged models draw nothing."""
+    m = _tiny()
+    lora.apply_lora(m, {"rank": 4, "lora_alpha": 8, "lora_dropout": 0.5})
+    pool = m.__dict__["_wft_lora_pool"]
+    ads = [mod.parametrizations.weight[0] for mod in m.modules() if "parametrizations" in mod._modules]
+    assert len(pool.adapters) == len(ads) == 64 and pool.total == sum(a.lora_A.shape[1] for a in ads)
+    m.train()
+    torch.manual_seed(0)
+    pool._on_forward(m, ())
+    first = [a.draw_mask(True).clone() for a in ads]
+    assert all(f.shape == (1, a.lora_A.shape[1]) for f, a in zip(first, ads))
+    assert all(set(f.unique().tolist()) <= {0.0, 2.0} for f in first)
+    again = [a.draw_mask(True) for a in ads]          # same forward: same masks (a checkpoint recompute sees what the forward saw)
+    assert all(torch.equal(x, y) for x, y in zip(first, again))
+    pool._on_forward(m, ())                            # next forward: a new draw
+    assert any(not torch.equal(x, a.draw_mask(True)) for x, a in zip(first, ads))
+    m.eval()
+    pool._on_forward(m, ())
+    assert all(a.draw_mask(False) is None for a in ads) and pool.buf is None
+    s1, s2 = ads[0].spec(True), ads[0].spec(True)      # every drawn mask carries its own serial number
+    m.train(); pool._on_forward(m, ())
+    s1, s2 = ads[0].spec(True), ads[0].spec(True)
+    assert s1.draw_id != s2.draw_id and s1.key() != s2.key()
+    lora.merge_lora(m)
+    assert "_wft_lora_pool" not in m.__dict__ and not m._forward_pre_hooks
