@@ -158,7 +158,10 @@ typedef struct {
    * Muon optimizer: B = b*A + c*A@A, X' = a*X + B@X — muon.py zeropower_via_newtonschulz5.)            */
   float beta;
   /* wft_gemm_tn_bf16 only (P = 128, f32 C): if 0 < p_valid <= 64, columns >= p_valid of A are known to be zero (a rank-r LoRA
-   * operand in its 128-wide padded buffer): the kernel skips the MFMA work on them; rows >= p_valid of C are written as zero. */
+   * operand in its 128-wide padded buffer).  Selects the load-stream kernel for rank-r operands: only the first
+   * 16*ceil(p_valid/16) columns of A are read, the split-K workspace holds only those rows (wft_gemm_tn_workspace_bytes
+   * accounts for it), rows >= 16*ceil(p_valid/16) of C are written as zero (left alone when accumulating).  Results are
+   * bit-identical to p_valid = 0. */
   int p_valid;
   /* wft_gemm_nt_bf16 only: if != NULL (bf16 C, batch == 1), colsum[n] = sum over rows of the C just written — the bias
    * gradient of the Linear that consumes C as its dy (C = d(pre-activation) from the DGELU epilogue).  With `workspace`

@@ -354,7 +354,9 @@ def test_gemm_tn_128_tile_split_k_is_bitwise_reproducible(R, P, Q):
     g = torch.Generator(device=DEV).manual_seed(R + P)
     a = bf(torch.randn(R, P, device=DEV, generator=g)); b = bf(torch.randn(R, Q, device=DEV, generator=g))
     outs = [K.gemm_tn(a, b) for _ in range(4)]
-    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    assert all(torch.isfinite(o).all() for o in outs), [int((~torch.isfinite(o)).sum()) for o in outs]
+    assert all(torch.equal(outs[0], o) for o in outs[1:]), [
+        (int((outs[0] != o).sum()), float((outs[0] - o).abs().max())) for o in outs[1:]]
     close(outs[0], a.float().t() @ b.float(), 2e-5)
     accs = []
     for _ in range(2):
@@ -445,10 +447,13 @@ def test_attention_backward_fused_projection_bias_sums(B, H, Tq, Tk, causal):
         assert (got - want).abs().max() < 2e-4 * want.abs().max() + 1e-3
 
 
-@pytest.mark.parametrize("R,Q,rc", [(48000, 1280, 16), (5000, 5120, 48), (3001, 384, 64)])
+@pytest.mark.parametrize("R,Q,rc", [(48000, 1280, 16), (5000, 5120, 48), (3001, 384, 64), (48000, 5120, 32), (100, 256, 16),
+                                    (449, 128, 32), (64, 128, 16), (1, 128, 16)])
 def test_gemm_tn_p_valid_skips_only_zero_columns(R, Q, rc):
-    """Weight-gradient GEMM with a rank-r operand in its 128-wide zero-padded buffer (dA = du^T x, dB^T = u^T dy): p_valid skips
-    the MFMA work on the zero columns and gives exactly the result of the full kernel (same products, same order)."""
+    """Weight-gradient GEMM with a rank-r operand in its 128-wide zero-padded buffer (dA = du^T x, dB^T = u^T dy): p_valid selects
+    the load-stream kernel for rank-r operands (gemm_tn_rank_kernel: compact A staging, only the valid rows of the split-K
+    partials in the workspace) and gives exactly the result of the 128-tile kernel (same products, same order), padding rows of
+    C zero; ragged reduction lengths, one-step and one-row reductions, a single split (direct store) and accumulation."""
     g = torch.Generator().manual_seed(R + rc)
     a = torch.zeros(R, 128)
     a[:, :rc - 5] = torch.randn(R, rc - 5, generator=g)
@@ -459,3 +464,10 @@ def test_gemm_tn_p_valid_skips_only_zero_columns(R, Q, rc):
     assert torch.equal(full, fast)
     assert torch.count_nonzero(fast[rc:]) == 0
     close(fast, a.float().t() @ b.float(), 2e-5)
+    again = K.gemm_tn(a, b, p_valid=rc)
+    assert torch.equal(fast, again)  # split-K through the workspace: reproducible
+    base = torch.randn(128, Q, generator=g).to(DEV)
+    acc = K.gemm_tn(a, b, out=base.clone(), accumulate=True, p_valid=rc, alpha=0.5)
+    want = K.gemm_tn(a, b, out=base.clone(), accumulate=True, alpha=0.5)
+    assert torch.equal(acc, want)
+    assert torch.equal(acc[rc + 15:], base[rc + 15:])  # accumulation leaves the padding rows alone

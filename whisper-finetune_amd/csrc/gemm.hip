@@ -32,6 +32,7 @@ struct GemmP {
   int res_first;
   float* ws;  // split-K partial tiles [nsplit][P][Q] fp32 (TN, optional)
   float* cs_part;  // NT256: per-(row tile, wave row) column-sum partials [2*tiles_m][N] fp32, or NULL
+  int nsplit;  // gemm_tn_rank_kernel: split-K factor (its grid is 1-D)
   int diag;  // WFT_GEMM_DIAG, NT256 A/B switches: 6 skips the staged epilogue (timing only), 7 = general epilogue body everywhere, 8 = no continuous staging
 };
 
@@ -659,7 +660,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmP p) {
       int gr = t * 64 + r;
       gr = gr < R ? gr : R - 1;
       const int c = cp ^ (tn_f(r) << 1);
-      glds16(Ab + (long)gr * p.lda + p0 + (c << 3), sa + j * 1024);
+      // rank-r operand: only its first 2*PB 16-byte chunks per row are ever read back (the other LDS slots keep stale bytes)
+      if (PB == 0 || c < 2 * PB) glds16(Ab + (long)gr * p.lda + p0 + (c << 3), sa + j * 1024);
       glds16(Bb + (long)gr * p.ldb + q0 + (c << 3), sb + j * 1024);
     }
   };
@@ -741,6 +743,22 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmP p) {
     // stage the wave's 64(p) x 64(q) fp32 tile through LDS (two halves of 32 p-rows, row pitch 68
     // floats) so that every atomic wave-instruction adds one contiguous 256-byte row of C
     float* lds = (float*)(smem + wave * 16384);
+    if (PB > 0 && p.ws) {
+      // rank-r operand: the workspace holds only the 16*PB valid rows of every split, ws[split][16 PB][Q] (P == 128, p0 == 0)
+      if (wp == 0) {
+        float* wb = p.ws + (long)blockIdx.y * (16 * NPB) * Q + q0 + wq * 64 + lane;
+#pragma unroll
+        for (int jj = 0; jj < NPB; ++jj) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) *(f32x4*)(lds + li * 68 + i * 16 + 4 * g) = acc[i][jj] * p.alpha;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 8
+          for (int r = 0; r < 16; ++r) wb[(long)(jj * 16 + r) * Q] = lds[r * 68 + lane];
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+      }
+      return;
+    }
     // with a workspace (the default: wft_gemm_tn_workspace_bytes) the partial tile of split blockIdx.y is STORED to
     // ws[split][P][Q] and tn_splitk_reduce_kernel adds the splits in index order: bitwise reproducible.  Without one the
     // partial tiles are added into C with fp32 atomics (order, hence rounding, varies run to run).
@@ -786,6 +804,189 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmP p) {
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------- TN, rank-r A operand
+// The two LoRA adapter gradients dA = du^T x and dB^T = u^T dy: A is a rank-r operand (du / u, [R, lda]) whose data sits in the
+// first 16*PB columns of a 128-wide zero-padded buffer, B the [R, Q] activation stream.  HBM-bound on B (2 bytes per element
+// read once; the MFMA work is r/128 of a square tile's), so the kernel is built around the load stream instead of the tile:
+//   * ring of NST (4; 3 for PB > 2) stages {B [64 r][128 q] 16 KB, A [64 r][16 PB] 2 PB KB compact}: two workgroups per CU
+//     keep 2 x (NST - 1) x 18 KB in flight; LDS-DMA waited for with counted vmcnt and a plain s_barrier per step (the
+//     128-tile kernel's __syncthreads is a fence: it drains the prefetch it has just issued)
+//   * only the valid rows of a split's partial tile go to the workspace: ws[split][16 PB][Q] (tn_splitk_reduce_kernel adds
+//     the splits in index order and writes the padding rows of C as zero)
+//   * 1-D grid, split-major through xcd_remap: the q-tiles of one split run on one XCD and share its A rows in that L2.
+// All four waves multiply: wave w owns q columns [32 w, 32 w + 32) of the tile and all PB p-blocks.
+template <int PB>
+__global__ __launch_bounds__(256, 2) void gemm_tn_rank_kernel(GemmP p) {
+  constexpr int NST = PB <= 2 ? 4 : 3;
+  constexpr int APITCH = 32 * PB;        // bytes per A row in LDS
+  constexpr int ABYTES = 64 * APITCH;    // a stage's A part
+  constexpr int SBYTES = 16384 + ABYTES; // stage = B part, then A part
+  constexpr int NAI = (2 * PB + 3) / 4;  // A staging instructions per wave and stage (2 PB needed; surplus ones repeat a piece)
+  constexpr int LPS = 4 + NAI;           // LDS-DMA instructions per wave and stage
+  extern __shared__ __attribute__((aligned(16))) char dsmem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int Q = p.N, R = p.K;
+  const int tiles_q = Q >> 7;
+  const int nsplit = p.nsplit;
+  const int sid = xcd_remap(blockIdx.x, tiles_q * nsplit);
+  const int split = sid / tiles_q, tq = sid - split * tiles_q;
+  const int q0 = tq << 7;
+
+  const int tpb = (R + 63) >> 6;  // reduction tiles per batch item
+  const int nsteps_all = tpb * p.batch;
+  const int per = (nsteps_all + nsplit - 1) / nsplit;
+  const int s_begin = split * per;
+  const int s_end = (s_begin + per) < nsteps_all ? (s_begin + per) : nsteps_all;
+  const int nsteps = s_end - s_begin;
+  if (nsteps <= 0) return;  // (the host drops empty splits)
+
+  // staging.  B as in gemm_tn_kernel: instruction i (0..15) covers rows 4i..4i+3, lane -> (rr = lane>>4, position cp = lane&15)
+  // holding global chunk cp ^ swizzle(row); A compact row-major: piece ai (1 KB) = chunks 64 ai .. 64 ai + 63 of the
+  // [64][2 PB] chunk array.
+  const int rr = lane >> 4, cp = lane & 15;
+  int ld_b = s_begin / tpb, ld_t = s_begin - ld_b * tpb;
+  int ld_slot = 0;
+  auto stage = [&]() {
+    char* sbase = dsmem + ld_slot * SBYTES;
+    const unsigned short* Bb = p.B + (long)ld_b * p.sB + q0;
+    const unsigned short* Ab = p.A + (long)ld_b * p.sA;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = (wave * 4 + j) * 4 + rr;
+      int gr = ld_t * 64 + r;
+      gr = gr < R ? gr : R - 1;
+      const int c = cp ^ (tn_f(r) << 1);
+      glds16(Bb + (long)gr * p.ldb + (c << 3), sbase + wave * 4096 + j * 1024);
+    }
+#pragma unroll
+    for (int k = 0; k < NAI; ++k) {
+      const int ai = (wave + 4 * k) % (2 * PB);
+      const int id = ai * 64 + lane;
+      const int r = id / (2 * PB), c = id - r * (2 * PB);
+      int gr = ld_t * 64 + r;
+      gr = gr < R ? gr : R - 1;
+      glds16(Ab + (long)gr * p.lda + (c << 3), sbase + 16384 + ai * 1024);
+    }
+    if (++ld_t == tpb) { ld_t = 0; ++ld_b; }
+    if (++ld_slot == NST) ld_slot = 0;
+  };
+  const int rem_last = R - (tpb - 1) * 64;  // valid rows of the last tile of a batch item (64 = full)
+  int rd_t = ld_t, rd_slot = 0;
+
+  f32x4 acc[2][PB];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < PB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int g = lane >> 4, li = lane & 15;
+  const int r_in = li >> 2;
+  const int fsw = (r_in | ((g & 1) << 2)) << 1;  // tn_f(r) << 1 for r = 32 s + 8 g + 4 t + r_in
+  const unsigned lds0 = lds_addr_of(dsmem);
+  // per-lane byte offsets inside a stage of the (s = 0, t = 0) reads; t adds 4 rows, s adds 32 rows (immediates)
+  unsigned boff[2], aoff[PB];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int cq = wave * 32 + i * 16 + 4 * (li & 3);
+    boff[i] = (unsigned)((8 * g + r_in) * 256 + (((cq >> 3) ^ fsw) << 4) + ((cq & 7) << 1));
+  }
+#pragma unroll
+  for (int j = 0; j < PB; ++j) aoff[j] = (unsigned)(16384 + (8 * g + r_in) * APITCH + (j * 16 + 4 * (li & 3)) * 2);
+
+#pragma unroll
+  for (int u = 0; u < NST - 1; ++u)
+    if (u < nsteps) stage();
+
+  for (int step = 0; step < nsteps; ++step) {
+    const int ahead = nsteps - 1 - step;  // stages issued after this one so far: min(ahead, NST - 2)
+    if (ahead >= NST - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * LPS) : "memory");
+    else if (NST == 4 && ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave's pieces of this stage have landed; every wave is done reading the previous one
+    if (step + NST - 1 < nsteps) stage();
+    const unsigned sb = lds0 + rd_slot * SBYTES;
+    s16x4 qh[2][2][2], ph[2][PB][2];  // [s][block][t]
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int j = 0; j < PB; ++j) {
+        const unsigned ad = sb + aoff[j] + s * (32 * APITCH);
+        ph[s][j][0] = tn_tr_asm<0>(ad);
+        ph[s][j][1] = tn_tr_asm<4 * APITCH>(ad);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const unsigned ad = sb + boff[i] + s * 8192;
+        qh[s][i][0] = tn_tr_asm<0>(ad);
+        qh[s][i][1] = tn_tr_asm<1024>(ad);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    const bool ragged = rd_t == tpb - 1 && rem_last < 64;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 qf[2], pf[PB];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        s16x8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e] = qh[s][i][0][e]; o[4 + e] = qh[s][i][1][e]; }
+        qf[i] = __builtin_bit_cast(bf16x8, o);
+      }
+#pragma unroll
+      for (int j = 0; j < PB; ++j) {
+        s16x8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e] = ph[s][j][0][e]; o[4 + e] = ph[s][j][1][e]; }
+        pf[j] = __builtin_bit_cast(bf16x8, o);
+      }
+      if (ragged) {
+        // rows >= rem_last of this tile hold clamped duplicates: zero them in ONE operand (element e of the fragment is row
+        // 32 s + 8 g + e of the tile)
+#pragma unroll
+        for (int j = 0; j < PB; ++j)
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (32 * s + 8 * g + e >= rem_last) pf[j][e] = (__bf16)0.0f;
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < PB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[i], pf[j], acc[i][j], 0, 0, 0);
+    }
+    if (++rd_t == tpb) rd_t = 0;
+    if (++rd_slot == NST) rd_slot = 0;
+  }
+
+  // D[q][p]: lane (li, g) holds acc[i][j][e] = C[p = 16 j + li][q = 16 i + 4 g + e] of the wave's 32 columns
+  if (nsplit > 1) {
+    float* wb = p.ws + (long)split * (16 * PB) * Q + q0 + wave * 32 + 4 * g;
+#pragma unroll
+    for (int j = 0; j < PB; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) *(f32x4*)(wb + (long)(j * 16 + li) * Q + i * 16) = acc[i][j] * p.alpha;
+    return;
+  }
+  float* cb = (float*)p.C + q0 + wave * 32 + 4 * g;
+#pragma unroll
+  for (int j = 0; j < PB; ++j)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float* cptr = cb + (long)(j * 16 + li) * p.ldc + i * 16;
+      f32x4 o = acc[i][j] * p.alpha;
+      if (p.accumulate) o += *(const f32x4*)cptr;
+      *(f32x4*)cptr = o;
+    }
+  if (!p.accumulate)  // the padding rows of C
+    for (int idx = tid; idx < (128 - 16 * PB) * 32; idx += 256) {
+      const int row = 16 * PB + (idx >> 5), c4 = (idx & 31) * 4;
+      *(f32x4*)((float*)p.C + (long)row * p.ldc + q0 + c4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 }
 
 // ---------------------------------------------------------------------------------- TN 256x256
@@ -1014,13 +1215,18 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmP p) {
 }
 
 // split-K reduction: C[p][q] (+)= sum_s ws[s][p][q], splits added in index order (reproducible)
+// Rows P .. Pz-1 of C (the padding rows of a rank-r operand, absent from the workspace) are written as zero.
 __global__ __launch_bounds__(256) void tn_splitk_reduce_kernel(const float* ws, float* C, long ldc, int P, int Q, int nsplit,
-                                                                int accumulate) {
+                                                                int accumulate, int Pz) {
   const long nq4 = Q >> 2;
-  const long total = (long)P * nq4;
+  const long total = (long)(Pz > P ? Pz : P) * nq4;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const long pp = i / nq4, q4 = (i - pp * nq4) * 4;
     float* cp = C + pp * ldc + q4;
+    if (pp >= P) {
+      if (!accumulate) *(f32x4*)cp = f32x4{0.f, 0.f, 0.f, 0.f};
+      continue;
+    }
     f32x4 s = accumulate ? *(const f32x4*)cp : f32x4{0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < nsplit; ++k) s += *(const f32x4*)(ws + ((long)k * P + pp) * Q + q4);
     *(f32x4*)cp = s;
@@ -1232,10 +1438,20 @@ static int tn128_nsplit(const wft_gemm_args* a) {
   const long per = (nsteps + nsplit - 1) / nsplit;  // no empty split (see tn256_nsplit)
   return (int)((nsteps + per - 1) / per);
 }
+// p_valid: A is a rank-r operand in a 128-wide zero-padded buffer -> number of 16-column blocks that hold data (0: general path)
+static int tn128_pb(const wft_gemm_args* a) {
+  return (a->c_is_f32 && a->M == 128 && a->p_valid > 0 && a->p_valid <= 64) ? (a->p_valid + 15) / 16 : 0;
+}
+// rows of a split's partial tile kept in the workspace
+static int64_t tn_ws_rows(const wft_gemm_args* a) {
+  if (tn_uses_256(a)) return a->M;
+  const int pb = tn128_pb(a);
+  return pb ? 16 * pb : a->M;
+}
 extern "C" int64_t wft_gemm_tn_workspace_bytes(const wft_gemm_args* a) {
   if (!a) return 0;
   const int nsplit = tn_uses_256(a) ? tn256_nsplit(a) : tn128_nsplit(a);
-  return nsplit > 1 ? (int64_t)nsplit * a->M * a->N * 4 : 0;
+  return nsplit > 1 ? (int64_t)nsplit * tn_ws_rows(a) * a->N * 4 : 0;
 }
 
 extern "C" int wft_gemm_tn_bf16(const wft_gemm_args* a, void* stream) {
@@ -1269,22 +1485,40 @@ extern "C" int wft_gemm_tn_bf16(const wft_gemm_args* a, void* stream) {
       long g = (total + 255) / 256;
       if (g > 2048) g = 2048;
       hipLaunchKernelGGL(tn_splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, (const float*)a->workspace, (float*)a->C,
-                         (long)a->ldc, (int)a->M, (int)a->N, nsplit, a->accumulate);
+                         (long)a->ldc, (int)a->M, (int)a->N, nsplit, a->accumulate, (int)a->M);
     }
     WFT_CHECK_LAUNCH();
     return WFT_OK;
   }
   const long tiles = (a->M / 128) * (a->N / 128);
   const int nsplit = tn128_nsplit(a);
-  const bool use_ws = nsplit > 1 && a->workspace && a->workspace_bytes >= (int64_t)nsplit * a->M * a->N * 4 &&
+  const bool use_ws = nsplit > 1 && a->workspace && a->workspace_bytes >= (int64_t)nsplit * tn_ws_rows(a) * a->N * 4 &&
                       (((uintptr_t)a->workspace) & 15) == 0;
   if (use_ws) p.ws = (float*)a->workspace;
   if (nsplit > 1 && !use_ws && !a->accumulate)
     (void)hipMemset2DAsync(a->C, (size_t)a->ldc * 4, 0, (size_t)a->N * 4, (size_t)a->M, s);
   dim3 grid((unsigned)tiles, (unsigned)nsplit), block(256);
-  // p_valid: A is a rank-r operand in a 128-wide zero-padded buffer — skip the MFMA work on its zero columns
-  const int pb = (a->c_is_f32 && a->M == 128 && a->p_valid > 0 && a->p_valid <= 64) ? (a->p_valid + 15) / 16 : 0;
-  if (!a->c_is_f32) hipLaunchKernelGGL((gemm_tn_kernel<false>), grid, block, 0, s, p);
+  // p_valid: A is a rank-r operand in a 128-wide zero-padded buffer — its own load-stream kernel (gemm_tn_rank_kernel); the
+  // 128-tile kernel below only when a split-K run was given no workspace (WFT_GEMM_DIAG=9 forces it: A/B runs)
+  const int pb = tn128_pb(a);
+  if (pb > 0 && (nsplit == 1 || use_ws) && g_diag != 9) {
+    p.nsplit = nsplit;
+    const dim3 g1((unsigned)(tiles * nsplit));
+#define WFT_RANK_LAUNCH(PBV)                                                                      \
+  {                                                                                               \
+    constexpr int nst = (PBV) <= 2 ? 4 : 3;                                                       \
+    constexpr int bytes = nst * (16384 + 2048 * (PBV));                                           \
+    static DynLdsOnce once;                                                                       \
+    auto kfn = gemm_tn_rank_kernel<PBV>;                                                          \
+    once.set(kfn, bytes);                                                                         \
+    hipLaunchKernelGGL(kfn, g1, block, bytes, s, p);                                              \
+  }
+    if (pb == 1) WFT_RANK_LAUNCH(1)
+    else if (pb == 2) WFT_RANK_LAUNCH(2)
+    else if (pb == 3) WFT_RANK_LAUNCH(3)
+    else WFT_RANK_LAUNCH(4)
+#undef WFT_RANK_LAUNCH
+  } else if (!a->c_is_f32) hipLaunchKernelGGL((gemm_tn_kernel<false>), grid, block, 0, s, p);
   else if (pb == 1) hipLaunchKernelGGL((gemm_tn_kernel<true, 1>), grid, block, 0, s, p);
   else if (pb == 2) hipLaunchKernelGGL((gemm_tn_kernel<true, 2>), grid, block, 0, s, p);
   else if (pb == 3) hipLaunchKernelGGL((gemm_tn_kernel<true, 3>), grid, block, 0, s, p);
@@ -1295,7 +1529,7 @@ extern "C" int wft_gemm_tn_bf16(const wft_gemm_args* a, void* stream) {
     long g = (total + 255) / 256;
     if (g > 2048) g = 2048;
     hipLaunchKernelGGL(tn_splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, (const float*)a->workspace, (float*)a->C,
-                       (long)a->ldc, (int)a->M, (int)a->N, nsplit, a->accumulate);
+                       (long)a->ldc, (int)tn_ws_rows(a), (int)a->N, nsplit, a->accumulate, (int)a->M);
   }
   WFT_CHECK_LAUNCH();
   return WFT_OK;

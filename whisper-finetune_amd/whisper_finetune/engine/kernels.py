@@ -263,7 +263,8 @@ def gemm_nt(a, b, *, M=None, N=None, K=None, lda=None, ldb=None, out=None, out_f
 def gemm_tn(a, b, *, P=None, Q=None, R=None, lda=None, ldb=None, out=None, out_f32=True, accumulate=False,
             alpha=1.0, batch=1, strideA=0, strideB=0, p_valid=0):
     """C[P,Q] (+)= alpha * A[R,P]^T @ B[R,Q]  (weight gradients).  p_valid (P = 128 only): columns >= p_valid of A are zero
-    padding (a rank-r LoRA operand): their MFMA work is skipped."""
+    padding (a rank-r LoRA operand): the reduction runs in the load-stream kernel for rank-r operands (gemm.hip
+    gemm_tn_rank_kernel — 4-stage LDS-DMA ring, compact A, compact split-K workspace), bit-identical to the general path."""
     _chk(a, BF16, "A"); _chk(b, BF16, "B")
     if R is None:
         R = a.shape[0]

@@ -274,9 +274,10 @@ class LinearFn(torch.autograd.Function):
             Am, AmT, Bb, BbT = cfg.group.lora_shadows(weights, cfg.loras)
             dA_full = dB_full = None
             rtot = sum(s.A.shape[0] for s in cfg.loras if s is not None)
-            # the rank-r operand of the weight-gradient GEMMs sits in a 128-wide zero-padded buffer: p_valid lets the kernel skip
-            # the MFMA work on the padding (the two NT products below already run at the HBM rate of their activation operand
-            # through the 128-wide tile kernel: 27 us for 123 MB, measured — a dedicated skinny kernel was slower)
+            # the rank-r operand of the weight-gradient GEMMs sits in a 128-wide zero-padded buffer: p_valid routes them to the
+            # load-stream kernel for rank-r operands (35 us for the 123 MB activation of a 1280-wide Linear at 32 clips, 52 us
+            # through the square-tile kernel); the two NT products below already run at the HBM rate of their activation
+            # operand through the 128-wide tile kernel (27 us, measured — a dedicated skinny kernel was slower)
             pv = rtot if (_LORA_PVALID and rtot <= 64) else 0
             if any(a_need):
                 du = K.gemm_nt(dy, BbT)                       # [M, Rpad] = dy @ (s*B)
