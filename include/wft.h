@@ -168,6 +168,17 @@ typedef struct {
    * of wft_gemm_nt_colsum_workspace_bytes(args) bytes the sums are formed in the epilogue of the 256x256 kernel (no
    * second pass over C); otherwise the library runs wft_colsum_bf16 over C after the GEMM.                      */
   float* colsum;
+  /* wft_gemm_tn_bf16 with p_valid > 0 only (the two LoRA adapter gradients; both need the workspace, whose size
+   * wft_gemm_tn_workspace_bytes reports with these fields set).  Applied by the kernel that sums the split-K partials, so the
+   * adapter gradients leave the library in the layout autograd hands to the optimizer — no element-wise pass after the GEMM:
+   *  tn_col_scale: f32 [S][Q] or NULL; C[p][q] *= tn_col_scale[p / tn_scale_rows][q] (tn_scale_rows = 0: S = 1, one row for
+   *    all p).  dA = (du^T x) * mask, the dropout mask of each adapter of the group (model/lora.py via minLoRA's
+   *    dropout-on-A);
+   *  tn_block_n > 0: C is NOT a [128][ldc] matrix but Q / tn_block_n contiguous blocks [tn_block_n][tn_block_r], block b
+   *    holding the TRANSPOSE of rows b*tn_block_r .. +tn_block_r, columns b*tn_block_n .. +tn_block_n of the product (the
+   *    off-diagonal blocks are not stored): dB of adapter b of a group of equally shaped Linears, as [out, r] row-major. */
+  const float* tn_col_scale; int tn_scale_rows;
+  int tn_block_n; int tn_block_r;
 } wft_gemm_args;
 int wft_gemm_nt_bf16(const wft_gemm_args* args, void* stream);
 /* Which kernel wft_gemm_nt_bf16 dispatches these arguments to: 256 (gemm_nt256_kernel, 256x256

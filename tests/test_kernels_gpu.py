@@ -471,3 +471,33 @@ def test_gemm_tn_p_valid_skips_only_zero_columns(R, Q, rc):
     want = K.gemm_tn(a, b, out=base.clone(), accumulate=True, alpha=0.5)
     assert torch.equal(acc, want)
     assert torch.equal(acc[rc + 15:], base[rc + 15:])  # accumulation leaves the padding rows alone
+
+
+@pytest.mark.parametrize("R,Q,nb,r", [(48000, 1280, 1, 16), (5000, 3840, 3, 16), (449, 256, 2, 8), (100, 128, 1, 16), (3001, 2560, 2, 32)])
+def test_gemm_tn_adapter_gradient_outputs(R, Q, nb, r):
+    """The two output forms of the rank-r weight-gradient GEMM that finish the LoRA adapter gradients inside the split-K reduce
+    (wft.h tn_col_scale / tn_block_n): dA = (du^T x) * mask with one mask row per adapter of the group, and dB as per-adapter
+    [out, r] row-major blocks (the transposed diagonal blocks of u^T dy) — both exactly the plain product followed by the
+    torch ops they replace, also with a single split (short reductions) and when accumulating."""
+    g = torch.Generator().manual_seed(R + Q + r)
+    rtot, n = nb * r, Q // nb
+    a = torch.zeros(R, 128)
+    a[:, :rtot] = torch.randn(R, rtot, generator=g)
+    a = bf(a).to(DEV)
+    b = bf(torch.randn(R, Q, generator=g)).to(DEV)
+    ref = K.gemm_tn(a, b, p_valid=rtot)
+    scale = (torch.rand(nb, Q, generator=g) < 0.8).float().mul(1.25).to(DEV)
+    got = K.gemm_tn(a, b, p_valid=rtot, col_scale=scale, scale_rows=r if nb > 1 else 0)
+    want = ref.clone()
+    for i in range(nb):
+        want[i * r:(i + 1) * r] *= scale[i]
+    assert torch.equal(got, want) and torch.count_nonzero(got[rtot:]) == 0
+    blocks = K.gemm_tn(a, b, p_valid=rtot, block_n=n, block_r=r)
+    assert blocks.shape == (Q * r,)
+    for i in range(nb):
+        assert torch.equal(blocks[i * n * r:(i + 1) * n * r].view(n, r), ref[i * r:(i + 1) * r, i * n:(i + 1) * n].t())
+    base = torch.randn(Q * r, generator=g).to(DEV)
+    acc = K.gemm_tn(a, b, p_valid=rtot, block_n=n, block_r=r, out=base.clone(), accumulate=True)
+    assert torch.equal(acc, base + blocks)
+    with pytest.raises(Exception):
+        K.gemm_tn(a, b, col_scale=scale)  # only for rank-r operands

@@ -964,7 +964,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_rank_kernel(GemmP p) {
   }
 
   // D[q][p]: lane (li, g) holds acc[i][j][e] = C[p = 16 j + li][q = 16 i + 4 g + e] of the wave's 32 columns
-  if (nsplit > 1) {
+  if (p.ws) {  // also with ONE split when the reduce kernel has work of its own (column scale, block-transposed output)
     float* wb = p.ws + (long)split * (16 * PB) * Q + q0 + wave * 32 + 4 * g;
 #pragma unroll
     for (int j = 0; j < PB; ++j)
@@ -1216,20 +1216,44 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmP p) {
 
 // split-K reduction: C[p][q] (+)= sum_s ws[s][p][q], splits added in index order (reproducible)
 // Rows P .. Pz-1 of C (the padding rows of a rank-r operand, absent from the workspace) are written as zero.
+// col_scale / blk_n: the LoRA adapter-gradient forms of wft_gemm_args (tn_col_scale, tn_block_n): a per-(row group, column)
+// factor, and the transposed block-diagonal output.
 __global__ __launch_bounds__(256) void tn_splitk_reduce_kernel(const float* ws, float* C, long ldc, int P, int Q, int nsplit,
-                                                                int accumulate, int Pz) {
+                                                                int accumulate, int Pz, const float* col_scale, int scale_rows,
+                                                                int blk_n, int blk_r) {
   const long nq4 = Q >> 2;
   const long total = (long)(Pz > P ? Pz : P) * nq4;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const long pp = i / nq4, q4 = (i - pp * nq4) * 4;
     float* cp = C + pp * ldc + q4;
     if (pp >= P) {
-      if (!accumulate) *(f32x4*)cp = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (!accumulate && blk_n == 0) *(f32x4*)cp = f32x4{0.f, 0.f, 0.f, 0.f};
       continue;
     }
-    f32x4 s = accumulate ? *(const f32x4*)cp : f32x4{0.f, 0.f, 0.f, 0.f};
+    int pr = 0;
+    float* ob = nullptr;
+    if (blk_n > 0) {
+      const int blk = (int)(q4 / blk_n);  // q4 .. q4+3 lie in one block (blk_n % 4 == 0)
+      pr = (int)pp - blk * blk_r;
+      if (pr < 0 || pr >= blk_r) continue;  // off-diagonal: not stored
+      ob = C + (long)blk * blk_n * blk_r + (q4 - (long)blk * blk_n) * blk_r + pr;
+    }
+    const bool plain = !col_scale && !ob;
+    // plain form: C (+)= sum of the splits, starting from C when accumulating (the order the 256x256 path always had)
+    f32x4 s = (plain && accumulate) ? *(const f32x4*)cp : f32x4{0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < nsplit; ++k) s += *(const f32x4*)(ws + ((long)k * P + pp) * Q + q4);
-    *(f32x4*)cp = s;
+    if (plain) {
+      *(f32x4*)cp = s;
+      continue;
+    }
+    if (col_scale) s *= *(const f32x4*)(col_scale + (scale_rows > 0 ? pp / scale_rows : 0) * Q + q4);
+    if (ob) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ob[(long)e * blk_r] = accumulate ? ob[(long)e * blk_r] + s[e] : s[e];
+    } else {
+      if (accumulate) s += *(const f32x4*)cp;
+      *(f32x4*)cp = s;
+    }
   }
 }
 
@@ -1448,10 +1472,12 @@ static int64_t tn_ws_rows(const wft_gemm_args* a) {
   const int pb = tn128_pb(a);
   return pb ? 16 * pb : a->M;
 }
+// the adapter-gradient forms (column scale / block-transposed output) are applied by the reduce kernel: always through the workspace
+static bool tn_needs_reduce(const wft_gemm_args* a) { return a->tn_col_scale != nullptr || a->tn_block_n > 0; }
 extern "C" int64_t wft_gemm_tn_workspace_bytes(const wft_gemm_args* a) {
   if (!a) return 0;
   const int nsplit = tn_uses_256(a) ? tn256_nsplit(a) : tn128_nsplit(a);
-  return nsplit > 1 ? (int64_t)nsplit * tn_ws_rows(a) * a->N * 4 : 0;
+  return (nsplit > 1 || tn_needs_reduce(a)) ? (int64_t)nsplit * tn_ws_rows(a) * a->N * 4 : 0;
 }
 
 extern "C" int wft_gemm_tn_bf16(const wft_gemm_args* a, void* stream) {
@@ -1463,6 +1489,15 @@ extern "C" int wft_gemm_tn_bf16(const wft_gemm_args* a, void* stream) {
                 "base pointers must be 16-byte aligned");
   WFT_CHECK_ARG(!(a->accumulate && !a->c_is_f32), "accumulate needs an f32 C");
   WFT_CHECK_ARG(a->M < (1ll << 31) && a->N < (1ll << 31) && a->K < (1ll << 31), "dims exceed int32");
+  if (tn_needs_reduce(a)) {
+    WFT_CHECK_ARG(tn128_pb(a) > 0 && !tn_uses_256(a), "tn_col_scale / tn_block_n need a rank-r operand (P = 128, 0 < p_valid <= 64)");
+    WFT_CHECK_ARG(a->workspace && a->workspace_bytes >= wft_gemm_tn_workspace_bytes(a) && (((uintptr_t)a->workspace) & 15) == 0,
+                  "tn_col_scale / tn_block_n need the workspace of wft_gemm_tn_workspace_bytes");
+    WFT_CHECK_ARG(a->tn_scale_rows >= 0 && (((uintptr_t)a->tn_col_scale) & 15) == 0, "tn_col_scale: 16-byte aligned f32 [S][Q]");
+    if (a->tn_block_n > 0)
+      WFT_CHECK_ARG(a->tn_block_n % 4 == 0 && a->N % a->tn_block_n == 0 && a->tn_block_r >= 1 &&
+                    (a->N / a->tn_block_n) * (int64_t)a->tn_block_r <= 16 * tn128_pb(a), "tn_block_n / tn_block_r do not tile the product");
+  }
   GemmP p;
   fill_params(a, p);
   hipStream_t s = (hipStream_t)stream;
@@ -1485,15 +1520,15 @@ extern "C" int wft_gemm_tn_bf16(const wft_gemm_args* a, void* stream) {
       long g = (total + 255) / 256;
       if (g > 2048) g = 2048;
       hipLaunchKernelGGL(tn_splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, (const float*)a->workspace, (float*)a->C,
-                         (long)a->ldc, (int)a->M, (int)a->N, nsplit, a->accumulate, (int)a->M);
+                         (long)a->ldc, (int)a->M, (int)a->N, nsplit, a->accumulate, (int)a->M, (const float*)nullptr, 0, 0, 0);
     }
     WFT_CHECK_LAUNCH();
     return WFT_OK;
   }
   const long tiles = (a->M / 128) * (a->N / 128);
   const int nsplit = tn128_nsplit(a);
-  const bool use_ws = nsplit > 1 && a->workspace && a->workspace_bytes >= (int64_t)nsplit * tn_ws_rows(a) * a->N * 4 &&
-                      (((uintptr_t)a->workspace) & 15) == 0;
+  const bool use_ws = (nsplit > 1 || tn_needs_reduce(a)) && a->workspace &&
+                      a->workspace_bytes >= (int64_t)nsplit * tn_ws_rows(a) * a->N * 4 && (((uintptr_t)a->workspace) & 15) == 0;
   if (use_ws) p.ws = (float*)a->workspace;
   if (nsplit > 1 && !use_ws && !a->accumulate)
     (void)hipMemset2DAsync(a->C, (size_t)a->ldc * 4, 0, (size_t)a->N * 4, (size_t)a->M, s);
@@ -1529,7 +1564,8 @@ extern "C" int wft_gemm_tn_bf16(const wft_gemm_args* a, void* stream) {
     long g = (total + 255) / 256;
     if (g > 2048) g = 2048;
     hipLaunchKernelGGL(tn_splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, (const float*)a->workspace, (float*)a->C,
-                       (long)a->ldc, (int)tn_ws_rows(a), (int)a->N, nsplit, a->accumulate, (int)a->M);
+                       (long)a->ldc, (int)tn_ws_rows(a), (int)a->N, nsplit, a->accumulate, (int)a->M, a->tn_col_scale,
+                       a->tn_scale_rows, a->tn_block_n, a->tn_block_r);
   }
   WFT_CHECK_LAUNCH();
   return WFT_OK;

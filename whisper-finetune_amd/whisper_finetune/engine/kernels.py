@@ -261,10 +261,14 @@ def gemm_nt(a, b, *, M=None, N=None, K=None, lda=None, ldb=None, out=None, out_f
 
 
 def gemm_tn(a, b, *, P=None, Q=None, R=None, lda=None, ldb=None, out=None, out_f32=True, accumulate=False,
-            alpha=1.0, batch=1, strideA=0, strideB=0, p_valid=0):
+            alpha=1.0, batch=1, strideA=0, strideB=0, p_valid=0, col_scale=None, scale_rows=0, block_n=0, block_r=0):
     """C[P,Q] (+)= alpha * A[R,P]^T @ B[R,Q]  (weight gradients).  p_valid (P = 128 only): columns >= p_valid of A are zero
     padding (a rank-r LoRA operand): the reduction runs in the load-stream kernel for rank-r operands (gemm.hip
-    gemm_tn_rank_kernel — 4-stage LDS-DMA ring, compact A, compact split-K workspace), bit-identical to the general path."""
+    gemm_tn_rank_kernel — 4-stage LDS-DMA ring, compact A, compact split-K workspace), bit-identical to the general path.
+    With p_valid the kernel that sums the split-K partials can also finish the two LoRA adapter gradients (wft.h tn_col_scale /
+    tn_block_n): col_scale f32 [S, Q] multiplies C[p, q] by col_scale[p // scale_rows, q] (dA = (du^T x) * mask);
+    block_n / block_r return a flat f32 tensor of Q / block_n blocks [block_n, block_r], block b = the transpose of rows
+    b*block_r.., columns b*block_n.. of the product (dB of adapter b as [out, r] row-major)."""
     _chk(a, BF16, "A"); _chk(b, BF16, "B")
     if R is None:
         R = a.shape[0]
@@ -276,17 +280,28 @@ def gemm_tn(a, b, *, P=None, Q=None, R=None, lda=None, ldb=None, out=None, out_f
         lda = a.stride(0)
     if ldb is None:
         ldb = b.stride(0)
-    if out is None:
-        out = torch.empty((P, Q), dtype=F32 if out_f32 else BF16, device=a.device)
-        accumulate = False
+    if block_n:
+        if out is None:
+            out = torch.empty(Q * block_r, dtype=F32, device=a.device)
+            accumulate = False
+        ldc = Q
+    else:
+        if out is None:
+            out = torch.empty((P, Q), dtype=F32 if out_f32 else BF16, device=a.device)
+            accumulate = False
+        ldc = out.stride(0)
     args = L.GemmArgs()
     args.A, args.lda, args.strideA = a.data_ptr(), lda, strideA
     args.B, args.ldb, args.strideB = b.data_ptr(), ldb, strideB
-    args.C, args.ldc, args.strideC = out.data_ptr(), out.stride(0), 0
+    args.C, args.ldc, args.strideC = out.data_ptr(), ldc, 0
     args.c_is_f32, args.accumulate = int(out.dtype == F32), int(accumulate)
     args.epilogue, args.alpha = L.EPI_NONE, alpha
     args.M, args.N, args.K, args.batch = P, Q, R, batch
     args.p_valid = int(p_valid)
+    if col_scale is not None:
+        _chk(col_scale, F32, "col_scale")
+        args.tn_col_scale, args.tn_scale_rows = col_scale.data_ptr(), int(scale_rows)
+    args.tn_block_n, args.tn_block_r = int(block_n), int(block_r)
     lib = L.load()
     need = lib.wft_gemm_tn_workspace_bytes(C.byref(args))
     if need > 0:

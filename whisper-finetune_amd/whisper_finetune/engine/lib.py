@@ -35,6 +35,7 @@ class GemmArgs(C.Structure):
         ("workspace", c_vp), ("workspace_bytes", c_i64),
         ("beta", C.c_float), ("p_valid", C.c_int),
         ("colsum", c_vp),
+        ("tn_col_scale", c_vp), ("tn_scale_rows", C.c_int), ("tn_block_n", C.c_int), ("tn_block_r", C.c_int),
     ]
 
 

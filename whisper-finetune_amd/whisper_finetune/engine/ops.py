@@ -67,7 +67,8 @@ class LinearGroup:
     as ONE GEMM (q/k/v -> N = 3*d).  Rebuilt only when a parameter changed."""
 
     def __init__(self):
-        self.key = None
+        self.key = self.bkey = None
+        self.bias_aliased = False
         self.W = self.WT = self.bias = None
         self.lkey = None
         self.Am = self.AmT = self.Bb = self.BbT = None
@@ -93,7 +94,25 @@ class LinearGroup:
         if loras is not None and any(sp is not None for sp in loras):
             lkey = tuple(None if sp is None else sp.key() for sp in loras)
             live = True
-        key = (tuple(_ver(w) for w in weights), tuple(_ver(b) for b in biases), want_t, _SHADOW_EPOCH[0] if live else -1, lkey)
+        key = (tuple(_ver(w) for w in weights), want_t, _SHADOW_EPOCH[0] if live else -1, lkey)
+        # biases have a key of their own: frozen ones (a LoRA run) are copied once, not with every new dropout mask
+        bkey = (tuple(_ver(b) for b in biases), _SHADOW_EPOCH[0] if any(b is not None and b.requires_grad for b in biases) else -1)
+        if bkey != self.bkey:
+            n, k, npad = self.dims(weights)
+            if not any(b is not None for b in biases):
+                self.bias = None
+            elif len(weights) == 1 and n == npad and biases[0].dtype == F32 and biases[0].is_contiguous() and biases[0].data_ptr() % 16 == 0:
+                self.bias = biases[0].detach()  # the parameter itself: nothing to copy, never stale
+            else:
+                if self.bias is None or self.bias.shape[0] != npad or self.bias_aliased:
+                    self.bias = torch.zeros(npad, dtype=F32, device=weights[0].device)
+                off = 0
+                for w, b in zip(weights, biases):
+                    if b is not None:
+                        self.bias[off:off + w.shape[0]].copy_(b.detach())
+                    off += w.shape[0]
+            self.bias_aliased = self.bias is not None and any(b is not None and b.data_ptr() == self.bias.data_ptr() for b in biases)
+            self.bkey = bkey
         if key != self.key:
             n, k, npad = self.dims(weights)
             dev = weights[0].device
@@ -113,16 +132,6 @@ class LinearGroup:
                     K.lora_merge(w.detach(), sp.B.detach(), sp.A.detach(), None if sp.mask is None else sp.mask.detach(), sp.scaling,
                                  rows_pad=o, cols_pad=k, out=self.W[off:off + o], out_t=self.WT[:, off:off + o] if want_t else None)
                 off += o
-            if any(b is not None for b in biases):
-                if self.bias is None or self.bias.shape[0] != npad:
-                    self.bias = torch.zeros(npad, dtype=F32, device=dev)
-                off = 0
-                for w, b in zip(weights, biases):
-                    if b is not None:
-                        self.bias[off:off + w.shape[0]].copy_(b.detach())
-                    off += w.shape[0]
-            else:
-                self.bias = None
             self.key = key
         return self.W, self.WT, self.bias
 
@@ -162,6 +171,8 @@ class _LinearCfg:
 
 # WFT_LORA_PVALID=0: rank-r weight-gradient GEMMs without the p_valid shortcut (A/B runs)
 _LORA_PVALID = os.environ.get("WFT_LORA_PVALID", "1") != "0"
+# WFT_LORA_FUSED_OUT=0: adapter gradients sliced / masked / transposed by torch ops after the GEMMs (A/B runs)
+_LORA_FUSED_OUT = os.environ.get("WFT_LORA_FUSED_OUT", "1") != "0"
 # WFT_GELU_PAIR=0: keep the pre-activation and evaluate gelu' in the backward-data GEMM's epilogue (A/B runs)
 _GELU_PAIR = os.environ.get("WFT_GELU_PAIR", "1") != "0"
 
@@ -279,6 +290,23 @@ class LinearFn(torch.autograd.Function):
             # through the square-tile kernel); the two NT products below already run at the HBM rate of their activation
             # operand through the 128-wide tile kernel (27 us, measured — a dedicated skinny kernel was slower)
             pv = rtot if (_LORA_PVALID and rtot <= 64) else 0
+            specs = [s for s in cfg.loras if s is not None]
+            r0, n0 = specs[0].A.shape[0], weights[0].shape[0]
+            # every Linear of the group adapted, equal shapes, nothing padded, every adapter gradient wanted (the normal case:
+            # q/k/v, k/v or a single Linear): the kernel that sums the split-K partials applies the dropout masks to dA and
+            # writes dB as [out, r] blocks, so both leave the library as the contiguous tensors autograd hands on — no
+            # `dA * mask` kernel and no strided-view copy in AccumulateGrad per adapter (WFT_LORA_FUSED_OUT=0: the slicing below)
+            fused = (_LORA_FUSED_OUT and pv > 0 and len(specs) == n_w and all(a_need) and all(b2_need) and kpad == k
+                     and npad == n and all(s.A.shape[0] == r0 for s in specs) and all(w.shape[0] == n0 for w in weights)
+                     and all((s.mask is None) == (specs[0].mask is None) for s in specs))
+            if fused:
+                du = K.gemm_nt(dy, BbT)                       # [M, Rpad] = dy @ (s*B)
+                dA_full = K.gemm_tn(du, x, p_valid=pv, col_scale=_stacked_masks(specs), scale_rows=r0 if n_w > 1 else 0)
+                u = K.gemm_nt(x, Am)                          # [M, Rpad] = x @ (s*A*mask)^T (carries the scaling: wft_lora_pack)
+                dB_blocks = K.gemm_tn(u, dy, p_valid=pv, block_n=n0, block_r=r0)
+                out.extend(dA_full[i * r0:(i + 1) * r0] for i in range(n_w))
+                out.extend(dB_blocks[i * n0 * r0:(i + 1) * n0 * r0].view(n0, r0) for i in range(n_w))
+                return tuple(out)
             if any(a_need):
                 du = K.gemm_nt(dy, BbT)                       # [M, Rpad] = dy @ (s*B)
                 dA_full = K.gemm_tn(du, x, p_valid=pv)        # [Rpad, Kpad]
@@ -304,6 +332,22 @@ class LinearFn(torch.autograd.Function):
             out.extend(dAs)
             out.extend(dBs)
         return tuple(out)
+
+
+def _stacked_masks(specs):
+    """The dropout masks of a group's adapters as one f32 [S, K] tensor (None without dropout): a view when they are
+    consecutive slices of the model's mask pool (model/lora.py LoraMaskPool — q, k, v are drawn side by side), else a copy."""
+    m0 = specs[0].mask
+    if m0 is None:
+        return None
+    kk = m0.shape[-1]
+    if len(specs) == 1:
+        return m0.detach().view(1, kk)
+    st = m0.untyped_storage().data_ptr()
+    if all(s.mask.untyped_storage().data_ptr() == st and s.mask.is_contiguous()
+           and s.mask.data_ptr() == m0.data_ptr() + 4 * kk * i for i, s in enumerate(specs)):
+        return torch.as_strided(m0.detach(), (len(specs), kk), (kk, 1))
+    return torch.cat([s.mask.detach().view(1, kk) for s in specs], 0)
 
 
 _COLSUMS = {}  # data_ptr -> (producing tensor, colsum)
