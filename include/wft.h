@@ -73,6 +73,16 @@ int wft_lora_merge(const float* W, int64_t rows, int64_t cols, const float* B, c
 int wft_lora_pack(const float* A, const float* mask, const float* B, int rank, int64_t K, int64_t n, float scaling,
                   wft_bf16* Am, wft_bf16* AmT, wft_bf16* Bb, wft_bf16* BbT, int64_t rpad, int64_t npad, int64_t ro,
                   int64_t no, void* stream);
+/* wft_lora_merge (dst + dst_t) and wft_lora_pack of EVERY adapter of a model in one launch — issued once per training forward,
+ * right after the dropout masks are drawn, instead of two launches per Linear (2 x 512 for large-v3).  tab: device array of n
+ * rows x 20 int64:
+ *   0 W, 1 rows, 2 cols, 3 B, 4 A, 5 mask (or 0), 6 rank, 7 scaling (the float's bits), 8 dst, 9 dst_t (or 0), 10 ld_dst,
+ *   11 ld_dst_t, 12 Am, 13 AmT, 14 Bb, 15 BbT (12-15 all 0: no pack), 16 rpad, 17 npad, 18 ro, 19 no
+ * with the meanings of the two per-adapter entry points; rows % 64 == 0, cols % 64 == 0, rank <= 64, W 16-byte and dst / dst_t
+ * 8-byte aligned, ld_dst % 4 == 0, ld_dst_t % 4 == 0 (the caller checks: a model that does not fit keeps the per-adapter calls).
+ * tile_start: device int32 [n + 1], prefix sums of (rows / 64) * (cols / 64); total_tiles = tile_start[n].  Values are
+ * bit-identical to the per-adapter entry points. */
+int wft_lora_refresh_mt(const void* tab, const int32_t* tile_start, int n, int total_tiles, void* stream);
 /* y[i] = a[i] + b[i] (bf16) — gradient accumulation on the residual stream. */
 int wft_add_bf16(const wft_bf16* a, const wft_bf16* b, wft_bf16* y, int64_t n, void* stream);
 /* out = a*x + b*y over n bf16 elements (y may be NULL).  StochasticDepthMixin's train-time rescale

@@ -293,9 +293,13 @@ def test_lora_mask_pool_draws_once_per_forward_and_is_dropped_on_merge():
     m.eval()
     pool._on_forward(m, ())
     assert all(a.draw_mask(False) is None for a in ads) and pool.buf is None
-    s1, s2 = ads[0].spec(True), ads[0].spec(True)      # every drawn mask carries its own serial number
     m.train(); pool._on_forward(m, ())
-    s1, s2 = ads[0].spec(True), ads[0].spec(True)
-    assert s1.draw_id != s2.draw_id and s1.key() != s2.key()
+    s1, s2 = ads[0].spec(True), ads[0].spec(True)      # one serial number per draw of the pool: the same inside a forward
+    assert s1.draw_id == s2.draw_id == pool.serial and s1.key() == s2.key() and s1.owner is ads[0]
+    pool._on_forward(m, ())
+    s3 = ads[0].spec(True)                             # ... and a new one with the next forward's masks
+    assert s3.draw_id != s1.draw_id and s3.key() != s1.key() and s3.mask.data_ptr() == s1.mask.data_ptr()
+    own = lora.LoRAParametrization(8, 8, rank=2, lora_dropout_p=0.5)   # an adapter outside any pool draws its own masks
+    assert own.spec(True).draw_id != own.spec(True).draw_id
     lora.merge_lora(m)
     assert "_wft_lora_pool" not in m.__dict__ and not m._forward_pre_hooks

@@ -582,3 +582,62 @@ def test_decoder_length_edge_cases_match_oracle(B, S):
         with torch.no_grad():
             logits = m(mel.to(DEV), y_in.to(DEV))
         assert logits.shape == (B, S, dims.n_vocab) and rel(logits, logits_ref) < (2e-2 if mode == "bf16" else 1e-3)
+
+
+def test_lora_batched_refresh_is_bit_identical_to_the_per_linear_kernels():
+    """One wft_lora_refresh_mt launch per training forward (merged shadows, their transposes and the rank-r gradient-GEMM
+    operands of every adapter; engine/ops.LoraRefreshPlan, driven by the mask pool) against the per-Linear wft_lora_merge /
+    wft_lora_pack path it replaces: three optimizer steps with dropout 0.25 and a two-micro-batch accumulation window give
+    bit-identical losses, gradients and parameters; from the second forward on no per-Linear merge or pack is launched."""
+    dims, params, audio, y_in, y_out = _tiny_case()
+    mel = O.log_mel_spectrogram(audio, dims.n_mels).to(DEV)
+    y_in, y_out = y_in.to(DEV), y_out.to(DEV)
+
+    def run(batched: bool):
+        torch.manual_seed(5)  # lora_A's kaiming init
+        m = Whisper(MODEL_DIMS["tiny"]); m.load_state_dict(params)
+        lora_mod.apply_lora(m, {"rank": 8, "lora_alpha": 16, "lora_dropout": 0.25})
+        gl = torch.Generator().manual_seed(9)
+        for mod in m.modules():
+            if "parametrizations" in mod._modules:
+                ad = mod.parametrizations.weight[0]
+                with torch.no_grad():
+                    ad.lora_B.copy_(torch.randn(ad.lora_B.shape, generator=gl) * 0.05)
+        m.to(DEV).train()
+        pool = m.__dict__["_wft_lora_pool"]
+        if not batched:
+            pool.plan = None
+        opt = torch.optim.SGD([p for p in m.parameters() if p.requires_grad], lr=0.05)
+        counts = {"merge": 0, "pack": 0, "mt": 0}
+        real = (K.lora_merge, K.lora_pack, K.lora_refresh_mt)
+
+        def wrap(name, f):
+            def g(*a, **k):
+                counts[name] += 1
+                return f(*a, **k)
+            return g
+
+        K.lora_merge, K.lora_pack, K.lora_refresh_mt = wrap("merge", real[0]), wrap("pack", real[1]), wrap("mt", real[2])
+        try:
+            torch.manual_seed(77)
+            out, per_step = [], []
+            for step in range(3):
+                before = dict(counts)
+                for micro in range(2):
+                    loss = m(mel, y_in, targets=y_out, label_smoothing=0.1) / 2
+                    loss.backward()
+                    out.append(loss.detach().clone())
+                grads = [p.grad.detach().clone() for p in m.parameters() if p.requires_grad]
+                opt.step(); opt.zero_grad(set_to_none=True)
+                per_step.append({k: counts[k] - before[k] for k in counts})
+            return out, grads, [p.detach().clone() for p in m.parameters() if p.requires_grad], per_step
+        finally:
+            K.lora_merge, K.lora_pack, K.lora_refresh_mt = real
+
+    l1, g1, p1, c1 = run(True)
+    l0, g0, p0, c0 = run(False)
+    assert all(torch.equal(a, b) for a, b in zip(l1, l0)), ([x.item() for x in l1], [x.item() for x in l0])
+    assert all(torch.equal(a, b) for a, b in zip(g1, g0)) and all(torch.equal(a, b) for a, b in zip(p1, p0))
+    n_ad = 4 * 6 + 4 * 10
+    assert c0[1] == {"merge": 2 * n_ad, "pack": 2 * n_ad, "mt": 0}, c0
+    assert c1[0]["merge"] >= n_ad and c1[1] == {"merge": 0, "pack": 0, "mt": 2} and c1[2] == {"merge": 0, "pack": 0, "mt": 2}, c1

@@ -265,6 +265,103 @@ extern "C" int wft_lora_pack(const float* A, const float* mask, const float* B, 
   return WFT_OK;
 }
 
+// All adapters of a model in ONE launch: wft_lora_merge (bf16 shadow + transposed shadow) and wft_lora_pack for every row of
+// the table — what the 2 x 512 per-Linear launches of a large-v3 LoRA forward/backward do, once per forward, right after the
+// dropout masks are drawn.  Row layout (int64 x WFT_LORA_MT_FIELDS): see wft.h.  Blocks are 64x64 tiles of the weights, found by
+// bisection over tile_start; the tile in the first row band also writes its 64 columns of Am / AmT, the tile in the first column
+// band its 64 rows of Bb / BbT (the values are already in LDS for the merge).  Every value is computed exactly as by the
+// per-adapter kernels.
+#define WFT_LORA_MT_FIELDS 20
+__global__ __launch_bounds__(256) void lora_refresh_mt_kernel(const long* tab, const int* tile_start, int n) {
+  __shared__ unsigned short tile[64][68];
+  __shared__ float bs[64][65];
+  __shared__ __attribute__((aligned(16))) float as[64][68];
+  int lo = 0, hi = n - 1;
+  const int bid = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tile_start[mid] <= bid) lo = mid; else hi = mid - 1;
+  }
+  const long* e = tab + (long)lo * WFT_LORA_MT_FIELDS;
+  const float* W = (const float*)e[0];
+  const long rows = e[1], cols = e[2];
+  const float* Bm = (const float*)e[3];
+  const float* Am = (const float*)e[4];
+  const float* mask = (const float*)e[5];
+  const int r = (int)e[6];
+  const float scaling = __int_as_float((int)e[7]);
+  unsigned short* dst = (unsigned short*)e[8];
+  unsigned short* dst_t = (unsigned short*)e[9];
+  const long ld_dst = e[10], ld_dst_t = e[11];
+  unsigned short* pAm = (unsigned short*)e[12];
+  unsigned short* pAmT = (unsigned short*)e[13];
+  unsigned short* pBb = (unsigned short*)e[14];
+  unsigned short* pBbT = (unsigned short*)e[15];
+  const long rpad = e[16], npad = e[17], ro = e[18], no = e[19];
+  const int t = bid - tile_start[lo];
+  const int tiles_x = (int)(cols >> 6);
+  const int ty = t / tiles_x, tx = t - ty * tiles_x;
+  const long r0 = (long)ty * 64, c0 = (long)tx * 64;
+  for (int i = threadIdx.x; i < 64 * r; i += 256) {
+    const int a = i / r, q = i - a * r;
+    bs[a][q] = Bm[(r0 + a) * r + q];
+  }
+  for (int i = threadIdx.x; i < 64 * r; i += 256) {
+    const int q = i >> 6, j = i & 63;
+    const long c = c0 + j;
+    as[q][j] = scaling * Am[(long)q * cols + c] * (mask ? mask[c] : 1.f);
+  }
+  __syncthreads();
+  if (pAm && ty == 0)
+    for (int i = threadIdx.x; i < 64 * r; i += 256) {
+      const int q = i >> 6, j = i & 63;
+      const unsigned short v = f2bf(as[q][j]);
+      pAm[(ro + q) * cols + c0 + j] = v;
+      pAmT[(c0 + j) * rpad + ro + q] = v;
+    }
+  if (pBb && tx == 0)
+    for (int i = threadIdx.x; i < 64 * r; i += 256) {
+      const int a = i / r, q = i - a * r;
+      const unsigned short v = f2bf(scaling * bs[a][q]);
+      pBb[(no + r0 + a) * rpad + ro + q] = v;
+      pBbT[(ro + q) * npad + no + r0 + a] = v;
+    }
+  const int q4 = threadIdx.x & 15, rr0 = threadIdx.x >> 4;
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int rr = pass * 16 + rr0;
+    const long rw = r0 + rr, c = c0 + q4 * 4;
+    f32x4 w = *(const f32x4*)(W + rw * cols + c);
+    for (int q = 0; q < r; ++q) {
+      const float bq = bs[rr][q];
+      const f32x4 a4 = *(const f32x4*)&as[q][q4 * 4];
+      w[0] = fmaf(bq, a4[0], w[0]); w[1] = fmaf(bq, a4[1], w[1]); w[2] = fmaf(bq, a4[2], w[2]); w[3] = fmaf(bq, a4[3], w[3]);
+    }
+    const u32x2 pk = {pack2bf(w[0], w[1]), pack2bf(w[2], w[3])};
+    *(u32x2*)&tile[rr][q4 * 4] = pk;
+    *(u32x2*)(dst + rw * ld_dst + c) = pk;
+  }
+  if (dst_t) {
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int cc = pass * 16 + rr0;
+      const long c = c0 + cc, rw = r0 + q4 * 4;
+      const u32x2 pk = {(unsigned)tile[q4 * 4][cc] | ((unsigned)tile[q4 * 4 + 1][cc] << 16),
+                        (unsigned)tile[q4 * 4 + 2][cc] | ((unsigned)tile[q4 * 4 + 3][cc] << 16)};
+      *(u32x2*)(dst_t + c * ld_dst_t + rw) = pk;
+    }
+  }
+}
+extern "C" int wft_lora_refresh_mt(const void* tab, const int32_t* tile_start, int n, int total_tiles, void* stream) {
+  WFT_CHECK_ARG(tab && tile_start && n >= 0 && total_tiles >= 0, "bad args");
+  if (n == 0 || total_tiles == 0) return WFT_OK;
+  hipLaunchKernelGGL(lora_refresh_mt_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, (const long*)tab,
+                     (const int*)tile_start, n);
+  WFT_CHECK_LAUNCH();
+  return WFT_OK;
+}
+
 __global__ __launch_bounds__(256) void add_bf16_kernel(const unsigned short* a, const unsigned short* b,
                                                         unsigned short* y, long n) {
   const long nv = n >> 3;

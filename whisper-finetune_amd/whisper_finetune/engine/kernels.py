@@ -96,6 +96,12 @@ def lora_merge(w, B, A, mask, scaling: float, rows_pad=None, cols_pad=None, out=
     return out, out_t, out_f32
 
 
+def lora_refresh_mt(table: torch.Tensor, tile_start: torch.Tensor, n: int, total_tiles: int) -> None:
+    """wft_lora_refresh_mt: lora_merge (bf16 shadow + transposed shadow) and lora_pack of every adapter in the device table
+    (int64 [n, 20], see wft.h) in one launch."""
+    L.check(L.load().wft_lora_refresh_mt(_p(table), _p(tile_start), int(n), int(total_tiles), L.stream_ptr()), "wft_lora_refresh_mt")
+
+
 def lora_pack(A, mask, B, scaling: float, Am, AmT, Bb, BbT, ro: int, no: int) -> None:
     """One adapter's blocks of the rank-r gradient-GEMM operands (see wft_lora_pack): A f32 [r, K], mask f32 [1, K] or None,
     B f32 [n, r] -> Am [Rpad, K] / AmT, Bb [Npad, Rpad] / BbT (bf16, zero-initialised by the caller)."""

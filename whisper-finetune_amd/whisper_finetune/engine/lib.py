@@ -80,6 +80,7 @@ SIGNATURES = {
     "wft_cast_bf16_f32": [c_vp, c_vp, c_i64, c_vp],
     "wft_cast_pad_transpose_f32_bf16": [c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp],
     "wft_lora_merge": [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, C.c_int, C.c_float, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp],
+    "wft_lora_refresh_mt": [c_vp, c_vp, C.c_int, C.c_int, c_vp],
     "wft_lora_pack": [c_vp, c_vp, c_vp, C.c_int, c_i64, c_i64, C.c_float, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp],
     "wft_add_bf16": [c_vp, c_vp, c_vp, c_i64, c_vp],
     "wft_axpby_bf16": [C.c_float, c_vp, C.c_float, c_vp, c_vp, c_i64, c_vp],

@@ -48,15 +48,18 @@ class LoraSpec:
     """Low-rank adapter of one Linear (minLoRA semantics):
     W_eff = W + scaling * B @ (A * mask);  A [r, in], B [out, r], mask [1, in] (already drawn)."""
 
-    __slots__ = ("A", "B", "scaling", "mask", "draw_id")
+    __slots__ = ("A", "B", "scaling", "mask", "draw_id", "owner")
     _draws = itertools.count(1)
 
-    def __init__(self, A, B, scaling: float, mask: Optional[torch.Tensor]):
+    def __init__(self, A, B, scaling: float, mask: Optional[torch.Tensor], draw_id: Optional[int] = None, owner=None):
         self.A, self.B, self.scaling, self.mask = A, B, float(scaling), mask
         # a freshly drawn dropout mask is a new tensor with _version 0 whose storage the caching allocator very likely
         # recycles from the previous micro-batch's mask: (data_ptr, _version) cannot tell two draws apart.  Every drawn
-        # mask therefore carries a process-wide serial number that is part of the shadow-cache keys.
-        self.draw_id = 0 if mask is None else next(LoraSpec._draws)
+        # mask therefore carries a process-wide serial number that is part of the shadow-cache keys: its own, or — for masks
+        # that are slices of a model's mask pool — the serial of the pool's draw (one per forward of the model; a checkpoint
+        # recompute inside that forward sees the same masks under the same serial and reuses the shadows).
+        self.draw_id = 0 if mask is None else (next(LoraSpec._draws) if draw_id is None else draw_id)
+        self.owner = owner  # the adapter module (model/lora.py), for LoraRefreshPlan
 
     def key(self):
         return (_ver(self.A), _ver(self.B), self.draw_id, self.scaling)
@@ -133,6 +136,8 @@ class LinearGroup:
                                  rows_pad=o, cols_pad=k, out=self.W[off:off + o], out_t=self.WT[:, off:off + o] if want_t else None)
                 off += o
             self.key = key
+            if lkey is not None and None not in lkey:
+                _note_lora_group(self, weights, loras)
         return self.W, self.WT, self.bias
 
     def lora_shadows(self, weights, loras: Sequence[Optional[LoraSpec]]):
@@ -159,6 +164,116 @@ class LinearGroup:
                 no += w.shape[0]
             self.lkey = key
         return self.Am, self.AmT, self.Bb, self.BbT
+
+
+class LoraRefreshPlan:
+    """Every adapted Linear group of one model, refreshed by ONE wft_lora_refresh_mt launch per training forward (merged bf16
+    shadows W + s B (A*mask), their transposes, and the rank-r gradient-GEMM operands) instead of wft_lora_merge +
+    wft_lora_pack per Linear.  Owned by the model's mask pool (model/lora.py), which calls `refresh` right after it has drawn
+    the masks.  Groups enter the plan the first time they go through the per-Linear path (`LinearGroup.shadows` notes them);
+    after a refresh each group's cache keys are set to exactly what `shadows` / `lora_shadows` will compute for this forward,
+    so those calls find their buffers current — and fall back to the per-Linear kernels on any difference (a parameter
+    modified in between, a group that is not in the table yet, an adapter switched off)."""
+
+    def __init__(self):
+        self.groups = {}   # id(group) -> (group, weights, adapters)
+        self.dirty = True
+        self.items = []    # [(group, weights, adapters, packed)] in table order
+        self.ptrs = None
+        self.table = self.tile_start = None
+        self.total_tiles = 0
+        self.in_table = {}  # id(group) -> packed
+        self.unfit = set()  # groups whose shapes / alignment the batched kernel does not take: per-Linear path for good
+
+    def note(self, group: "LinearGroup", weights, adapters) -> None:
+        ent = self.groups.get(id(group))
+        if ent is None or len(ent[1]) != len(weights) or any(a is not b for a, b in zip(ent[1], weights)) \
+                or any(a is not b for a, b in zip(ent[2], adapters)):
+            self.groups[id(group)] = (group, tuple(weights), tuple(adapters))
+            self.dirty = True
+        elif not self.dirty and id(group) not in self.unfit and self.in_table.get(id(group)) != (group.Am is not None):
+            self.dirty = True  # noted before its buffers existed (or before its pack operands did)
+
+    def _build(self, mask_of) -> None:
+        import struct
+
+        rows, tiles, items, ptrs = [], [0], [], []
+        dev = None
+        for group, weights, adapters in self.groups.values():
+            if group.W is None or group.WT is None or not all(a.enabled for a in adapters):
+                continue
+            n, k, npad = group.dims(weights)
+            if k % 64 or any(w.shape[0] % 64 or w.data_ptr() % 16 or not w.is_contiguous() for w in weights) \
+                    or any(a.lora_A.shape[0] > 64 for a in adapters):
+                self.unfit.add(id(group))
+                continue
+            dev = weights[0].device
+            packed = group.Am is not None
+            rpad = group.Am.shape[0] if packed else 0
+            off = ro = 0
+            for w, ad in zip(weights, adapters):
+                o, r = w.shape[0], ad.lora_A.shape[0]
+                m = mask_of(ad)
+                rows.append([w.data_ptr(), o, k, ad.lora_B.data_ptr(), ad.lora_A.data_ptr(), 0 if m is None else m.data_ptr(), r,
+                             struct.unpack("<i", struct.pack("<f", float(ad.scaling)))[0],
+                             group.W.data_ptr() + 2 * off * group.W.stride(0), group.WT.data_ptr() + 2 * off,
+                             group.W.stride(0), group.WT.stride(0)]
+                            + ([group.Am.data_ptr(), group.AmT.data_ptr(), group.Bb.data_ptr(), group.BbT.data_ptr()] if packed
+                               else [0, 0, 0, 0]) + [rpad, npad, ro, off])
+                tiles.append(tiles[-1] + (o // 64) * (k // 64))
+                ptrs.extend((w.data_ptr(), ad.lora_A.data_ptr(), ad.lora_B.data_ptr()))
+                off += o
+                ro += r
+            items.append((group, weights, adapters, packed))
+        self.items, self.ptrs, self.total_tiles = items, ptrs, tiles[-1]
+        self.in_table = {id(it[0]): it[3] for it in items}
+        if rows:
+            self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
+            self.tile_start = torch.tensor(tiles, dtype=torch.int32).to(dev)
+        else:
+            self.table = self.tile_start = None
+        self.dirty = False
+
+    def refresh(self, mask_of, serial: int) -> None:
+        """mask_of(adapter) -> this forward's mask (a slice of the pool's PERSISTENT buffer) or None; serial: the draw id the
+        adapters' LoraSpecs carry for it."""
+        if not self.groups:
+            return
+        for attempt in range(2):
+            if self.dirty:
+                self._build(mask_of)
+            if self.table is None:
+                return
+            vers, cur = [], []
+            for group, weights, adapters, packed in self.items:
+                wv = tuple(_ver(w) for w in weights)
+                av = tuple((_ver(a.lora_A), _ver(a.lora_B)) for a in adapters)
+                vers.append((wv, av))
+                for x, (ya, yb) in zip(wv, av):
+                    cur.extend((x[0], ya[0], yb[0]))
+            stale = cur != self.ptrs or any(g.W is None or g.WT is None or (pk and g.Am is None) for g, _, _, pk in self.items)
+            if not stale:
+                break
+            self.dirty = True  # a parameter or a shadow buffer moved: rebuild the table once
+        else:
+            return
+        K.lora_refresh_mt(self.table, self.tile_start, self.table.shape[0], self.total_tiles)
+        epoch = _SHADOW_EPOCH[0]
+        for (group, weights, adapters, packed), (wv, av) in zip(self.items, vers):
+            lkey = tuple((a_v, b_v, 0 if mask_of(ad) is None else serial, float(ad.scaling)) for (a_v, b_v), ad in zip(av, adapters))
+            group.key = (wv, True, epoch, lkey)
+            if packed:
+                group.lkey = lkey + (epoch,)
+
+
+def _note_lora_group(group: "LinearGroup", weights, loras) -> None:
+    owners = [getattr(sp, "owner", None) for sp in loras]
+    if any(o is None for o in owners):
+        return
+    pool = getattr(owners[0], "_pool", None)
+    if pool is None or any(getattr(o, "_pool", None) is not pool for o in owners) or getattr(pool, "plan", None) is None:
+        return
+    pool.plan.note(group, weights, owners)
 
 
 class _LinearCfg:

@@ -16,6 +16,7 @@ the effective weight for code that reads it (merge / save / debugging).
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -59,7 +60,12 @@ class LoRAParametrization(nn.Module):
     def spec(self, training: bool) -> Optional[ops.LoraSpec]:
         if not self.enabled:
             return None
-        return ops.LoraSpec(self.lora_A, self.lora_B, self.scaling, self.draw_mask(training))
+        m = self.draw_mask(training)
+        pool = self._pool
+        if m is not None and pool is not None and pool.buf is not None and m.untyped_storage().data_ptr() == pool.buf.untyped_storage().data_ptr():
+            # the pool's draw for this forward of the model, under the pool's serial number
+            return ops.LoraSpec(self.lora_A, self.lora_B, self.scaling, m, draw_id=pool.serial, owner=self)
+        return ops.LoraSpec(self.lora_A, self.lora_B, self.scaling, m, owner=self)
 
     def forward(self, W: torch.Tensor) -> torch.Tensor:
         """Effective weight (off the hot path: merge / inspection)."""
@@ -85,10 +91,15 @@ class LoraMaskPool:
     def __init__(self, root: nn.Module):
         self.adapters = []
         self.offsets = {}
-        self.buf = None
+        self.buf = None      # this forward's masks, or None (eval, p = 0, mixed rates)
+        self.store = None    # the persistent buffer `buf` points at (wft_lora_refresh_mt's table holds addresses inside it)
+        self.serial = 0      # ops.LoraSpec draw id of the current masks
         self.total = 0
         self.handle = root.register_forward_pre_hook(self._on_forward)
         self.root = root
+        # all merged shadows / gradient-GEMM operands of the model in one launch per training forward (WFT_LORA_BATCH=0: the
+        # per-Linear kernels, A/B runs)
+        self.plan = ops.LoraRefreshPlan() if os.environ.get("WFT_LORA_BATCH", "1") != "0" else None
 
     def add(self, adapter: "LoRAParametrization") -> None:
         self.offsets[id(adapter)] = (self.total, adapter.lora_A.shape[1])
@@ -101,11 +112,21 @@ class LoraMaskPool:
             self.buf = None
             return
         p = self.adapters[0].lora_dropout_p
-        if p <= 0.0 or any(a.lora_dropout_p != p for a in self.adapters):
+        if any(a.lora_dropout_p != p for a in self.adapters):
             self.buf = None  # mixed rates: every adapter draws its own
             return
-        dev = self.adapters[0].lora_A.device
-        self.buf = torch.empty(self.total, device=dev, dtype=self.adapters[0].lora_A.dtype).bernoulli_(1.0 - p).mul_(1.0 / (1.0 - p))
+        if p > 0.0:
+            A0 = self.adapters[0].lora_A
+            if self.store is None or self.store.device != A0.device or self.store.dtype != A0.dtype or self.store.numel() != self.total:
+                self.store = torch.empty(self.total, device=A0.device, dtype=A0.dtype)
+                if self.plan is not None:
+                    self.plan.dirty = True
+            self.buf = self.store.bernoulli_(1.0 - p).mul_(1.0 / (1.0 - p))
+            self.serial = next(ops.LoraSpec._draws)
+        else:
+            self.buf = None
+        if self.plan is not None and self.adapters[0].lora_A.is_cuda and getattr(module, "compute_dtype", "bf16") != "fp32":
+            self.plan.refresh(self.mask_of, self.serial)
 
     def mask_of(self, adapter) -> Optional[torch.Tensor]:
         if self.buf is None:
