@@ -17,6 +17,8 @@ tail -1 $OUT/bench.json.log | cut -c1-400
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extras > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-extras > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-extras > $OUT/pmc_write.log 2>&1
+# BASELINE configs[2] (LoRA r16 + Muon + stochastic depth + deep SpecAugment, B = 32): kernel-trace stats of its own run
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lora_stats -- python3 bench.py --lora --muon --stochastic-depth 0.1 --deep-spec-augment --batch 32 --no-cpu-baseline --no-roofline --no-extras --steps 5 --warmup 2 > $OUT/lora_stats.log 2>&1
 python3 - <<PY
 import csv, glob, json, collections
 out = {}
