@@ -180,6 +180,14 @@ __device__ __forceinline__ s16x4 att_tr_asm(unsigned lds_byte_addr) {
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(lds_byte_addr), "n"(IMM));
   return r;
 }
+// ds_read_b128 from inline asm, same contract: hipcc sinks plain LDS loads to just in front of their first use (one LDS round
+// trip per MFMA pair in the S / dP loops); issued from asm they stay where they are written — all in one batch.
+template <int IMM>
+__device__ __forceinline__ bf16x8 att_row_asm(unsigned lds_byte_addr) {
+  bf16x8 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(lds_byte_addr), "n"(IMM));
+  return r;
+}
 __device__ __forceinline__ bf16x8 att_join(s16x4 a, s16x4 b) {
   s16x8 out;
 #pragma unroll
@@ -260,7 +268,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 // half a tile and left the kernel latency-bound (no-load experiment: +27 %).
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   __shared__ __attribute__((aligned(16))) char smem[3 * 16384];  // [slot 3][K 8K | V 8K]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: conditions on it are scalar branches, not exec masks
   const int r = lane & 31, h = lane >> 5;
   int bx, hd, b;
   att_block_coords((p.Tq + 127) >> 7, p.H, p.B, p.xcd, bx, hd, b);
@@ -479,7 +488,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnP p) {
 // ------------------------------------------------------------------------------ dQ
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
   __shared__ __attribute__((aligned(16))) char smem[32768];  // [buf 2][K 8K | V 8K]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: conditions on it are scalar branches, not exec masks
   const int r = lane & 31, h = lane >> 5;
   int bx, hd, b;
   att_block_coords((p.Tq + 127) >> 7, p.H, p.B, p.xcd, bx, hd, b);
@@ -610,7 +620,8 @@ __device__ __forceinline__ void glds4(const void* gsrc, void* lds_wave_base) {
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
   // [buf 2][Q 8K | dO 8K | lse2 256 B | delta 256 B]
   __shared__ __attribute__((aligned(16))) char smem[2 * DKDV_BUF];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: conditions on it are scalar branches, not exec masks
   const int r = lane & 31, h = lane >> 5;
   int bx, hd, b;
   att_block_coords((p.Tk + 127) >> 7, p.H, p.B, p.xcd, bx, hd, b);
@@ -639,6 +650,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
   for (int db = 0; db < 2; ++db)
 #pragma unroll
     for (int t = 0; t < 2; ++t) tra[db][t] = lds0 + offs.tr[db][t];
+  unsigned rowa[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) rowa[s] = lds0 + offs.row[s];
   const float c = p.scale * LOG2E;
   const f32x2 c2 = {c, c};
   const int nqt = (p.Tq + 63) >> 6;
@@ -685,34 +699,52 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
               qt_[ks][db][t] = att_tr_asm<CUR * DKDV_BUF + (2 * QB2 + ks) * 2048>(tra[db][t]);
             }
         });
-        f32x16 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_row_frag(q_l, offs, qb2, 0), kf[0], zero16, 0, 0, 0);
-        f32x16 pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_row_frag(do_l, offs, qb2, 0), vf[0], zero16, 0, 0, 0);
+        // all eight Q / dO row fragments of the half in one batch behind the transposed reads: ONE LDS round trip in front of
+        // the S / dP MFMAs instead of one per k-step (the reads used to be issued pairwise, each pair waited for on the spot)
+        bf16x8 aq[4], ad[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          aq[s] = att_row_asm<CUR * DKDV_BUF + QB2 * 4096>(rowa[s]);
+          ad[s] = att_row_asm<CUR * DKDV_BUF + 8192 + QB2 * 4096>(rowa[s]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[0], kf[0], zero16, 0, 0, 0);
+        f32x16 pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad[0], vf[0], zero16, 0, 0, 0);
 #pragma unroll
         for (int s = 1; s < 4; ++s) {
-          sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_row_frag(q_l, offs, qb2, s), kf[s], sacc, 0, 0, 0);
-          pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_row_frag(do_l, offs, qb2, s), vf[s], pacc, 0, 0, 0);
+          sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[s], kf[s], sacc, 0, 0, 0);
+          pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad[s], vf[s], pacc, 0, 0, 0);
         }
         f32x16 dsacc;
+        // one decision per 32-query half (wave-uniform): the unmasked body is a single basic block — its eight lse / delta
+        // reads, 32 exponentials and the packed arithmetic can be scheduled against each other
         const bool need_mask = (qq0 + 32 * qb2 + 32 > p.Tq) || (kw0 + 32 > p.Tk) || (p.causal && kw0 + 31 > qq0 + 32 * qb2);
+        f32x4 l4[4], d4[4];
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
           const int qoff = 32 * qb2 + 8 * a + 4 * h;
-          const f32x4 l4 = *(const f32x4*)(lse_l + qoff);
-          const f32x4 d4 = *(const f32x4*)(dlt_l + qoff);
-          if (need_mask) {
+          l4[a] = *(const f32x4*)(lse_l + qoff);
+          d4[a] = *(const f32x4*)(dlt_l + qoff);
+        }
+        if (need_mask) {
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const int qg = qq0 + qoff + e;
+              const int qg = qq0 + 32 * qb2 + 8 * a + 4 * h + e;
               const bool ok = qg < p.Tq && ki < p.Tk && !(p.causal && ki > qg);
-              const float pv = ok ? __builtin_amdgcn_exp2f(fmaf(sacc[4 * a + e], c, -l4[e])) : 0.f;
+              const float pv = ok ? __builtin_amdgcn_exp2f(fmaf(sacc[4 * a + e], c, -l4[a][e])) : 0.f;
               sacc[4 * a + e] = pv;
-              dsacc[4 * a + e] = ok ? pv * (pacc[4 * a + e] - d4[e]) : 0.f;
+              dsacc[4 * a + e] = ok ? pv * (pacc[4 * a + e] - d4[a][e]) : 0.f;
             }
-          } else {
+        } else {
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int e = 0; e < 4; e += 2) {  // packed fp32 pairs
               f32x2 t2 = {sacc[4 * a + e], sacc[4 * a + e + 1]};
-              const f32x2 l2 = {l4[e], l4[e + 1]}, d2 = {d4[e], d4[e + 1]};
+              const f32x2 l2 = {l4[a][e], l4[a][e + 1]}, d2 = {d4[a][e], d4[a][e + 1]};
               t2 = t2 * c2 - l2;
               const f32x2 p2 = {__builtin_amdgcn_exp2f(t2[0]), __builtin_amdgcn_exp2f(t2[1])};
               f32x2 g2 = {pacc[4 * a + e], pacc[4 * a + e + 1]};
@@ -722,7 +754,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
               dsacc[4 * a + e] = g2[0];
               dsacc[4 * a + e + 1] = g2[1];
             }
-          }
         }
         bf16x8 pf[2], dsf[2];
 #pragma unroll
