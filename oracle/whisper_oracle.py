@@ -224,15 +224,19 @@ def sinusoids(length: int, channels: int, max_timescale: float = 10000.0) -> Ten
     return torch.cat([torch.sin(scaled), torch.cos(scaled)], dim=1)
 
 
-def init_params(dims: ModelDimensions, seed: int = 0, std: float = 0.02) -> Dict[str, Tensor]:
+def init_params(dims: ModelDimensions, seed: int = 0, std: float = 0.02, device=None) -> Dict[str, Tensor]:
     """Random-init state dict with openai-whisper key names (scripts/convert_openai_to_hf.py:89-110
     is the in-tree spec of the names).  SURVEY §8d: matrices/embeddings N(0, 0.02^2), biases 0,
-    LN gamma 1 beta 0; encoder positions = sinusoids (a buffer, not trained)."""
-    g = torch.Generator().manual_seed(seed)
+    LN gamma 1 beta 0; encoder positions = sinusoids (a buffer, not trained).  `device`: where the normal draws are made
+    (default: the CPU generator every fixture was produced with; the large-v3 tests draw their 1.5e9 values on the
+    accelerator — 1 s instead of 19 — and get CPU tensors back, a different but equally seeded sample)."""
+    g = torch.Generator().manual_seed(seed) if device is None else torch.Generator(device=device).manual_seed(seed)
     sd: Dict[str, Tensor] = {}
 
     def mat(*shape):
-        return torch.randn(*shape, generator=g) * std
+        if device is None:
+            return torch.randn(*shape, generator=g) * std
+        return (torch.randn(*shape, generator=g, device=device) * std).cpu()
 
     d = dims.n_audio_state
     sd["encoder.conv1.weight"] = mat(d, dims.n_mels, 3)

@@ -352,7 +352,7 @@ def test_turbo_lora_prompt_and_timestamp_targets_match_oracle():
     Linear, a batch item with a prompt (targets -100 up to and including the prompt) and timestamp tokens in the target
     stream.  One clip, S = 48, against the fp32 oracle with the same adapters (minLoRA parametrization form)."""
     dims = O.DIMS["large-v3-turbo"]
-    params = O.init_params(dims, seed=5)
+    params = O.init_params(dims, seed=5, device=DEV)  # 8e8 normal draws: on the accelerator, CPU tensors back
     g = torch.Generator().manual_seed(11)
     audio = torch.randn(1, 480000, generator=g) * 0.1
     sot_prev, sot, lang, task, ts0 = 50362, 50258, 50261, 50360, 50365
