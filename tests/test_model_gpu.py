@@ -641,3 +641,51 @@ def test_lora_batched_refresh_is_bit_identical_to_the_per_linear_kernels():
     n_ad = 4 * 6 + 4 * 10
     assert c0[1] == {"merge": 2 * n_ad, "pack": 2 * n_ad, "mt": 0}, c0
     assert c1[0]["merge"] >= n_ad and c1[1] == {"merge": 0, "pack": 0, "mt": 2} and c1[2] == {"merge": 0, "pack": 0, "mt": 2}, c1
+
+
+def test_batched_weight_shadow_refresh_is_bit_identical_to_the_per_weight_kernel():
+    """Full fine-tune: after an optimizer step ONE launch re-casts every trainable Linear group's bf16 shadow and its transpose
+    (engine/ops.PlainRefreshPlan, the rank-0 rows of wft_lora_refresh_mt) instead of one wft_cast_pad_transpose per weight: three
+    AdamW steps give bit-identical losses and parameters with and without it, and from the second step on the per-weight kernel
+    only runs for the shapes the batched one does not take (the conv stem and the tied vocabulary matrix keep their own paths)."""
+    from whisper_finetune.engine import ops
+    from whisper_finetune.model.optimizer import WftAdamW
+    dims, params, audio, y_in, y_out = _tiny_case()
+    mel = O.log_mel_spectrogram(audio, dims.n_mels).to(DEV)
+    y_in, y_out = y_in.to(DEV), y_out.to(DEV)
+
+    def run(batched: bool):
+        m = Whisper(MODEL_DIMS["tiny"]); m.load_state_dict(params)
+        m.to(DEV).train()
+        opt = WftAdamW([p for p in m.parameters() if p.requires_grad], lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.1)
+        counts = {"cast": 0, "mt": 0}
+        real = (K.weight_shadow, K.lora_refresh_mt)
+
+        def wrap(name, f):
+            def g(*a, **k):
+                counts[name] += 1
+                return f(*a, **k)
+            return g
+
+        K.weight_shadow, K.lora_refresh_mt = wrap("cast", real[0]), wrap("mt", real[1])
+        old = ops._SHADOW_BATCH
+        ops._SHADOW_BATCH = batched
+        try:
+            losses, per_step = [], []
+            for step in range(3):
+                before = dict(counts)
+                loss = m(mel, y_in, targets=y_out, label_smoothing=0.1)
+                loss.backward()
+                opt.step(); opt.zero_grad(set_to_none=True)
+                losses.append(loss.detach().clone())
+                per_step.append({k: counts[k] - before[k] for k in counts})
+            return losses, [p.detach().clone() for p in m.parameters()], per_step
+        finally:
+            K.weight_shadow, K.lora_refresh_mt = real
+            ops._SHADOW_BATCH = old
+
+    l1, p1, c1 = run(True)
+    l0, p0, c0 = run(False)
+    assert all(torch.equal(a, b) for a, b in zip(l1, l0)) and all(torch.equal(a, b) for a, b in zip(p1, p0))
+    assert c0[1]["mt"] == 0 and c0[1]["cast"] >= 4 * 6 + 4 * 10
+    assert c1[1]["mt"] == 1 and c1[2]["mt"] == 1 and c1[1]["cast"] <= c0[1]["cast"] - (4 * 6 + 4 * 10) + 4, (c1, c0)

@@ -10,6 +10,7 @@ from __future__ import annotations
 from typing import List, Optional, Sequence, Tuple
 
 import itertools
+import weakref
 
 import os
 import torch
@@ -116,6 +117,9 @@ class LinearGroup:
                     off += w.shape[0]
             self.bias_aliased = self.bias is not None and any(b is not None and b.data_ptr() == self.bias.data_ptr() for b in biases)
             self.bkey = bkey
+        if key != self.key and lkey is None and live and _SHADOW_BATCH and _PLAIN_PLAN.epoch != _SHADOW_EPOCH[0] \
+                and id(self) in _PLAIN_PLAN.groups and self.WT is not None:
+            _PLAIN_PLAN.refresh()  # every trainable group's shadows in one launch; sets self.key if this group took part
         if key != self.key:
             n, k, npad = self.dims(weights)
             dev = weights[0].device
@@ -138,6 +142,8 @@ class LinearGroup:
             self.key = key
             if lkey is not None and None not in lkey:
                 _note_lora_group(self, weights, loras)
+            elif lkey is None and _SHADOW_BATCH and want_t and all(w.requires_grad for w in weights):
+                _PLAIN_PLAN.note(self, weights)
         return self.W, self.WT, self.bias
 
     def lora_shadows(self, weights, loras: Sequence[Optional[LoraSpec]]):
@@ -264,6 +270,96 @@ class LoraRefreshPlan:
             group.key = (wv, True, epoch, lkey)
             if packed:
                 group.lkey = lkey + (epoch,)
+
+
+class PlainRefreshPlan:
+    """The same single launch for the bf16 shadows (+ transposes) of every TRAINABLE, un-adapted Linear group of the process: after
+    an optimizer step the first group that finds its shadow stale refreshes all of them (wft_lora_refresh_mt rows with rank 0:
+    cast + transpose), instead of one wft_cast_pad_transpose launch per weight spread over the forward (513 for large-v3, 97 for
+    base).  Groups and parameters are held weakly; a group whose weights moved, or whose shapes the kernel does not take, stays on
+    the per-weight path."""
+
+    def __init__(self):
+        self.groups = {}  # id(group) -> (weakref(group), tuple(weakref(weight)))
+        self.dirty = True
+        self.epoch = None
+        self.tables = []  # [(table, tile_start, total_tiles, items, device)]; items: [(weakref(group), weights)]
+        self.ptrs = None
+        self.in_table = set()
+
+    def note(self, group: "LinearGroup", weights) -> None:
+        ent = self.groups.get(id(group))
+        if ent is None or ent[0]() is not group or len(ent[1]) != len(weights) or any(r() is not w for r, w in zip(ent[1], weights)):
+            n, k, npad = group.dims(weights)
+            if k % 64 or any(w.shape[0] % 64 or w.data_ptr() % 16 or not w.is_contiguous() or w.dtype != F32 for w in weights):
+                return
+            self.groups[id(group)] = (weakref.ref(group), tuple(weakref.ref(w) for w in weights))
+            self.dirty = True
+        elif id(group) not in self.in_table:
+            self.dirty = True  # noted before its transposed shadow existed
+
+    def _live(self):
+        out = []
+        for key, (gref, wrefs) in list(self.groups.items()):
+            g, ws = gref(), [r() for r in wrefs]
+            if g is None or any(w is None for w in ws) or g.W is None or g.WT is None:
+                if g is None or any(w is None for w in ws):
+                    del self.groups[key]
+                continue
+            out.append((g, ws))
+        return out
+
+    def _build(self) -> None:
+        by_dev = {}
+        for g, ws in self._live():
+            by_dev.setdefault(ws[0].device, []).append((g, ws))
+        self.tables, self.ptrs = [], []
+        self.in_table = {id(g) for items in by_dev.values() for g, _ in items}
+        for dev, items in by_dev.items():
+            rows, tiles = [], [0]
+            for g, ws in items:
+                n, k, npad = g.dims(ws)
+                off = 0
+                for w in ws:
+                    o = w.shape[0]
+                    rows.append([w.data_ptr(), o, k, 0, 0, 0, 0, 0, g.W.data_ptr() + 2 * off * g.W.stride(0), g.WT.data_ptr() + 2 * off,
+                                 g.W.stride(0), g.WT.stride(0), 0, 0, 0, 0, 0, npad, 0, off])
+                    tiles.append(tiles[-1] + (o // 64) * (k // 64))
+                    self.ptrs.append(w.data_ptr())
+                    off += o
+            self.tables.append((torch.tensor(rows, dtype=torch.int64).to(dev), torch.tensor(tiles, dtype=torch.int32).to(dev),
+                                tiles[-1], [(weakref.ref(g), ws) for g, ws in items], dev))
+        self.dirty = False
+
+    def refresh(self) -> None:
+        epoch = _SHADOW_EPOCH[0]
+        self.epoch = epoch
+        for attempt in range(2):
+            if self.dirty:
+                self._build()
+            cur, ok = [], True
+            for table, tile_start, total, items, dev in self.tables:
+                for gref, ws in items:
+                    g = gref()
+                    ok = ok and g is not None and g.W is not None and g.WT is not None
+                    cur.extend(w.data_ptr() for w in ws)
+            if ok and cur == self.ptrs:
+                break
+            self.dirty = True
+        else:
+            return
+        for table, tile_start, total, items, dev in self.tables:
+            with torch.cuda.device(dev):
+                K.lora_refresh_mt(table, tile_start, table.shape[0], total)
+            for gref, ws in items:
+                g = gref()
+                # only groups whose every weight is trainable were noted: `live` in shadows() is True for them
+                g.key = (tuple(_ver(w) for w in ws), True, epoch, None)
+
+
+_PLAIN_PLAN = PlainRefreshPlan()
+# WFT_SHADOW_BATCH=0: one cast/transpose launch per weight (A/B runs)
+_SHADOW_BATCH = os.environ.get("WFT_SHADOW_BATCH", "1") != "0"
 
 
 def _note_lora_group(group: "LinearGroup", weights, loras) -> None:
