@@ -27,9 +27,11 @@ t0 = time.perf_counter()
 for _ in range(10):
     train_step(case.net, it, case.opt, case.sched, case.t_cfg)
 torch.cuda.synchronize(); print(f"wall {1e3 * (time.perf_counter() - t0) / 10:.2f} ms/step")
-pr = cProfile.Profile(); pr.enable()
-for _ in range(10):
-    train_step(case.net, it, case.opt, case.sched, case.t_cfg)
-torch.cuda.synchronize()
-pr.disable()
+pr = cProfile.Profile()
+with torch.autograd.set_multithreading_enabled(False):  # the backward pass on this thread: visible to cProfile
+    pr.enable()
+    for _ in range(10):
+        train_step(case.net, it, case.opt, case.sched, case.t_cfg)
+    torch.cuda.synchronize()
+    pr.disable()
 st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(28)

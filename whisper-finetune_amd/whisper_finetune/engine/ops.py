@@ -257,7 +257,8 @@ class LoraRefreshPlan:
                 vers.append((wv, av))
                 for x, (ya, yb) in zip(wv, av):
                     cur.extend((x[0], ya[0], yb[0]))
-            stale = cur != self.ptrs or any(g.W is None or g.WT is None or (pk and g.Am is None) for g, _, _, pk in self.items)
+            stale = cur != self.ptrs or any(g.W is None or g.WT is None or (pk and g.Am is None) or not all(a.enabled for a in ads)
+                                            for g, _, ads, pk in self.items)
             if not stale:
                 break
             self.dirty = True  # a parameter or a shadow buffer moved: rebuild the table once
@@ -302,8 +303,9 @@ class PlainRefreshPlan:
         out = []
         for key, (gref, wrefs) in list(self.groups.items()):
             g, ws = gref(), [r() for r in wrefs]
-            if g is None or any(w is None for w in ws) or g.W is None or g.WT is None:
-                if g is None or any(w is None for w in ws):
+            gone = g is None or any(w is None for w in ws) or not all(w.requires_grad for w in ws)  # dropped, or frozen since
+            if gone or g.W is None or g.WT is None:
+                if gone:
                     del self.groups[key]
                 continue
             out.append((g, ws))
@@ -341,7 +343,7 @@ class PlainRefreshPlan:
             for table, tile_start, total, items, dev in self.tables:
                 for gref, ws in items:
                     g = gref()
-                    ok = ok and g is not None and g.W is not None and g.WT is not None
+                    ok = ok and g is not None and g.W is not None and g.WT is not None and all(w.requires_grad for w in ws)
                     cur.extend(w.data_ptr() for w in ws)
             if ok and cur == self.ptrs:
                 break
