@@ -1220,7 +1220,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmP p) {
 // factor, and the transposed block-diagonal output.
 __global__ __launch_bounds__(256) void tn_splitk_reduce_kernel(const float* ws, float* C, long ldc, int P, int Q, int nsplit,
                                                                 int accumulate, int Pz, const float* col_scale, int scale_rows,
-                                                                int blk_n, int blk_r) {
+                                                                int blk_n, int blk_r, int Pv) {
   const long nq4 = Q >> 2;
   const long total = (long)(Pz > P ? Pz : P) * nq4;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -1246,7 +1246,8 @@ __global__ __launch_bounds__(256) void tn_splitk_reduce_kernel(const float* ws, 
       *(f32x4*)cp = s;
       continue;
     }
-    if (col_scale) s *= *(const f32x4*)(col_scale + (scale_rows > 0 ? pp / scale_rows : 0) * Q + q4);
+    // rows >= Pv (p_valid rounded up to 16 leaves up to 15 of them) are sums of zeros and have no scale row
+    if (col_scale && pp < Pv) s *= *(const f32x4*)(col_scale + (scale_rows > 0 ? pp / scale_rows : 0) * Q + q4);
     if (ob) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) ob[(long)e * blk_r] = accumulate ? ob[(long)e * blk_r] + s[e] : s[e];
@@ -1520,7 +1521,7 @@ extern "C" int wft_gemm_tn_bf16(const wft_gemm_args* a, void* stream) {
       long g = (total + 255) / 256;
       if (g > 2048) g = 2048;
       hipLaunchKernelGGL(tn_splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, (const float*)a->workspace, (float*)a->C,
-                         (long)a->ldc, (int)a->M, (int)a->N, nsplit, a->accumulate, (int)a->M, (const float*)nullptr, 0, 0, 0);
+                         (long)a->ldc, (int)a->M, (int)a->N, nsplit, a->accumulate, (int)a->M, (const float*)nullptr, 0, 0, 0, (int)a->M);
     }
     WFT_CHECK_LAUNCH();
     return WFT_OK;
@@ -1565,7 +1566,7 @@ extern "C" int wft_gemm_tn_bf16(const wft_gemm_args* a, void* stream) {
     if (g > 2048) g = 2048;
     hipLaunchKernelGGL(tn_splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, (const float*)a->workspace, (float*)a->C,
                        (long)a->ldc, (int)tn_ws_rows(a), (int)a->N, nsplit, a->accumulate, (int)a->M, a->tn_col_scale,
-                       a->tn_scale_rows, a->tn_block_n, a->tn_block_r);
+                       a->tn_scale_rows, a->tn_block_n, a->tn_block_r, pb > 0 ? a->p_valid : (int)a->M);
   }
   WFT_CHECK_LAUNCH();
   return WFT_OK;
