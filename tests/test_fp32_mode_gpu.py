@@ -152,6 +152,7 @@ def test_fp32_mode_with_lora_stochastic_depth_and_deep_specaug():
     m.encoder = CheckpointedStochasticAudioEncoder(dims.n_mels, dims.n_audio_ctx, dims.n_audio_state, dims.n_audio_head, dims.n_audio_layer, 0.3)
     m.decoder = CheckpointedStochasticTextDecoder(dims.n_vocab, dims.n_text_ctx, dims.n_text_state, dims.n_text_head, dims.n_text_layer, 0.3)
     m.load_state_dict(params)
+    torch.manual_seed(31)  # lora_A's kaiming init draws from the global generator: the same adapters in every run
     lora_mod.apply_lora(m, {"rank": 8, "lora_alpha": 16, "lora_dropout": 0.25})
     g = torch.Generator().manual_seed(9)
     cfg, adapters = {}, {}

@@ -151,6 +151,7 @@ def test_large_v3_lora_muon_config_step_matches_oracle():
     m.decoder = CheckpointedStochasticTextDecoder(dims.n_vocab, dims.n_text_ctx, dims.n_text_state, dims.n_text_head,
                                                   dims.n_text_layer, t_cfg["stochastic_depth"])
     m.load_state_dict(params)
+    torch.manual_seed(17)  # lora_A's kaiming init draws from the global generator: the same adapters in every run
     lora_mod.apply_lora(m, {"rank": r, "lora_alpha": alpha, "lora_dropout": p_drop})
     g = torch.Generator().manual_seed(23)
     adapters = {}
