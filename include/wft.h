@@ -171,7 +171,11 @@ typedef struct {
    * operand in its 128-wide padded buffer).  Selects the load-stream kernel for rank-r operands: only the first
    * 16*ceil(p_valid/16) columns of A are read, the split-K workspace holds only those rows (wft_gemm_tn_workspace_bytes
    * accounts for it), rows >= 16*ceil(p_valid/16) of C are written as zero (left alone when accumulating).  Results are
-   * bit-identical to p_valid = 0. */
+   * bit-identical to p_valid = 0.
+   * wft_gemm_nt_bf16 (N = 128, bf16 C, batch 1, no bias / residual / epilogue): rows >= p_valid of B are zero padding (the
+   * other two adapter products, u = x (sA*mask)^T and du = dy (sB)): only rows < 16*ceil(p_valid/16) of B are read and ONLY
+   * those columns of C are written — the rest of the 128-wide buffer is left as it was (its consumer is the call above with the
+   * same p_valid); bit-identical to p_valid = 0 in the written columns. */
   int p_valid;
   /* wft_gemm_nt_bf16 only: if != NULL (bf16 C, batch == 1), colsum[n] = sum over rows of the C just written — the bias
    * gradient of the Linear that consumes C as its dy (C = d(pre-activation) from the DGELU epilogue).  With `workspace`

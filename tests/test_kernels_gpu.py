@@ -502,3 +502,22 @@ def test_gemm_tn_adapter_gradient_outputs(R, Q, nb, r):
     assert torch.equal(acc, base + blocks)
     with pytest.raises(Exception):
         K.gemm_tn(a, b, col_scale=scale)  # only for rank-r operands
+
+
+@pytest.mark.parametrize("M,Kd,rc", [(48000, 1280, 16), (4096, 5120, 48), (3001, 384, 64), (100, 128, 32), (1, 64, 16)])
+def test_gemm_nt_p_valid_writes_only_the_rank_columns(M, Kd, rc):
+    """u = x (sA*mask)^T / du = dy (sB): the rank-r operand sits in the first rows of a 128-row zero-padded buffer; p_valid selects the
+    load-stream kernel (gemm_nt_rank_kernel), which gives exactly the 128-tile kernel's values in the 16*ceil(p_valid/16) data
+    columns and leaves the other columns of the output buffer untouched; ragged M, one k-step, one row."""
+    g = torch.Generator().manual_seed(M + rc)
+    b = torch.zeros(128, Kd)
+    b[:rc - 3] = torch.randn(rc - 3, Kd, generator=g)
+    b = bf(b).to(DEV)
+    a = bf(torch.randn(M, Kd, generator=g)).to(DEV)
+    full = K.gemm_nt(a, b)
+    out = torch.full((M, 128), 7.0, dtype=torch.bfloat16, device=DEV)
+    K.gemm_nt(a, b, out=out, p_valid=rc)
+    nc = 16 * ((rc + 15) // 16)
+    assert torch.equal(out[:, :nc], full[:, :nc])
+    assert (out[:, nc:] == 7.0).all()
+    close(out[:, :nc].float(), (a.float() @ b.float().t())[:, :nc], 1e-2)

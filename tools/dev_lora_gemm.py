@@ -15,7 +15,7 @@ for Kd in (1280, 5120):
     x = torch.randn(M, Kd, device=dev).to(torch.bfloat16)
     a = torch.zeros(128, Kd, device=dev).to(torch.bfloat16); a[:16] = torch.randn(16, Kd, device=dev).to(torch.bfloat16)
     du = torch.zeros(M, 128, device=dev).to(torch.bfloat16); du[:, :16] = torch.randn(M, 16, device=dev).to(torch.bfloat16)
-    t0 = bench(lambda: K.gemm_nt(x, a))
-    print(f"u = x[{M}x{Kd}] @ Am^T: tile128 {t0:6.1f} us ({M*Kd*2/t0/1e6:.2f} TB/s)")
+    t0 = bench(lambda: K.gemm_nt(x, a)); t1 = bench(lambda: K.gemm_nt(x, a, p_valid=16))
+    print(f"u = x[{M}x{Kd}] @ Am^T: tile128 {t0:6.1f} us | p_valid {t1:6.1f} us ({M*Kd*2/t1/1e6:.2f} TB/s)")
     t0 = bench(lambda: K.gemm_tn(du, x)); t1 = bench(lambda: K.gemm_tn(du, x, p_valid=16))
     print(f"dA = du^T @ x[{M}x{Kd}]: tile128 {t0:6.1f} us | p_valid {t1:6.1f} us ({M*Kd*2/t1/1e6:.2f} TB/s)")

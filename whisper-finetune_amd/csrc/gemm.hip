@@ -806,6 +806,133 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmP p) {
   }
 }
 
+template <int V>
+struct RankIntC { static constexpr int value = V; };
+template <int N, class F>
+__device__ __forceinline__ void static_for_rank(F&& f) {
+  if constexpr (N > 0) {
+    static_for_rank<N - 1>(f);
+    f(RankIntC<N - 1>{});
+  }
+}
+// ---------------------------------------------------------------------------------- NT, rank-r B operand
+// The other two LoRA adapter products, u = x (s A*mask)^T and du = dy (s B): C[M, 16 PB] = A[M, K] B[16 PB, K]^T with B a rank-r
+// operand in the first rows of a 128-row zero-padded buffer.  HBM-bound on A (the activation, read once): the 128-tile
+// kernel spends half of its loads in flight on B's zero rows and drains its one-deep prefetch at every __syncthreads; here a
+// workgroup streams 128 rows of A through a ring of NST stages {A [128][64 k] 16 KB, B [16 PB][64 k] 2 PB KB} (counted vmcnt,
+// plain s_barrier, inline-asm fragment reads) and writes only the 16 PB data columns of the 128-wide C buffer — its consumer,
+// gemm_tn_rank_kernel, reads no others.  Same products in the same order as gemm_nt_kernel: bit-identical in those columns.
+template <int IMM>
+__device__ __forceinline__ bf16x8 lds_b128_asm(unsigned lds_byte_addr) {
+  bf16x8 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(lds_byte_addr), "n"(IMM));
+  return r;
+}
+template <int PB>
+__global__ __launch_bounds__(256, 2) void gemm_nt_rank_kernel(GemmP p) {
+  constexpr int NST = PB <= 2 ? 4 : 3;
+  constexpr int BBYTES = 2048 * PB;
+  constexpr int SBYTES = 16384 + BBYTES;  // stage = A part, then B part
+  constexpr int NBI = (2 * PB + 3) / 4;   // B staging instructions per wave and stage (surplus ones repeat a piece)
+  constexpr int LPS = 4 + NBI;
+  extern __shared__ __attribute__((aligned(16))) char dsmem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.x << 7;
+  const int lr = lane >> 3, lc = lane & 7;
+  // per-lane source pointers of the staging instructions (row of the piece, swizzled 16-byte chunk), advanced by 64 k per step
+  const unsigned short* asrc[4];
+  const unsigned short* bsrc[NBI];
+  int bpiece[NBI];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int gm = m0 + (wave * 4 + j) * 8 + lr;
+    gm = gm < p.M ? gm : p.M - 1;
+    asrc[j] = p.A + (long)gm * p.lda + ((lc ^ lr) << 3);
+  }
+#pragma unroll
+  for (int k = 0; k < NBI; ++k) {
+    bpiece[k] = (wave + 4 * k) % (2 * PB);
+    bsrc[k] = p.B + (long)(bpiece[k] * 8 + lr) * p.ldb + ((lc ^ lr) << 3);
+  }
+  int ld_slot = 0, ld_k = 0;
+  auto stage = [&]() {
+    char* sbase = dsmem + ld_slot * SBYTES;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) glds16(asrc[j] + ld_k * 64, sbase + (wave * 4 + j) * 1024);
+#pragma unroll
+    for (int k = 0; k < NBI; ++k) glds16(bsrc[k] + ld_k * 64, sbase + 16384 + bpiece[k] * 1024);
+    ++ld_k;
+    if (++ld_slot == NST) ld_slot = 0;
+  };
+
+  f32x4 acc[2][PB];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < PB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fg = lane >> 4, sw = lane & 7;
+  const unsigned lds0 = lds_addr_of(dsmem);
+  // fragment addresses inside a stage for the k half s = 0; s = 1 flips chunk bit 2 (an XOR, so not an immediate: two bases)
+  unsigned aoff[2][2], boff[2];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    const unsigned coff = (unsigned)(((s2 * 4 + fg) ^ sw) << 4);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) aoff[s2][i] = (unsigned)((wave * 32 + i * 16 + frow) * 128) + coff;
+    boff[s2] = 16384u + (unsigned)(frow * 128) + coff;
+  }
+
+  const int nk = p.K >> 6;
+#pragma unroll
+  for (int u = 0; u < NST - 1; ++u)
+    if (u < nk) stage();
+  int rd_slot = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int ahead = nk - 1 - kt;
+    if (ahead >= NST - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * LPS) : "memory");
+    else if (NST == 4 && ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + NST - 1 < nk) stage();
+    const unsigned sb = lds0 + rd_slot * SBYTES;
+    bf16x8 af[2][2], bfr[2][PB];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[s2][i] = lds_b128_asm<0>(sb + aoff[s2][i]);
+      static_for_rank<PB>([&](auto jt) {
+        constexpr int j = decltype(jt)::value;
+        bfr[s2][j] = lds_b128_asm<j * 2048>(sb + boff[s2]);
+      });
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < PB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[s2][j], af[s2][i], acc[i][j], 0, 0, 0);
+    if (++rd_slot == NST) rd_slot = 0;
+  }
+
+  // lane holds C[m = 16 i + frow][n = 16 j + 4 fg + e] of the wave's 32 rows
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + wave * 32 + i * 16 + frow;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+      const f32x4 v = acc[i][j] * p.alpha;
+      const u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+      *(u32x2*)((unsigned short*)p.C + (long)m * p.ldc + j * 16 + fg * 4) = pk;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------- TN, rank-r A operand
 // The two LoRA adapter gradients dA = du^T x and dB^T = u^T dy: A is a rank-r operand (du / u, [R, lda]) whose data sits in the
 // first 16*PB columns of a 128-wide zero-padded buffer, B the [R, Q] activation stream.  HBM-bound on B (2 bytes per element
@@ -1401,6 +1528,30 @@ extern "C" int wft_gemm_nt_bf16(const wft_gemm_args* a, void* stream) {
                          (int)(2 * ((a->M + 255) / 256)), (int)a->N, a->colsum);
     WFT_CHECK_LAUNCH();
     if (a->colsum && !cs_fused) return wft_colsum_bf16((const wft_bf16*)a->C, a->M, a->N, a->ldc, a->colsum, 0, stream);
+    return WFT_OK;
+  }
+  // p_valid: B is a rank-r operand in the first rows of a 128-row zero-padded buffer (u = x (sA*mask)^T, du = dy (sB)): the
+  // load-stream kernel, which writes only the data columns of C (WFT_GEMM_DIAG=9: the 128-tile kernel, A/B runs)
+  const int npb = (!a->c_is_f32 && a->N == 128 && a->batch == 1 && a->p_valid > 0 && a->p_valid <= 64 && a->epilogue == WFT_EPI_NONE &&
+                   !a->bias && !a->residual && !a->aux && !a->colsum && a->valid_rows_period == 0 && g_diag != 9)
+                      ? (a->p_valid + 15) / 16 : 0;
+  if (npb) {
+    const dim3 g1((unsigned)((a->M + 127) / 128));
+#define WFT_NT_RANK_LAUNCH(PBV)                                                                   \
+  {                                                                                               \
+    constexpr int nst = (PBV) <= 2 ? 4 : 3;                                                       \
+    constexpr int bytes = nst * (16384 + 2048 * (PBV));                                           \
+    static DynLdsOnce once;                                                                       \
+    auto kfn = gemm_nt_rank_kernel<PBV>;                                                          \
+    once.set(kfn, bytes);                                                                         \
+    hipLaunchKernelGGL(kfn, g1, dim3(256), bytes, s, p);                                          \
+  }
+    if (npb == 1) WFT_NT_RANK_LAUNCH(1)
+    else if (npb == 2) WFT_NT_RANK_LAUNCH(2)
+    else if (npb == 3) WFT_NT_RANK_LAUNCH(3)
+    else WFT_NT_RANK_LAUNCH(4)
+#undef WFT_NT_RANK_LAUNCH
+    WFT_CHECK_LAUNCH();
     return WFT_OK;
   }
   const long tiles = ((a->M + 127) / 128) * (a->N / 128);

@@ -207,11 +207,14 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, mask=None, want_colsum=Fa
 def gemm_nt(a, b, *, M=None, N=None, K=None, lda=None, ldb=None, out=None, out_f32=False, accumulate=False,
             bias=None, residual=None, aux=None, epilogue=L.EPI_NONE, alpha=1.0, batch=1,
             strideA=0, strideB=0, strideC=0, strideR=0, strideAux=0, ldc=None,
-            valid_rows_period=0, valid_rows=0, residual_first=False, ldaux=None, ldr=None, beta=1.0, colsum=None):
+            valid_rows_period=0, valid_rows=0, residual_first=False, ldaux=None, ldr=None, beta=1.0, colsum=None, p_valid=0):
     """C[M,N] = alpha * A[M,K] @ B[N,K]^T (+bias) (epilogue) (+residual).
 
     a: bf16, row m at a.data_ptr() + m*lda; b: bf16 [N, K] (ldb).  Defaults take the shapes
     from 2-D contiguous tensors.  `aux`: GELU pre-activation out (EPI_GELU) / in (EPI_DGELU); gelu' out (EPI_GELU_GRAD) / in (EPI_MUL_AUX).
+    p_valid (N = 128, plain bf16 product): rows >= p_valid of b are zero padding (a rank-r LoRA operand) — the load-stream
+    kernel for rank-r operands, which writes ONLY columns < 16*ceil(p_valid/16) of the output (the rest stays uninitialised:
+    the consumer is gemm_tn with the same p_valid).
     """
     _chk(a, BF16, "A"); _chk(b, BF16, "B")
     if M is None:
@@ -247,6 +250,7 @@ def gemm_nt(a, b, *, M=None, N=None, K=None, lda=None, ldb=None, out=None, out_f
     args.M, args.N, args.K, args.batch = M, N, K, batch
     args.valid_rows_period, args.valid_rows = valid_rows_period, valid_rows
     args.residual_first = int(residual_first)
+    args.p_valid = int(p_valid)
     if colsum is not None:  # f32 [N]: column sums of C (bias gradient of C's consumer), fused into the epilogue when possible
         _chk(colsum, F32, "colsum")
         args.colsum = colsum.data_ptr()

@@ -513,18 +513,18 @@ class LinearFn(torch.autograd.Function):
                      and npad == n and all(s.A.shape[0] == r0 for s in specs) and all(w.shape[0] == n0 for w in weights)
                      and all((s.mask is None) == (specs[0].mask is None) for s in specs))
             if fused:
-                du = K.gemm_nt(dy, BbT)                       # [M, Rpad] = dy @ (s*B)
+                du = K.gemm_nt(dy, BbT, p_valid=pv)                      # [M, Rpad] = dy @ (s*B)
                 dA_full = K.gemm_tn(du, x, p_valid=pv, col_scale=_stacked_masks(specs), scale_rows=r0 if n_w > 1 else 0)
-                u = K.gemm_nt(x, Am)                          # [M, Rpad] = x @ (s*A*mask)^T (carries the scaling: wft_lora_pack)
+                u = K.gemm_nt(x, Am, p_valid=pv)                       # [M, Rpad] = x @ (s*A*mask)^T (carries the scaling: wft_lora_pack)
                 dB_blocks = K.gemm_tn(u, dy, p_valid=pv, block_n=n0, block_r=r0)
                 out.extend(dA_full[i * r0:(i + 1) * r0] for i in range(n_w))
                 out.extend(dB_blocks[i * n0 * r0:(i + 1) * n0 * r0].view(n0, r0) for i in range(n_w))
                 return tuple(out)
             if any(a_need):
-                du = K.gemm_nt(dy, BbT)                       # [M, Rpad] = dy @ (s*B)
+                du = K.gemm_nt(dy, BbT, p_valid=pv)                      # [M, Rpad] = dy @ (s*B)
                 dA_full = K.gemm_tn(du, x, p_valid=pv)        # [Rpad, Kpad]
             if any(b2_need):
-                u = K.gemm_nt(x, Am)                          # [M, Rpad] = x @ (s*A*mask)^T, recomputed here, not saved by the forward
+                u = K.gemm_nt(x, Am, p_valid=pv)                       # [M, Rpad] = x @ (s*A*mask)^T, recomputed here, not saved by the forward
                 # rank-r operand first (its zero-padded columns are skipped): [Rpad, Npad], read through its transpose
                 dB_full = K.gemm_tn(u, dy, p_valid=pv).t()    # [Npad, Rpad]
             dAs, dBs = [], []
