@@ -521,3 +521,26 @@ def test_gemm_nt_p_valid_writes_only_the_rank_columns(M, Kd, rc):
     assert torch.equal(out[:, :nc], full[:, :nc])
     assert (out[:, nc:] == 7.0).all()
     close(out[:, :nc].float(), (a.float() @ b.float().t())[:, :nc], 1e-2)
+
+
+def test_rank_kernels_random_shapes():
+    """The two load-stream kernels for rank-r LoRA operands against the 128-tile kernels on 40 seeded random shapes each: every
+    rank 1..64, reduction / row counts that are not multiples of the tile, k extents of one to 40 steps — bit-identical."""
+    rng = np.random.RandomState(1234)
+    for _ in range(40):
+        M, Kd, rc = int(rng.randint(1, 4000)), 64 * int(rng.randint(1, 41)), int(rng.randint(1, 65))
+        g = torch.Generator().manual_seed(M * 7 + rc)
+        b = torch.zeros(128, Kd)
+        b[:rc] = torch.randn(rc, Kd, generator=g)
+        a, b = bf(torch.randn(M, Kd, generator=g)).to(DEV), bf(b).to(DEV)
+        nc = 16 * ((rc + 15) // 16)
+        out = torch.full((M, 128), -3.0, dtype=torch.bfloat16, device=DEV)
+        K.gemm_nt(a, b, out=out, p_valid=rc)
+        assert torch.equal(out[:, :nc], K.gemm_nt(a, b)[:, :nc]) and (out[:, nc:] == -3.0).all(), (M, Kd, rc)
+    for _ in range(40):
+        R, Q, rc = int(rng.randint(1, 6000)), 128 * int(rng.randint(1, 9)), int(rng.randint(1, 65))
+        g = torch.Generator().manual_seed(R * 5 + rc)
+        a = torch.zeros(R, 128)
+        a[:, :rc] = torch.randn(R, rc, generator=g)
+        a, b = bf(a).to(DEV), bf(torch.randn(R, Q, generator=g)).to(DEV)
+        assert torch.equal(K.gemm_tn(a, b, p_valid=rc), K.gemm_tn(a, b)), (R, Q, rc)
