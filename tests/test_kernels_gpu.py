@@ -474,7 +474,7 @@ def test_gemm_tn_p_valid_skips_only_zero_columns(R, Q, rc):
 
 
 @pytest.mark.parametrize("R,Q,nb,r", [(48000, 1280, 1, 16), (5000, 3840, 3, 16), (449, 256, 2, 8), (100, 128, 1, 16), (3001, 2560, 2, 32),
-                                      (2000, 384, 3, 8)])
+                                      (2000, 384, 3, 8), (1000, 384, 3, 5), (777, 256, 2, 24), (64, 128, 1, 1)])
 def test_gemm_tn_adapter_gradient_outputs(R, Q, nb, r):
     """The two output forms of the rank-r weight-gradient GEMM that finish the LoRA adapter gradients inside the split-K reduce
     (wft.h tn_col_scale / tn_block_n): dA = (du^T x) * mask with one mask row per adapter of the group, and dB as per-adapter
