@@ -122,6 +122,16 @@ def test_gemm_nt_persistent_epilogues_counted_waits(M, N, Kd):
         close(first, want, 1e-2, name)
         for _ in range(3):
             assert torch.equal(fn(), first), f"{name}: not reproducible"
+    # fused column sums across full row tiles (register body) AND the ragged last one (direct body): every row counted once
+    for epi, kw in ((L.EPI_MUL_AUX, dict(aux=aux)), (L.EPI_NONE, dict(residual=res)), (L.EPI_NONE, dict())):
+        cs = torch.full((N,), 7.0, device=DEV)
+        c = K.gemm_nt(a, b, epilogue=epi, colsum=cs, **kw)
+        want_cs = c.double().sum(0)
+        scale = c.double().abs().sum(0).max()
+        assert (cs.double() - want_cs).abs().max() < 2e-3 * scale, "fused column sums"  # (sums of the un-rounded fp32 values)
+        cs2 = torch.empty(N, device=DEV)
+        K.gemm_nt(a, b, epilogue=epi, colsum=cs2, **kw)
+        assert torch.equal(cs, cs2), "column sums not reproducible"
 
 
 def test_gemm_nt_rejects_bad_shapes():
