@@ -183,6 +183,12 @@ __device__ __forceinline__ s16x4 att_tr_asm(unsigned lds_byte_addr) {
 // ds_read_b128 from inline asm, same contract: hipcc sinks plain LDS loads to just in front of their first use (one LDS round
 // trip per MFMA pair in the S / dP loops); issued from asm they stay where they are written — all in one batch.
 template <int IMM>
+__device__ __forceinline__ f32x4 att_f4_asm(unsigned lds_byte_addr) {
+  f32x4 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(lds_byte_addr), "n"(IMM));
+  return r;
+}
+template <int IMM>
 __device__ __forceinline__ bf16x8 att_row_asm(unsigned lds_byte_addr) {
   bf16x8 r;
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(lds_byte_addr), "n"(IMM));
@@ -480,8 +486,10 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnP p) {
   if (q < p.Tq) {
     const long sidx = ((long)b * p.H + hd) * p.Tq + q;
     const long total = (long)p.B * p.Tq * p.H;
-    p.delta[sidx] = mine;
-    p.delta[total + sidx] = p.lse[sidx] * LOG2E;  // second half of the workspace: lse in log2 units, staged by LDS-DMA in dK/dV
+    // NEGATED, so that both row constants enter the backward kernels' S and dP MFMA chains as their initial accumulators
+    // (S' = S - lse / scale, so exp2(c S') = exp(scale S - lse) needs no subtraction; dP' = dP - delta)
+    p.delta[sidx] = -mine;
+    p.delta[total + sidx] = -p.lse[sidx] / p.scale;
   }
 }
 
@@ -510,8 +518,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
   const AttOffs offs = att_offsets(lane);
   const AttStage stK = att_stage_init(p.ldk, wave, lane), stV = att_stage_init(p.ldv, wave, lane);
   const long sidx = ((long)b * p.H + hd) * p.Tq + qc;
-  const float lse2 = p.lse[sidx] * LOG2E;
-  const float dlt = p.delta[sidx];
+  // row constants of this lane's query (written negated by attn_delta_kernel): the initial accumulators of the S and dP chains
+  const float nlse = p.delta[(long)p.B * p.H * p.Tq + sidx];  // -lse / scale
+  const float ndlt = p.delta[sidx];                            // -rowsum(dO * O)
 
   int nkt = (p.Tk + 63) >> 6;
   if (p.causal) {
@@ -523,6 +532,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
   f32x16 dqacc[2];
   dqacc[0] = zero16;
   dqacc[1] = zero16;
+  f32x16 sinit, pinit;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { sinit[e] = nlse; pinit[e] = ndlt; }
 
   att_stage2(stK, kb, p.ldk, smem, stV, vb, p.ldv, smem + 8192, 0, p.Tk, wave, lane);
   __syncthreads();
@@ -540,8 +552,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
       f32x16 sacc[2], pacc[2];
 #pragma unroll
       for (int kb2 = 0; kb2 < 2; ++kb2) {
-        sacc[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_row_frag(kt_l, offs, kb2, 0), qf[0], zero16, 0, 0, 0);
-        pacc[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_row_frag(vt_l, offs, kb2, 0), dof[0], zero16, 0, 0, 0);
+        sacc[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_row_frag(kt_l, offs, kb2, 0), qf[0], sinit, 0, 0, 0);
+        pacc[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_row_frag(vt_l, offs, kb2, 0), dof[0], pinit, 0, 0, 0);
 #pragma unroll
         for (int s = 1; s < 4; ++s) {
           sacc[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_row_frag(kt_l, offs, kb2, s), qf[s], sacc[kb2], 0, 0, 0);
@@ -555,21 +567,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const bool ok = (32 * kb2 + (e & 3) + 8 * (e >> 2)) < lim;
-            const float pv = ok ? __builtin_amdgcn_exp2f(fmaf(sacc[kb2][e], c, -lse2)) : 0.f;
-            sacc[kb2][e] = pv * (pacc[kb2][e] - dlt);
+            const float pv = ok ? __builtin_amdgcn_exp2f(sacc[kb2][e] * c) : 0.f;
+            sacc[kb2][e] = pv * pacc[kb2][e];
           }
       } else {
-        // packed fp32 (v_pk_fma / v_pk_add / v_pk_mul): half the VALU issue slots of the scalar form
-        const f32x2 c2 = {c, c}, l2 = {lse2, lse2}, d2 = {dlt, dlt};
+        // packed fp32 (v_pk_mul): two elements per VALU issue slot; the subtractions of lse and delta happened in the MFMAs
+        const f32x2 c2 = {c, c};
 #pragma unroll
         for (int kb2 = 0; kb2 < 2; ++kb2)
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             f32x2 t2 = {sacc[kb2][2 * e], sacc[kb2][2 * e + 1]};
-            t2 = t2 * c2 - l2;
+            t2 = t2 * c2;
             const f32x2 p2 = {__builtin_amdgcn_exp2f(t2[0]), __builtin_amdgcn_exp2f(t2[1])};
             f32x2 g2 = {pacc[kb2][2 * e], pacc[kb2][2 * e + 1]};
-            g2 = (g2 - d2) * p2;  // dS^T (unscaled)
+            g2 = g2 * p2;  // dS^T (unscaled)
             sacc[kb2][2 * e] = g2[0];
             sacc[kb2][2 * e + 1] = g2[1];
           }
@@ -635,7 +647,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
   const unsigned short* dob = p.d_o + (long)b * p.do_bs + hd * 64;
   const long sbase = ((long)b * p.H + hd) * p.Tq;
   const float* dlt_b = p.delta + sbase;
-  const float* lse_b = p.delta + (long)p.B * p.H * p.Tq + sbase;  // lse * log2(e), written by attn_delta_kernel
+  const float* lse_b = p.delta + (long)p.B * p.H * p.Tq + sbase;  // -lse / scale, written (like -delta) by attn_delta_kernel
   bf16x8 kf[4], vf[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
@@ -653,6 +665,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
   unsigned rowa[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) rowa[s] = lds0 + offs.row[s];
+  const unsigned rca = lds0 + 16384 + 16 * h;  // this lane's first row constant: query 4 h of a 32-query half (+ 32 a via immediates)
   const float c = p.scale * LOG2E;
   const f32x2 c2 = {c, c};
   const int nqt = (p.Tq + 63) >> 6;
@@ -681,8 +694,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
     if (qt + 1 < nqt) stage_q(smem + (CUR ^ 1) * DKDV_BUF, qt + 1);
     const char* q_l = smem + CUR * DKDV_BUF;
     const char* do_l = q_l + 8192;
-    const float* lse_l = (const float*)(q_l + 16384);
-    const float* dlt_l = lse_l + 64;
     if (!(p.causal && kw0 > qq0 + 63)) {
       static_for<2>([&](auto qb_tag) {
         constexpr int QB2 = decltype(qb_tag)::value;
@@ -707,10 +718,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
           aq[s] = att_row_asm<CUR * DKDV_BUF + QB2 * 4096>(rowa[s]);
           ad[s] = att_row_asm<CUR * DKDV_BUF + 8192 + QB2 * 4096>(rowa[s]);
         }
+        // the half's row constants -lse / scale and -delta: the 16 values a lane needs (queries 8 a + 4 h + e) are laid out
+        // exactly like the f32x16 C operand, so they ARE the initial accumulators of the S and dP chains (no VALU at all)
+        f32x4 l4[4], d4[4];
+        static_for<4>([&](auto a_tag) {
+          constexpr int a = decltype(a_tag)::value;
+          l4[a] = att_f4_asm<CUR * DKDV_BUF + 128 * QB2 + 32 * a>(rca);
+          d4[a] = att_f4_asm<CUR * DKDV_BUF + 256 + 128 * QB2 + 32 * a>(rca);
+        });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        f32x16 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[0], kf[0], zero16, 0, 0, 0);
-        f32x16 pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad[0], vf[0], zero16, 0, 0, 0);
+        f32x16 sinit, pinit;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { sinit[4 * a + e] = l4[a][e]; pinit[4 * a + e] = d4[a][e]; }
+        f32x16 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[0], kf[0], sinit, 0, 0, 0);
+        f32x16 pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad[0], vf[0], pinit, 0, 0, 0);
 #pragma unroll
         for (int s = 1; s < 4; ++s) {
           sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[s], kf[s], sacc, 0, 0, 0);
@@ -720,13 +744,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
         // one decision per 32-query half (wave-uniform): the unmasked body is a single basic block — its eight lse / delta
         // reads, 32 exponentials and the packed arithmetic can be scheduled against each other
         const bool need_mask = (qq0 + 32 * qb2 + 32 > p.Tq) || (kw0 + 32 > p.Tk) || (p.causal && kw0 + 31 > qq0 + 32 * qb2);
-        f32x4 l4[4], d4[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          const int qoff = 32 * qb2 + 8 * a + 4 * h;
-          l4[a] = *(const f32x4*)(lse_l + qoff);
-          d4[a] = *(const f32x4*)(dlt_l + qoff);
-        }
         if (need_mask) {
 #pragma unroll
           for (int a = 0; a < 4; ++a)
@@ -734,9 +751,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
             for (int e = 0; e < 4; ++e) {
               const int qg = qq0 + 32 * qb2 + 8 * a + 4 * h + e;
               const bool ok = qg < p.Tq && ki < p.Tk && !(p.causal && ki > qg);
-              const float pv = ok ? __builtin_amdgcn_exp2f(fmaf(sacc[4 * a + e], c, -l4[a][e])) : 0.f;
+              const float pv = ok ? __builtin_amdgcn_exp2f(sacc[4 * a + e] * c) : 0.f;
               sacc[4 * a + e] = pv;
-              dsacc[4 * a + e] = ok ? pv * (pacc[4 * a + e] - d4[a][e]) : 0.f;
+              dsacc[4 * a + e] = ok ? pv * pacc[4 * a + e] : 0.f;
             }
         } else {
 #pragma unroll
@@ -744,11 +761,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
 #pragma unroll
             for (int e = 0; e < 4; e += 2) {  // packed fp32 pairs
               f32x2 t2 = {sacc[4 * a + e], sacc[4 * a + e + 1]};
-              const f32x2 l2 = {l4[a][e], l4[a][e + 1]}, d2 = {d4[a][e], d4[a][e + 1]};
-              t2 = t2 * c2 - l2;
+              t2 = t2 * c2;
               const f32x2 p2 = {__builtin_amdgcn_exp2f(t2[0]), __builtin_amdgcn_exp2f(t2[1])};
               f32x2 g2 = {pacc[4 * a + e], pacc[4 * a + e + 1]};
-              g2 = (g2 - d2) * p2;
+              g2 = g2 * p2;
               sacc[4 * a + e] = p2[0];
               sacc[4 * a + e + 1] = p2[1];
               dsacc[4 * a + e] = g2[0];
