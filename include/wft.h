@@ -187,7 +187,8 @@ typedef struct {
    * adapter gradients leave the library in the layout autograd hands to the optimizer — no element-wise pass after the GEMM:
    *  tn_col_scale: f32 [S][Q] or NULL; C[p][q] *= tn_col_scale[p / tn_scale_rows][q] (tn_scale_rows = 0: S = 1, one row for
    *    all p).  dA = (du^T x) * mask, the dropout mask of each adapter of the group (model/lora.py via minLoRA's
-   *    dropout-on-A);
+   *    dropout-on-A).  In this form C is a [p_valid][ldc] matrix: rows >= p_valid are NOT written (the
+   *    adapter gradients keep no 128-row buffer alive);
    *  tn_block_n > 0: C is NOT a [128][ldc] matrix but Q / tn_block_n contiguous blocks [tn_block_n][tn_block_r], block b
    *    holding the TRANSPOSE of rows b*tn_block_r .. +tn_block_r, columns b*tn_block_n .. +tn_block_n of the product (the
    *    off-diagonal blocks are not stored): dB of adapter b of a group of equally shaped Linears, as [out, r] row-major. */
@@ -225,7 +226,7 @@ typedef struct {
   int B; int H; int Tq; int Tk; int causal; float scale;
   /* backward only */
   const wft_bf16* d_o; int64_t lddo; int64_t do_bs;
-  float* delta;                 /* f32 workspace [2, B, H, Tq]: rowsum(dO*O), then lse*log2(e) */
+  float* delta;                 /* f32 workspace [2, B, H, Tq] (kernel-internal contents: -rowsum(dO*O), then -lse/scale) */
   wft_bf16* dq; int64_t lddq; int64_t dq_bs;
   wft_bf16* dk; int64_t lddk; int64_t dk_bs;
   wft_bf16* dv; int64_t lddv; int64_t dv_bs;

@@ -296,10 +296,18 @@ def test_lora_mask_pool_draws_once_per_forward_and_is_dropped_on_merge():
     m.train(); pool._on_forward(m, ())
     s1, s2 = ads[0].spec(True), ads[0].spec(True)      # one serial number per draw of the pool: the same inside a forward
     assert s1.draw_id == s2.draw_id == pool.serial and s1.key() == s2.key() and s1.owner is ads[0]
+    s1_vals, s1_ptr = s1.mask.clone(), s1.mask.data_ptr()
     pool._on_forward(m, ())
     s3 = ads[0].spec(True)                             # ... and a new one with the next forward's masks
-    assert s3.draw_id != s1.draw_id and s3.key() != s1.key() and s3.mask.data_ptr() == s1.mask.data_ptr()
+    assert s3.draw_id != s1.draw_id and s3.key() != s1.key()
+    # the pool's buffer is persistent (s3 views the bytes s1 used to view) and was overwritten in place; s1 is still alive — a
+    # forward whose backward has not run — so the draw moved it to a snapshot of ITS values
+    assert s3.mask.data_ptr() == s1_ptr and s1.mask.data_ptr() != s1_ptr and torch.equal(s1.mask, s1_vals) and torch.equal(s2.mask, s1_vals)
+    del s1, s2
+    pool._on_forward(m, ())                            # (s3 alive: moved as well; dead specs cost nothing)
+    assert s3.mask.data_ptr() != s1_ptr
     own = lora.LoRAParametrization(8, 8, rank=2, lora_dropout_p=0.5)   # an adapter outside any pool draws its own masks
     assert own.spec(True).draw_id != own.spec(True).draw_id
     lora.merge_lora(m)
-    assert "_wft_lora_pool" not in m.__dict__ and not m._forward_pre_hooks
+    assert "_wft_lora_pool" not in m.__dict__ and not m._forward_pre_hooks and not m._forward_hooks
+    assert not m.encoder._forward_pre_hooks and not m.decoder._forward_pre_hooks

@@ -502,7 +502,10 @@ def test_gemm_tn_adapter_gradient_outputs(R, Q, nb, r):
     want = ref.clone()
     for i in range(nb):
         want[i * r:(i + 1) * r] *= scale[i]
-    assert torch.equal(got, want) and torch.count_nonzero(got[rtot:]) == 0
+    assert got.shape == (rtot, Q) and torch.equal(got, want[:rtot])  # compact: p_valid rows, nothing written below them
+    guard = torch.full((rtot + 4, Q), 3.0, device=DEV)
+    K.gemm_tn(a, b, p_valid=rtot, col_scale=scale, scale_rows=r if nb > 1 else 0, out=guard, accumulate=False)
+    assert torch.equal(guard[:rtot], want[:rtot]) and bool((guard[rtot:] == 3.0).all())
     blocks = K.gemm_tn(a, b, p_valid=rtot, block_n=n, block_r=r)
     assert blocks.shape == (Q * r,)
     for i in range(nb):

@@ -440,6 +440,54 @@ def test_lora_dropout_masks_are_redrawn_per_micro_batch():
     assert ad.lora_A.grad[:, dead[0].to(DEV)].abs().max() == 0
 
 
+def test_lora_masks_survive_a_second_forward_before_the_backward():
+    """the mask pool's buffer is overwritten in place by the next draw.  `loss = model(a) + model(b)` runs two
+    training forwards before the first backward: the first forward's adapters must back-propagate through THEIR masks (the pool
+    moves still-alive specs to a snapshot).  Reference: the same two forwards run one after the other (forward, backward,
+    forward, backward) under the same RNG seeds — the gradients of the accumulation window must agree.  Also: a train-mode call
+    that enters below the root (`model.encoder(x)`) draws its own masks."""
+    dims, params, audio, y_in, y_out = _tiny_case()
+    mel = O.log_mel_spectrogram(audio, dims.n_mels).to(DEV)
+    y_in, y_out = y_in.to(DEV), y_out.to(DEV)
+    mel_b = torch.roll(mel, 1, 0).contiguous()
+
+    def build():
+        torch.manual_seed(5)
+        m = Whisper(MODEL_DIMS["tiny"]); m.load_state_dict(params)
+        lora_mod.apply_lora(m, {"rank": 8, "lora_alpha": 16, "lora_dropout": 0.5})
+        gl = torch.Generator().manual_seed(9)
+        for mod in m.modules():
+            if "parametrizations" in mod._modules:
+                ad = mod.parametrizations.weight[0]
+                with torch.no_grad():
+                    ad.lora_B.copy_(torch.randn(ad.lora_B.shape, generator=gl) * 0.05)
+        return m.to(DEV).train()
+
+    def grads(m):
+        return {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.requires_grad}
+
+    m = build()
+    torch.manual_seed(101); la = m(mel, y_in, targets=y_out)
+    torch.manual_seed(202); lb = m(mel_b, y_in, targets=y_out)  # second draw while the first forward's graph is alive
+    (la + lb).backward()
+    g_joint = grads(m)
+    m2 = build()
+    torch.manual_seed(101); la2 = m2(mel, y_in, targets=y_out); la2.backward()
+    torch.manual_seed(202); lb2 = m2(mel_b, y_in, targets=y_out); lb2.backward()
+    g_seq = grads(m2)
+    assert torch.equal(la, la2) and torch.equal(lb, lb2)
+    worst = max(rel(g_joint[n], g_seq[n]) for n in g_seq)
+    assert worst < 1e-5, worst  # (same kernels, same masks; only the order in which the two graphs add into .grad differs)
+    # entering below the root: every call is its own draw
+    pool = m.__dict__["_wft_lora_pool"]
+    s0 = pool.serial
+    with torch.no_grad():
+        m.encoder(mel)
+        s1 = pool.serial
+        m.encoder(mel)
+    assert s1 > s0 and pool.serial > s1
+
+
 def test_train_step_on_the_engine_follows_the_references_loss_sequence():
     """GPU leg of tests/golden/ref_train_step.npz (the REFERENCE'S OWN train_step driving the fp32 oracle, 4 optimizer steps x
     2 micro-batches, AdamW, clip 0.5, linear schedule): the engine in bf16 under this package's train_step stays within 3e-3

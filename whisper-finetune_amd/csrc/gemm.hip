@@ -1353,6 +1353,7 @@ __global__ __launch_bounds__(256) void tn_splitk_reduce_kernel(const float* ws, 
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const long pp = i / nq4, q4 = (i - pp * nq4) * 4;
     float* cp = C + pp * ldc + q4;
+    if (col_scale && blk_n == 0 && pp >= Pv) continue;  // col-scale form: C has p_valid rows, nothing is written below them
     if (pp >= P) {
       if (!accumulate && blk_n == 0) *(f32x4*)cp = f32x4{0.f, 0.f, 0.f, 0.f};
       continue;

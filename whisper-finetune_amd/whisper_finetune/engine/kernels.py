@@ -297,7 +297,9 @@ def gemm_tn(a, b, *, P=None, Q=None, R=None, lda=None, ldb=None, out=None, out_f
         ldc = Q
     else:
         if out is None:
-            out = torch.empty((P, Q), dtype=F32 if out_f32 else BF16, device=a.device)
+            # col_scale form (dA of a group's adapters): the library writes p_valid rows only — a compact gradient tensor
+            rows = int(p_valid) if (col_scale is not None and p_valid > 0) else P
+            out = torch.empty((rows, Q), dtype=F32 if out_f32 else BF16, device=a.device)
             accumulate = False
         ldc = out.stride(0)
     args = L.GemmArgs()
@@ -372,7 +374,7 @@ def attn_bwd(q, k, v, o, lse, do, n_head: int, causal: bool, scale: float, dq=No
     dq = torch.empty((B, Tq, D), dtype=BF16, device=q.device) if dq is None else dq
     dk = torch.empty((B, Tk, D), dtype=BF16, device=q.device) if dk is None else dk
     dv = torch.empty((B, Tk, D), dtype=BF16, device=q.device) if dv is None else dv
-    delta = torch.empty((2, B, n_head, Tq), dtype=F32, device=q.device)  # [0] rowsum(dO*O), [1] lse*log2(e)
+    delta = torch.empty((2, B, n_head, Tq), dtype=F32, device=q.device)  # kernel-internal workspace: [0] -rowsum(dO*O), [1] -lse/scale
     a = L.AttnArgs()
     a.q, a.ldq, a.q_bs = _attn_view(q)
     a.k, a.ldk, a.k_bs = _attn_view(k)

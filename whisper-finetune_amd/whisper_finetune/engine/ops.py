@@ -49,7 +49,7 @@ class LoraSpec:
     """Low-rank adapter of one Linear (minLoRA semantics):
     W_eff = W + scaling * B @ (A * mask);  A [r, in], B [out, r], mask [1, in] (already drawn)."""
 
-    __slots__ = ("A", "B", "scaling", "mask", "draw_id", "owner")
+    __slots__ = ("A", "B", "scaling", "mask", "draw_id", "owner", "__weakref__")
     _draws = itertools.count(1)
 
     def __init__(self, A, B, scaling: float, mask: Optional[torch.Tensor], draw_id: Optional[int] = None, owner=None):
@@ -257,7 +257,9 @@ class LoraRefreshPlan:
                 vers.append((wv, av))
                 for x, (ya, yb) in zip(wv, av):
                     cur.extend((x[0], ya[0], yb[0]))
-            stale = cur != self.ptrs or any(g.W is None or g.WT is None or (pk and g.Am is None) or not all(a.enabled for a in ads)
+            # (pk != (g.Am is not None): a group that entered the table before its pack operands existed must be re-tabled as
+            # packed, or every backward falls back to one wft_lora_pack launch per adapter for good — ADVICE r2)
+            stale = cur != self.ptrs or any(g.W is None or g.WT is None or pk != (g.Am is not None) or not all(a.enabled for a in ads)
                                             for g, _, ads, pk in self.items)
             if not stale:
                 break

@@ -135,7 +135,10 @@ class LinearFn(torch.autograd.Function):
 def linear(x, w, b, spec=None):
     if spec is None:
         return LinearFn.apply(x, w, b, None, None, 1.0, None)
-    return LinearFn.apply(x, w, b, spec.A, spec.B, spec.scaling, spec.mask)
+    mask = spec.mask
+    if mask is not None and getattr(spec.owner, "_pool", None) is not None:
+        mask = mask.clone()  # a slice of the model's persistent mask pool: autograd must save THIS forward's values (parity mode: one small copy per Linear)
+    return LinearFn.apply(x, w, b, spec.A, spec.B, spec.scaling, mask)
 
 
 # ------------------------------------------------------------------------------------------------ LayerNorm / GELU

@@ -46,10 +46,17 @@ def evaluate_single_dataset(model, dataloader, dataset_name: str, t_config: dict
     model.eval()
     device = next(model.parameters()).device
     mixed = t_config.get("mixed_precision_training", True)
-    amp_dtype = torch.float16 if t_config.get("mp_dtype", "fp16") == "fp16" else torch.bfloat16
-    from whisper_finetune.engine.whisper_model import check_amp_request
+    from whisper_finetune.engine.whisper_model import Whisper as _EngineWhisper, check_amp_request
 
-    check_amp_request(model, mixed, t_config.get("mp_dtype", "fp16"))
+    mp_dtype = t_config.get("mp_dtype", "fp16")
+    if mixed and mp_dtype == "fp16" and isinstance(model, _EngineWhisper):
+        # the reference's evaluator accepts a minimal config (mp_dtype defaults to fp16, every shipped YAML says fp16): on the
+        # engine that means bf16 autocast, said once — the same rewrite scripts/finetune.resolve_precision makes for training
+        rt.print_once("WARNING: evaluation with mp_dtype: fp16 -> bf16 autocast on MI355X (the libwft engine computes in bf16; "
+                      "set mp_dtype: bf16 to silence this)")
+        mp_dtype = "bf16"
+    amp_dtype = torch.float16 if mp_dtype == "fp16" else torch.bfloat16
+    check_amp_request(model, mixed, mp_dtype)
     if tokenizer is None:
         tokenizer = _default_tokenizer()
     specials = set(tokenizer.special_tokens.values())

@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import math
 import os
+import weakref
 from typing import Optional
 
 import torch
@@ -63,8 +64,11 @@ class LoRAParametrization(nn.Module):
         m = self.draw_mask(training)
         pool = self._pool
         if m is not None and pool is not None and pool.buf is not None and m.untyped_storage().data_ptr() == pool.buf.untyped_storage().data_ptr():
-            # the pool's draw for this forward of the model, under the pool's serial number
-            return ops.LoraSpec(self.lora_A, self.lora_B, self.scaling, m, draw_id=pool.serial, owner=self)
+            # the pool's draw for this forward of the model, under the pool's serial number; the pool keeps track of the specs
+            # that view its buffer so that the NEXT draw can move the ones still alive (a backward yet to run) to a snapshot
+            sp = ops.LoraSpec(self.lora_A, self.lora_B, self.scaling, m, draw_id=pool.serial, owner=self)
+            pool.handed.append(weakref.ref(sp))
+            return sp
         return ops.LoraSpec(self.lora_A, self.lora_B, self.scaling, m, owner=self)
 
     def forward(self, W: torch.Tensor) -> torch.Tensor:
@@ -86,7 +90,15 @@ class LoraMaskPool:
     """All dropout masks of a model's adapters as slices of one buffer, redrawn once per forward of the root module (a
     forward pre-hook): `bernoulli_(1 - p) / (1 - p)` over the concatenated input widths — the distribution of minLoRA's
     per-adapter `Dropout(p)(ones[1, in])`, 2 launches instead of 512.  A checkpoint recompute inside the same forward sees the
-    same masks (they change only when the root forward starts)."""
+    same masks (they change only when the root forward starts).
+
+    The buffer is persistent (the batched refresh kernel's table holds addresses inside it) and overwritten in place by the next
+    draw, so a draw first looks for LoraSpecs of the PREVIOUS draw that are still alive — a forward whose backward has not run
+    yet: `loss = model(a) + model(b)`, R-Drop, a train-mode probe — and moves their masks to a snapshot of the old values; their
+    backward then rebuilds its operands from exactly the masks its forward used (the per-Linear path: the serial differs).  In the
+    ordinary loop (forward, backward, step) no spec survives to the next draw and nothing is copied.
+    Train-mode calls that enter below the root (`model.encoder(x)`, `model.forward_loss(...)`) reach the same draw through hooks
+    on the root's direct children: they draw when no forward of the root is in progress."""
 
     def __init__(self, root: nn.Module):
         self.adapters = []
@@ -95,7 +107,12 @@ class LoraMaskPool:
         self.store = None    # the persistent buffer `buf` points at (wft_lora_refresh_mt's table holds addresses inside it)
         self.serial = 0      # ops.LoraSpec draw id of the current masks
         self.total = 0
-        self.handle = root.register_forward_pre_hook(self._on_forward)
+        self.handed = []     # weak references to the LoraSpecs that view `store` under the current serial
+        self.depth = 0       # > 0 while a forward of the root is running
+        self.handle = root.register_forward_pre_hook(self._on_root_forward)
+        self.handles = [root.register_forward_hook(self._after_root_forward, always_call=True)]
+        for child in root.children():  # (encoder, decoder): entry points of calls that bypass root.__call__
+            self.handles.append(child.register_forward_pre_hook(self._on_child_forward))
         self.root = root
         # all merged shadows / gradient-GEMM operands of the model in one launch per training forward (WFT_LORA_BATCH=0: the
         # per-Linear kernels, A/B runs)
@@ -106,6 +123,27 @@ class LoraMaskPool:
         self.total += adapter.lora_A.shape[1]
         self.adapters.append(adapter)
         adapter.__dict__["_pool"] = self
+
+    def _on_root_forward(self, module, inputs):
+        self.depth += 1
+        self._on_forward(module, inputs)
+
+    def _after_root_forward(self, module, inputs, output):
+        self.depth = max(0, self.depth - 1)
+
+    def _on_child_forward(self, module, inputs):
+        if self.depth == 0:  # entered below the root: this call is its own "forward of the model"
+            self._on_forward(self.root, inputs)
+
+    def _detach_live_specs(self) -> None:
+        """Specs of the previous draw whose backward is still to come keep the OLD mask values (a snapshot)."""
+        live = [sp for sp in (r() for r in self.handed) if sp is not None and sp.mask is not None]
+        self.handed = []
+        if live and self.store is not None:
+            snap = self.store.clone()
+            for sp in live:
+                off, n = self.offsets[id(sp.owner)]
+                sp.mask = snap[off:off + n].view(1, n)
 
     def _on_forward(self, module, inputs):
         if not module.training or not self.adapters:
@@ -121,6 +159,7 @@ class LoraMaskPool:
                 self.store = torch.empty(self.total, device=A0.device, dtype=A0.dtype)
                 if self.plan is not None:
                     self.plan.dirty = True
+            self._detach_live_specs()
             self.buf = self.store.bernoulli_(1.0 - p).mul_(1.0 / (1.0 - p))
             self.serial = next(ops.LoraSpec._draws)
         else:
@@ -210,6 +249,8 @@ def _drop_pool(model: nn.Module) -> None:
     pool = model.__dict__.pop("_wft_lora_pool", None)
     if pool is not None:
         pool.handle.remove()
+        for h in pool.handles:
+            h.remove()
 
 
 def remove_lora(model: nn.Module) -> None:

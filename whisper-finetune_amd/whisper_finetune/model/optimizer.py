@@ -174,9 +174,14 @@ def _muon_shard():
     world = dist.get_world_size()
 
     def all_gather(out, inp):
-        if dist.get_backend() == "nccl":
-            dist.all_gather_into_tensor(out, inp)  # one RCCL all-gather per same-shape bucket
-        else:  # gloo (tests): list form
+        # one all-gather per same-shape bucket, the into-tensor form on EVERY backend that has it (RCCL in production; gloo
+        # takes it for CPU tensors, so the world-size-2 CPU test runs the production call with its padded `inp` and
+        # world * per sized `out`); gloo with device tensors falls back to the list form over the same layout
+        try:
+            dist.all_gather_into_tensor(out, inp)
+        except (RuntimeError, NotImplementedError):
+            if dist.get_backend() == "nccl":
+                raise
             dist.all_gather(list(out.chunk(world, dim=0)), inp)
 
     return dist.get_rank(), world, all_gather
