@@ -96,6 +96,19 @@ def _check(got, emu, f32, tag, emu_med=EMU_MED, f32_med=F32_MED):
     bad = [(n, e_emu[n], e_f32[n], cond[n]) for n in got
            if e_emu[n] > EMU_FLOOR + 3 * cond[n] or e_f32[n] > F32_FLOOR + 3 * cond[n]]
     assert not bad, sorted(bad, key=lambda t: -t[1])[:8]
+    # per ROLE (one parameter name over all blocks): the median over the blocks is insensitive to the few badly conditioned
+    # layers that set the per-tensor allowance above, so it gets the tight bound — a factor-2 slip in one role (a mis-scaled
+    # term in the decoder's q / k gradients, say) moves that role's median by tens of per cent
+    role_of = lambda n: re.sub(r"blocks\.\d+\.", "blocks.*.", n)
+    by_role = defaultdict(lambda: ([], [], []))
+    for n in got:
+        r3 = by_role[role_of(n)]
+        r3[0].append(e_emu[n]); r3[1].append(e_f32[n]); r3[2].append(raw[n])
+    role_rows = {r: (float(np.median(a)), float(np.median(b)), float(np.median(c))) for r, (a, b, c) in by_role.items()}
+    worst_roles = sorted(role_rows.items(), key=lambda kv: -(kv[1][0] - kv[1][2]))[:4]
+    print(f"[{tag}] per-role medians (gpu vs emulated, gpu vs fp32, emulated vs fp32), largest excess first: {worst_roles}")
+    bad_roles = [(r, v) for r, v in role_rows.items() if v[0] > EMU_FLOOR + 1.5 * v[2] or v[1] > F32_FLOOR + 1.5 * v[2]]
+    assert not bad_roles, bad_roles[:6]
     assert float(np.median(list(raw.values()))) < 3e-2, "the model / inputs are too ill-conditioned for this test to mean anything"
     assert float(np.median(list(e_emu.values()))) < emu_med
     assert float(np.median(list(e_f32.values()))) < f32_med
@@ -250,25 +263,54 @@ def test_large_v3_lora_muon_config_step_matches_oracle():
         f1 = ex.submit(O.muon_with_aux_adam_step, g_bf16, {})                          # the package's arithmetic: Newton-Schulz in bf16
         f2 = ex.submit(O.muon_with_aux_adam_step, g_f32, {}, ns_dtype=torch.float32)   # same iteration in fp32: the bf16 sensitivity
         f1.result(); f2.result()
-    errs, cond = {}, {}
+    # ---- what the update must satisfy (the old bound 6e-2 + 2 x sensitivity reached 3.8 on rank-16 adapter
+    # gradients, where two bf16 Newton-Schulz evaluations differ by up to 1.9 in relative L2 — the negated update would have
+    # passed).  Per Muon matrix: SPECTRAL checks of the update against the gradient that went in (tests/_muon_spectral.py: gains
+    # along the strong singular pairs in the Newton-Schulz-5 band, on the scalar iteration; update inside the gradient's row /
+    # column space up to the oracle's own bf16 leak; strong-subspace projection within 5e-2 of the oracle's; <U, G> > 0), the
+    # relative L2 bound 6e-2 only where the measured bf16 sensitivity is below 5e-2, and the three wrong updates (negated,
+    # un-scaled, un-normalised) as negative controls that must FAIL.  Auxiliary-Adam parameters: plain relative L2 (2e-3).
+    from tests._muon_spectral import negative_controls, spectral_violations
+
+    muon_names = {names_of[id(p)] for grp in opt.param_groups if grp["use_muon"] for p in grp["params"]}
+    lr_of = {names_of[id(p)]: (grp["lr"], grp["weight_decay"]) for grp in opt.param_groups for p in grp["params"]}
+    errs, cond, bad, n_spec, n_l2, ctl_missed = {}, {}, [], 0, 0, []
     for n, want in ref_bf16.items():
+        lr, wd = lr_of[n]
         d_got, d_want, d_f32 = named[n].detach().cpu() - before[n], want - before[n], ref_f32[n] - before[n]
         if d_want.norm() == 0:
             assert d_got.norm() == 0, n
             continue
         errs[n] = ((d_got - d_want).norm() / d_want.norm()).item()
         cond[n] = ((d_want - d_f32).norm() / d_f32.norm()).item()
+        if n not in muon_names:
+            if errs[n] > 2e-3:
+                bad.append((n, "aux adam", errs[n]))
+            continue
+        if named[n].grad is None or named[n].grad.norm() == 0:  # a block dropped by stochastic depth: weight decay only
+            if errs[n] > 2e-3:
+                bad.append((n, "decay-only update", errs[n]))
+            continue
+        G = named[n].grad.detach().cpu().float()
+        # the update itself: p' = p (1 - lr wd) - lr U  (first step: the momentum-mixed gradient is a multiple of G)
+        shrink = before[n].double() * (1 - lr * wd)
+        U_got = (shrink - named[n].detach().cpu().double()) / lr
+        U_ref = (shrink - want.double()) / lr
+        v = spectral_violations(U_got, G, U_ref)
+        n_spec += 1
+        if v:
+            bad.append((n, "spectral", v))
+        if cond[n] < 5e-2:
+            n_l2 += 1
+            if errs[n] > 6e-2:
+                bad.append((n, "relative L2 of a well-conditioned update", errs[n], cond[n]))
+        if n_spec <= 48 or n_spec % 16 == 0:  # negative controls on a sample of the 1 000+ matrices (each one SVD more)
+            for cname, wrong in negative_controls(U_got, G).items():
+                if not spectral_violations(wrong, G, U_ref):
+                    ctl_missed.append((n, cname))
     _report(cond, "Muon step: bf16 vs fp32 Newton-Schulz in the oracle (sensitivity)")
-    worst = _report(errs, "Muon step: gpu vs oracle (update relative error)")
-    # The orthogonalised update of a rank-16 gradient is dominated by its weak singular directions, which five bf16
-    # Newton-Schulz iterations amplify together with their rounding noise: two bf16 evaluations differ by about what bf16
-    # differs from fp32.  Bound = 6e-2 (the well-conditioned case, tests/test_scheduler_optimizer.py) + 2x that sensitivity.
-    import re
-    from collections import defaultdict
-    roles = defaultdict(list)
-    for n, c in cond.items():
-        roles[re.sub(r"blocks\.\d+\.", "blocks.*.", n)].append(c)
-    bad = [(n, e, cond[n]) for n, e in errs.items()
-           if e > 6e-2 + 2 * max(cond[n], float(np.median(roles[re.sub(r"blocks\.\d+\.", "blocks.*.", n)])))]
-    assert not bad, sorted(bad, key=lambda t: -t[1])[:8]
-    assert float(np.median(list(errs.values()))) < 6e-2 + 2 * float(np.median(list(cond.values())))
+    _report(errs, "Muon step: gpu vs oracle (update relative error)")
+    print(f"[Muon step] spectral checks on {n_spec} matrices, relative-L2 bound applied to {n_l2} well-conditioned ones")
+    assert n_spec >= 800, n_spec
+    assert not bad, bad[:8]
+    assert not ctl_missed, ctl_missed[:8]

@@ -199,3 +199,35 @@ def test_single_tensor_adamw_entry_point_matches_torch_adamw_with_clip_scale():
         K.adamw_step(p, g, m, v, shadow, 1e-2, 0.9, 0.98, 1e-6, 0.1, 1 - 0.9 ** step, 1 - 0.98 ** step, gscale)
     torch.testing.assert_close(p, ref.detach(), atol=1e-6, rtol=1e-5)
     assert torch.equal(shadow, p.to(torch.bfloat16))
+
+
+def test_muon_spectral_check_accepts_the_oracle_and_rejects_wrong_updates():
+    """tests/_muon_spectral.py (the large-v3 Muon check) on the CPU: the oracle's bf16 Newton-Schulz update
+    of rank-16 gradients with singular-value spreads of 1 ... 1e-3 passes against a second bf16 evaluation — also where two
+    evaluations differ by 20 % in relative L2 — and so does the fp32 evaluation, while the negated, the un-scaled (rows > cols) and the un-normalised update each fail."""
+    from oracle import whisper_oracle as O
+    from tests._muon_spectral import NS_BAND, negative_controls, ns5_scalar, spectral_violations
+
+    x = torch.logspace(-3, 0, 4000)
+    y = ns5_scalar(x)[x >= 0.025]  # a strong direction (sigma >= 0.1 sigma_max) of a rank-16 matrix has sigma / |M|_F >= 0.025
+    assert NS_BAND[0] < float(y.min()) and float(y.max()) < NS_BAND[1]
+    g = torch.Generator().manual_seed(0)
+    for shape in ((16, 1280), (1280, 16), (64, 64), (5120, 16)):
+        r = min(shape)
+        for spread in (1.0, 1e-1, 1e-2, 1e-3):
+            P = torch.linalg.qr(torch.randn(shape[0], r, generator=g))[0]
+            Q = torch.linalg.qr(torch.randn(shape[1], r, generator=g))[0]
+            sv = torch.logspace(0, float(torch.log10(torch.tensor(spread))), r) * 3e-3
+            M = (P * sv) @ Q.T
+            sc = max(1, shape[0] / shape[1]) ** 0.5
+            U16 = O.zeropower_via_newtonschulz5(M.clone()).float() * sc
+            U32 = O.zeropower_via_newtonschulz5(M.clone(), dtype=torch.float32) * sc
+            # a second bf16 evaluation of the same update (the iteration is scale invariant; other roundings): the reference the
+            # GPU update is held against in tests/test_large_v3_gpu.py is such an evaluation, rounding noise included
+            U16b = O.zeropower_via_newtonschulz5(M.clone() * 1.37).float() * sc
+            assert spectral_violations(U16, M, U16b) == [], (shape, spread, spectral_violations(U16, M, U16b))
+            assert spectral_violations(U32, M, U16b) == [], (shape, spread)
+            ctl = negative_controls(U16, M)
+            assert ("unscaled" in ctl) == (shape[0] > shape[1])
+            for name, wrong in ctl.items():
+                assert spectral_violations(wrong, M, U16b), (shape, spread, name)
