@@ -22,7 +22,14 @@ and, on the default (headline) invocation, extra keys measured in the same proce
   "hand_rolled_ms_per_step": round 1's hand-written loop on the same state (cross-check of the product loop),
   "reference_yaml_shapes":   the reference YAML's batch 32 at S = 128 and at the S = 448 stress length,
   "configs2_lora_muon":      BASELINE configs[2] (LoRA r16 + Muon + stochastic depth + deep SpecAugment, B = 32) with
-                             its own roofline object.  `--no-extras` prints the headline only.
+                             its own roofline object,
+  "configs1_base":           BASELINE configs[1] (whisper-base full fine-tune, B = 8, S = 128),
+  "configs4_turbo_lora":     BASELINE configs[4]'s per-GPU workload (large-v3-turbo, LoRA r16, 64-token prompt with -100 targets +
+                             timestamp tokens every 16th position, B = 64 — SURVEY.md §8d config 5),
+  "entrypoint_loop":         scripts/finetune.py's real loop (SyntheticDataset -> DataLoader workers -> GpuMelLoader ->
+                             train_step, tools/e2e_entrypoint.py) at B = 32 next to the same batches replayed from HBM.
+`ms_per_step` is the mean over the K timed steps (the contract's clock); `ms_per_step_median` is the median of the per-step
+wall times inside that region (train_step ends with loss.item()).  `--no-extras` prints the headline only.
 """
 from __future__ import annotations
 
@@ -72,9 +79,9 @@ def pmc_traffic_per_launch(batch: int, lora: bool = False):
     being --kernel-trace).  FETCH_SIZE is in KiB and counts 64 B per 128-B request on gfx950 for 16-B/lane streaming
     reads, so it is doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE (KiB) is exact.  Counters cannot be
     collected inside the timed run, so the value is only reported when the committed pass used the same batch."""
-    if lora:
-        return None, "no PMC pass committed for this configuration"
-    cands = sorted((ROOT / "profiles").glob("r0*_pmc_summary.json"))
+    cands = sorted((ROOT / "profiles").glob("r0*_lora_pmc_summary.json" if lora else "r0*_pmc_summary.json"))
+    if not lora:
+        cands = [c for c in cands if "_lora_" not in c.name]
     if not cands:
         return None, "no PMC summary committed"
     path = cands[-1]  # the latest round's pass
@@ -118,12 +125,26 @@ def build_model(name: str, device, sd_p: float = 0.0):
     return model, dims
 
 
-def synthetic_tokens(B: int, S: int, device, seed: int):
+def synthetic_tokens(B: int, S: int, device, seed: int, prompt_ts: bool = False):
+    """y_in = [sot, <|de|>, <|transcribe|>, <|notimestamps|>] + U{0..50256}^(S-4), y_out = shift + [eot].
+    prompt_ts (config 5): [sot_prev] + a 64-token prompt with -100 targets in front, no <|notimestamps|>, and a timestamp token
+    timestamp_begin + U{0..1500} at every 16th position of the transcript."""
     g = torch.Generator().manual_seed(4321 + seed)
-    specials = torch.tensor([50258, 50261, 50359, 50363])
-    body = torch.randint(0, 50257, (B, S - 4), generator=g)
-    y_in = torch.cat([specials.expand(B, -1), body], dim=1)
+    if not prompt_ts:
+        specials = torch.tensor([50258, 50261, 50359, 50363])
+        body = torch.randint(0, 50257, (B, S - 4), generator=g)
+        y_in = torch.cat([specials.expand(B, -1), body], dim=1)
+        y_out = torch.cat([y_in[:, 1:], torch.full((B, 1), 50257)], dim=1)
+        return y_in.to(device), y_out.to(device)
+    n_prompt = 64
+    body = torch.randint(0, 50257, (B, S - 3), generator=g)
+    ts = 50364 + torch.randint(0, 1501, (B, S - 3), generator=g)
+    pos = torch.arange(S - 3)
+    body = torch.where((pos % 16 == 0).expand(B, -1), ts, body)
+    prompt = torch.randint(0, 50257, (B, n_prompt), generator=g)
+    y_in = torch.cat([torch.full((B, 1), 50361), prompt, torch.tensor([50258, 50261, 50359]).expand(B, -1), body], dim=1)
     y_out = torch.cat([y_in[:, 1:], torch.full((B, 1), 50257)], dim=1)
+    y_out[:, :n_prompt + 1] = -100  # the prompt (and the step that predicts sot) carries no loss
     return y_in.to(device), y_out.to(device)
 
 
@@ -160,13 +181,15 @@ class Case:
     clip folded into the libwft optimizer, optimizer + scheduler step, zero_grad) pulling its micro-batch from an iterator
     that runs log-mel + SpecAugment on clips already resident in HBM."""
 
-    def __init__(self, args, device, rank, local_rank, world, ddp, lora=False, muon=False, sd=0.0, dsa=False):
+    def __init__(self, args, device, rank, local_rank, world, ddp, lora=False, muon=False, sd=0.0, dsa=False, model_name=None,
+                 prompt_ts=False):
         from whisper_finetune.data.gpu_frontend import GpuFrontend
         from whisper_finetune.model.optimizer import WftAdamW, get_optimizer
 
         self.args, self.device, self.rank, self.local_rank, self.world, self.ddp = args, device, rank, local_rank, world, ddp
-        self.lora, self.muon, self.sd, self.dsa = lora, muon, sd, dsa
-        self.model, self.dims = build_model(args.model, device, sd)
+        self.lora, self.muon, self.sd, self.dsa, self.prompt_ts = lora, muon, sd, dsa, prompt_ts
+        self.model_name = model_name or args.model
+        self.model, self.dims = build_model(self.model_name, device, sd)
         if lora:
             from whisper_finetune.model.lora import apply_lora
 
@@ -223,7 +246,8 @@ class Case:
         torch.manual_seed(1234 + rank)  # per-rank host RNG (finetune.py:325)
         gen = torch.Generator(device=dev).manual_seed(1234 + rank)
         audio = torch.randn(B, 480000, device=dev, generator=gen) * 0.1  # resident in HBM
-        y_in, y_out = synthetic_tokens(B, S, dev, rank)
+        y_in, y_out = synthetic_tokens(B, S, dev, rank, self.prompt_ts)
+        S = y_in.shape[1]  # (prompt_ts: S transcript positions + 65 prompt positions)
         frontend, net, opt, sched = self.frontend, self.net, self.opt, self.sched
 
         def batches():
@@ -248,9 +272,12 @@ class Case:
         for _ in range(warmup):
             step()
         self.fence()
+        per_step = []
         t0 = time.perf_counter()
         for _ in range(steps):
+            t1 = time.perf_counter()
             loss = step()
+            per_step.append(time.perf_counter() - t1)  # (train_step ends with loss.item(): this step's device work is done)
         self.fence()
         dt = time.perf_counter() - t0
         if self.ddp:
@@ -258,6 +285,7 @@ class Case:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = t.item()
         res = {"batch": B, "seq_len": S, "ms_per_step": round(dt / steps * 1e3, 2),
+               "ms_per_step_median": round(sorted(per_step)[len(per_step) // 2] * 1e3, 2),
                "value": round(B * self.world * steps * 30.0 / dt, 1), "final_loss": round(float(loss), 4)}
         tf = self.step_flops(B, S) / (dt / steps) / 1e12
         res["step_tflops_per_gpu"] = round(tf, 1)
@@ -279,14 +307,17 @@ class Case:
             if rank == 0:
                 recs, K.PROFILE_NT = K.PROFILE_NT, None
                 big = [(s_.elapsed_time(e_), f, nb) for s_, e_, f, v, nb in recs if v == 256]  # gemm_nt256_kernel launches
+                kname = "gemm_nt256_kernel"
+                if not big:  # small models (whisper-base at 8 clips): every NT GEMM takes the 128x128 kernel
+                    big, kname = [(s_.elapsed_time(e_), f, nb) for s_, e_, f, v, nb in recs], "gemm_nt_kernel"
                 ms = sum(t for t, _, _ in big)
                 flops = sum(f for _, f, _ in big)
                 all_ms = sum(s_.elapsed_time(e_) for s_, e_, _, _, _ in recs)
                 all_fl = sum(f for _, _, f, _, _ in recs)
                 ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-                traffic, traffic_note = pmc_traffic_per_launch(B, self.lora)
+                traffic, traffic_note = pmc_traffic_per_launch(B, self.lora) if (kname == "gemm_nt256_kernel" and self.model_name == "large-v3" and not self.prompt_ts) else (None, "no PMC pass committed for this configuration")
                 res["roofline"] = {
-                    "kernel": "gemm_nt256_kernel", "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
+                    "kernel": kname, "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                     "algorithmic_bytes_per_launch_avg": round(sum(nb for _, _, nb in big) / max(len(big), 1)),
                     "launches": len(big), "avg_launch_us": round(ms * 1e3 / max(len(big), 1), 2),
@@ -371,14 +402,38 @@ def main():
         lora_line = c2.measure(32, 128, 4, 2, roofline=not args.no_roofline)
         lora_line["workload"] = f"whisper-large-v3 {c2.mode()}, 32 clips per GPU per step, S=128 (BASELINE configs[2] shape)"
         c2.release()
+        # BASELINE configs[1]: whisper-base full fine-tune, 8 clips (host-bound: 810 launches of 13 ms of kernels per step)
+        c1 = Case(args, device, rank, local_rank, world, ddp, model_name="base")
+        base_line = c1.measure(8, 128, 20, 5, roofline=not args.no_roofline)
+        base_line["workload"] = f"whisper-base {c1.mode()}, 8 clips per GPU per step, S=128 (BASELINE configs[1])"
+        c1.release()
+        # BASELINE configs[4]'s per-GPU workload: large-v3-turbo (4-layer decoder), LoRA r16, prompt + timestamp targets, B = 64
+        c4 = Case(args, device, rank, local_rank, world, ddp, lora=True, model_name="large-v3-turbo", prompt_ts=True)
+        turbo_line = c4.measure(64, 128, 4, 2, roofline=not args.no_roofline)
+        turbo_line["workload"] = (f"whisper-large-v3-turbo {c4.mode()}, 64 clips per GPU per step, 64-token prompt (-100 targets) + 128 "
+                                  "transcript positions with a timestamp token every 16th (BASELINE configs[4] per-GPU shape)")
+        c4.release()
+        # the entrypoint's real loop (DataLoader workers -> GpuMelLoader -> train_step) next to the same batches from HBM
+        try:
+            sys.path.insert(0, str(ROOT / "tools"))
+            from e2e_entrypoint import measure as e2e_measure
+
+            entry_line = e2e_measure("large-v3", 32, steps=8, warmup=3, device=device)
+        except Exception as exc:  # informative; never lose the headline over it
+            entry_line = {"failed": repr(exc)}
+        import gc
+
+        gc.collect()
+        torch.cuda.empty_cache()
     else:
         mode, dims = case.mode(), case.dims
+        base_line = turbo_line = entry_line = None
 
     if rank == 0:
         out = {
             "metric": "audio-seconds/sec training throughput, whisper-large-v3 bf16",
             "value": head["value"], "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": head["ms_per_step"], "ms_per_step_median": head["ms_per_step_median"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {
                 "workload": f"whisper-{args.model} {mode}, bf16 MFMA / fp32 master weights, {B} synthetic 30 s clips per GPU "
@@ -398,6 +453,12 @@ def main():
             out["reference_yaml_shapes"] = other
         if lora_line is not None:
             out["configs2_lora_muon"] = lora_line
+        if base_line is not None:
+            out["configs1_base"] = base_line
+        if turbo_line is not None:
+            out["configs4_turbo_lora"] = turbo_line
+        if entry_line is not None:
+            out["entrypoint_loop"] = entry_line
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.model if args.model in ("tiny", "base", "small", "large-v3", "large-v3-turbo") else "large-v3", S)
