@@ -94,6 +94,14 @@ int wft_dgelu_mul_bf16(const wft_bf16* dy, const wft_bf16* pre, wft_bf16* out, i
 /* out[c] (+)= sum_r x[r, c] — bias gradients.  x bf16 [rows, ld], out f32[cols] */
 int wft_colsum_bf16(const wft_bf16* x, int64_t rows, int64_t cols, int64_t ld,
                     float* out, int accumulate, void* stream);
+/* The same sums for LARGE inputs (rows >= 65 536) through a caller workspace of wft_colsum_workspace_bytes(rows, cols): the
+ * rows are cut into 64 chunks summed by (column group, chunk) workgroups and folded in chunk order (fixed order, HBM rate;
+ * the one-pass kernel above occupies cols / 32 workgroups only).  Falls back to wft_colsum_bf16 when the workspace is
+ * missing or the input small.  Replaces: the bias gradient torch.autograd forms for nn.Conv1d in
+ * whisper.model.AudioEncoder (src/whisper_finetune/model/model_utils.py:271-281 via loss.backward(), :63-72).        */
+int64_t wft_colsum_workspace_bytes(int64_t rows, int64_t cols);
+int wft_colsum_bf16_ws(const wft_bf16* x, int64_t rows, int64_t cols, int64_t ld, float* out, int accumulate,
+                       void* workspace, int64_t workspace_bytes, void* stream);
 
 /* -------------------------------------------------------------- LayerNorm */
 /* whisper.model.LayerNorm.forward = F.layer_norm(x.float()).type(x.dtype)

@@ -439,6 +439,24 @@ def test_fused_bias_gradient_column_sums():
         assert (cs - want).abs().max() < 4e-3 * want.abs().max() + 1e-2  # fused sums are of the un-rounded fp32 values
 
 
+@pytest.mark.parametrize("rows,cols,ld", [(70001, 384, 384), (204000, 1280, 1280), (65536, 64, 128), (3000, 384, 384)])
+def test_colsum_chunked_over_the_chip(rows, cols, ld):
+    """wft_colsum_bf16_ws (large inputs: 64 row chunks, folded in chunk order) and the one-pass kernel (small inputs): column
+    sums of a bf16 matrix with a row stride, accumulate form, bitwise reproducible."""
+    g = torch.Generator().manual_seed(rows + cols)
+    buf = bf(torch.randn(rows, ld, generator=g)).to(DEV)
+    x = buf[:, :cols]
+    want = x.double().sum(0)
+    got = K.colsum(x)
+    tol = 1e-5 * x.double().abs().sum(0).max().item() + 1e-4
+    assert (got.double() - want).abs().max().item() < tol
+    assert torch.equal(K.colsum(x), got)
+    base = torch.randn(cols, generator=g).to(DEV)
+    acc = K.colsum(x, out=base.clone(), accumulate=True)
+    assert (acc.double() - (want + base.double())).abs().max().item() < tol
+    assert (L.load().wft_colsum_workspace_bytes(rows, cols) > 0) == (rows >= 65536)
+
+
 @pytest.mark.parametrize("B,H,Tq,Tk,causal", [(2, 3, 1500, 1500, False), (2, 2, 130, 130, True), (1, 2, 50, 333, False)])
 def test_attention_backward_fused_projection_bias_sums(B, H, Tq, Tk, causal):
     """dq_colsum / dv_colsum of wft_attn_bwd_bf16 = column sums of the bf16 dq / dv it wrote (ragged last 32-row groups,

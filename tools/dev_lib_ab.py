@@ -49,6 +49,12 @@ def child(what):
                 cases["none+cs"] = lambda: K.gemm_nt(a, b, out=o, colsum=cs)
             for name, fn in cases.items():
                 out[f"{N}x{Kd}:{name}"] = round(2.0 * M * N * Kd / bench(fn, 10) / 1e6, 1)  # TF/s
+    if what in ("tn", "all"):
+        R = 68 * 1500
+        for P, Q in ((1280, 1280), (3840, 1280), (5120, 1280), (1280, 5120)):
+            a = torch.randn(R, P, device=dev).bfloat16(); b = torch.randn(R, Q, device=dev).bfloat16()
+            o = torch.empty(P, Q, dtype=torch.float32, device=dev)
+            out[f"tn_{P}x{Q}"] = round(2.0 * R * P * Q / bench(lambda: K.gemm_tn(a, b, out=o), 10) / 1e6, 1)  # TF/s
     if what in ("attn", "all"):
         for tag, (B, H, Tq, Tk, causal) in {"enc": (32, 20, 1500, 1500, False), "cross": (32, 20, 128, 1500, False),
                                             "self": (32, 20, 448, 448, True)}.items():
@@ -77,11 +83,13 @@ if __name__ == "__main__":
         if args[0] == "--rounds": rounds = int(args[1])
         elif args[0] == "--what": what = args[1]
         args = args[2:]
-    libs = [a.split("=", 1) for a in args]
+    libs = [a.split("=", 1) for a in args]  # label=path[:VAR=VALUE[:VAR=VALUE ...]]
     acc = {lab: {} for lab, _ in libs}
     for rnd in range(rounds):
-        for lab, path in libs:
+        for lab, spec in libs:
+            path, *envs = spec.split(":")
             env = dict(os.environ, WFT_LIB=os.path.abspath(path))
+            env.update(dict(e.split("=", 1) for e in envs))
             r = subprocess.run([sys.executable, __file__, "child", what], env=env, capture_output=True, text=True)
             line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
             if not line:
@@ -90,6 +98,7 @@ if __name__ == "__main__":
             for k, v in json.loads(line[-1][7:]).items(): acc[lab].setdefault(k, []).append(v)
     keys = list(next(iter(acc.values())).keys()) if acc else []
     print(f"{'':28s}" + "".join(f"{lab:>26s}" for lab, _ in libs))
+    libs = [(lab, None) for lab, _ in libs]
     for k in keys:
         row = f"{k:28s}"
         for lab, _ in libs:

@@ -153,7 +153,14 @@ def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool
     if out is None:
         out = torch.empty(cols, dtype=F32, device=x.device)
         accumulate = False
-    L.check(L.load().wft_colsum_bf16(_p(x), rows, cols, x.stride(0), _p(out), int(accumulate), L.stream_ptr()), "wft_colsum_bf16")
+    lib = L.load()
+    need = lib.wft_colsum_workspace_bytes(rows, cols)
+    if need > 0:  # large inputs: chunked over the whole chip, folded in a fixed order
+        ws = _tn_workspace(x.device, need, slot="colsum")
+        L.check(lib.wft_colsum_bf16_ws(_p(x), rows, cols, x.stride(0), _p(out), int(accumulate), ws.data_ptr(), ws.numel(), L.stream_ptr()),
+                "wft_colsum_bf16_ws")
+    else:
+        L.check(lib.wft_colsum_bf16(_p(x), rows, cols, x.stride(0), _p(out), int(accumulate), L.stream_ptr()), "wft_colsum_bf16")
     return out
 
 

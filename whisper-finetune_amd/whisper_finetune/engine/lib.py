@@ -86,6 +86,8 @@ SIGNATURES = {
     "wft_axpby_bf16": [C.c_float, c_vp, C.c_float, c_vp, c_vp, c_i64, c_vp],
     "wft_dgelu_mul_bf16": [c_vp, c_vp, c_vp, c_i64, c_vp],
     "wft_colsum_bf16": [c_vp, c_i64, c_i64, c_i64, c_vp, C.c_int, c_vp],
+    "wft_colsum_bf16_ws": [c_vp, c_i64, c_i64, c_i64, c_vp, C.c_int, c_vp, c_i64, c_vp],
+    "wft_colsum_workspace_bytes": [c_i64, c_i64],
     "wft_layernorm_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_float,
                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp],
     "wft_layernorm_bwd_workspace": [c_i64, C.c_int],
@@ -133,7 +135,7 @@ SIGNATURES = {
     "wft_version": [],
 }
 _RESTYPES = {"wft_last_error": C.c_char_p, "wft_version": C.c_char_p, "wft_layernorm_bwd_workspace": c_i64,
-             "wft_gemm_tn_workspace_bytes": c_i64, "wft_gemm_nt_colsum_workspace_bytes": c_i64,
+             "wft_gemm_tn_workspace_bytes": c_i64, "wft_gemm_nt_colsum_workspace_bytes": c_i64, "wft_colsum_workspace_bytes": c_i64,
              "wft_attn_bwd_colsum_workspace_bytes": c_i64}
 
 _lib = None
