@@ -261,11 +261,12 @@ def test_product_path_refuses_cpu_tensors():
 
 def test_any_torch_optimizer_step_invalidates_bf16_shadows():
     """torch's fused optimizers do not bump tensor._version, so the shadow cache keys on an epoch that every
-    Optimizer.step() advances (engine/ops.py post-hook)."""
+    Optimizer.step() over a shadowed parameter advances (engine/ops.py post-hook)."""
     from whisper_finetune.engine import ops
 
     p = torch.nn.Parameter(torch.randn(4, 4))
     p.grad = torch.randn(4, 4)
+    ops.note_shadowed([p])  # (what LinearGroup.shadows does for the weights it casts)
     for opt in (torch.optim.AdamW([p], lr=1e-3), torch.optim.SGD([p], lr=1e-3)):
         before = ops._SHADOW_EPOCH[0]
         opt.step()
@@ -311,3 +312,24 @@ def test_lora_mask_pool_draws_once_per_forward_and_is_dropped_on_merge():
     lora.merge_lora(m)
     assert "_wft_lora_pool" not in m.__dict__ and not m._forward_pre_hooks and not m._forward_hooks
     assert not m.encoder._forward_pre_hooks and not m.decoder._forward_pre_hooks
+
+
+def test_optimizer_post_hook_only_counts_optimizers_that_own_shadowed_parameters():
+    """engine/ops.py: torch's fused optimizers do not bump tensor._version, so an optimizer step invalidates the bf16 weight
+    shadows through a global post-hook — scoped to optimizers that own a parameter the engine has shadowed: an
+    EMA / teacher optimizer over other tensors no longer forces a rebuild per step of its own."""
+    from whisper_finetune.engine import ops
+
+    mine = torch.nn.Parameter(torch.zeros(4, 4))
+    other = torch.nn.Parameter(torch.zeros(4, 4))
+    ops.note_shadowed([mine, None])
+    opt_mine, opt_other = torch.optim.SGD([mine], lr=0.1), torch.optim.SGD([other], lr=0.1)
+    mine.grad, other.grad = torch.ones(4, 4), torch.ones(4, 4)
+    e0 = ops._SHADOW_EPOCH[0]
+    opt_other.step()
+    assert ops._SHADOW_EPOCH[0] == e0
+    opt_mine.step()
+    assert ops._SHADOW_EPOCH[0] == e0 + 1
+    ops.note_shadowed([other])          # shadowed later: the cached classification is refreshed
+    opt_other.step()
+    assert ops._SHADOW_EPOCH[0] == e0 + 2

@@ -33,9 +33,37 @@ def bump_shadow_epoch():
 
 # torch's fused / foreach optimizers update parameters WITHOUT bumping `_version` (observed with
 # AdamW(fused=True): p._version stays 0 across steps), so the version part of the key cannot see them.
-# Every torch.optim.Optimizer.step() therefore invalidates the shadows through a global post-hook.
+# A torch.optim.Optimizer.step() therefore invalidates the shadows through a global post-hook — but only a step of an
+# optimizer that owns at least one parameter the engine has shadowed (an EMA / teacher optimizer over other tensors used to
+# force a rebuild of every shadow per step of its own).
+_SHADOWED = {}          # id(tensor) -> weakref: fp32 parameters (and conv weights) that have bf16 shadows somewhere in the process
+_SHADOWED_GEN = [0]     # bumped whenever the registry changes (optimizers re-classify themselves lazily)
+
+
+def note_shadowed(tensors) -> None:
+    for t in tensors:
+        if t is None or not t.requires_grad:
+            continue
+        r = _SHADOWED.get(id(t))
+        if r is None or r() is not t:
+            key = id(t)
+
+            def _gone(_, key=key):
+                _SHADOWED.pop(key, None)
+                _SHADOWED_GEN[0] += 1
+
+            _SHADOWED[key] = weakref.ref(t, _gone)
+            _SHADOWED_GEN[0] += 1
+
+
 def _optimizer_post_hook(optimizer, args, kwargs):
-    bump_shadow_epoch()
+    gen = _SHADOWED_GEN[0]
+    owns = optimizer.__dict__.get("_wft_owns_shadowed")
+    if owns is None or owns[0] != gen:  # (re-)classify when the set of shadowed parameters has changed
+        hit = any((r := _SHADOWED.get(id(p))) is not None and r() is p for g in optimizer.param_groups for p in g["params"])
+        owns = optimizer.__dict__["_wft_owns_shadowed"] = (gen, hit)
+    if owns[1]:
+        bump_shadow_epoch()
 
 
 register_optimizer_step_post_hook(_optimizer_post_hook)
@@ -121,6 +149,7 @@ class LinearGroup:
                 and id(self) in _PLAIN_PLAN.groups and self.WT is not None:
             _PLAIN_PLAN.refresh()  # every trainable group's shadows in one launch; sets self.key if this group took part
         if key != self.key:
+            note_shadowed(list(weights) + list(biases) + ([x for sp in loras if sp is not None for x in (sp.A, sp.B)] if loras else []))
             n, k, npad = self.dims(weights)
             dev = weights[0].device
             if self.W is None or self.W.shape != (npad, k):
@@ -759,6 +788,7 @@ class ConvStemFn(torch.autograd.Function):
         dev = mel_t.device
         key = (_ver(w1), _ver(w2), _ver(pos), _SHADOW_EPOCH[0])
         if cache.get("key") != key:
+            note_shadowed((w1, w2))
             n_mels = w1.shape[1]
             w1p = torch.zeros((d, 3, c_pad), dtype=F32, device=dev)
             w1p[:, :, :n_mels] = w1.detach().permute(0, 2, 1)
