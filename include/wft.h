@@ -116,7 +116,9 @@ int wft_layernorm_fwd(const wft_bf16* x, const float* gamma, const float* beta,
                       int64_t rows, int cols, float eps,
                       int rows_per_batch, int t0, int t1, int c0, int c1,
                       void* stream);
-/* dx = LN'(dy) (+ dres if dres != NULL); dgamma/dbeta are WRITTEN (=; no zero-fill needed).
+/* dx = LN'(dy) (+ dres if dres != NULL); dgamma/dbeta are WRITTEN (=; no zero-fill needed) or both NULL (frozen LayerNorm
+ * parameters: with dx_colsum NULL as well — a LoRA run — the partial sums and the two reduce launches are skipped and
+ * `partial` may be NULL).
  * partial: f32 workspace of wft_layernorm_bwd_workspace(rows, cols) bytes.
  * The same mask arguments zero the masked positions of dy first.
  * dx_colsum (f32 [cols] or NULL): column sums of the bf16 dx just written — dx is the gradient of the residual

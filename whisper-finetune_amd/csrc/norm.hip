@@ -232,6 +232,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const unsigned short* dy, c
     }
   }
   // block reduction of dgamma/dbeta partials, one piece-slot at a time through LDS
+  if (partial == nullptr) return;  // frozen gamma / beta and no column sums wanted (a LoRA run): dx was everything
   float* pg = partial + (long)blockIdx.x * (DXSUM ? 3 : 2) * cols;
   float* pb = pg + cols;
   float* ps = pb + cols;
@@ -286,8 +287,10 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* partial
       for (int k = 0; k < 3; ++k)
         if (k < nset) mp[(long)k * cols] = tot[k];
     } else {
-      dgamma[col] = tot[0];
-      dbeta[col] = tot[1];
+      if (dgamma) {
+        dgamma[col] = tot[0];
+        dbeta[col] = tot[1];
+      }
       if (dxsum) dxsum[col] = tot[2];
     }
   }
@@ -349,9 +352,13 @@ extern "C" int wft_layernorm_bwd(const wft_bf16* dy, const wft_bf16* x, const fl
                                  const float* rstd, const wft_bf16* dres, wft_bf16* dx, float* dgamma,
                                  float* dbeta, float* dx_colsum, void* partial, int64_t rows, int cols,
                                  int rows_per_batch, int t0, int t1, int c0, int c1, void* stream) {
-  WFT_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && partial, "null pointer");
+  WFT_CHECK_ARG(dy && x && gamma && mean && rstd && dx, "null pointer");
+  WFT_CHECK_ARG((dgamma != nullptr) == (dbeta != nullptr), "dgamma and dbeta go together (both or neither)");
+  const bool want_params = dgamma != nullptr;
+  WFT_CHECK_ARG(partial || (!want_params && !dx_colsum), "the partial-sum workspace is required unless dgamma, dbeta and dx_colsum are all NULL");
   WFT_CHECK_ARG(rows >= 1 && cols >= 8 && cols % 8 == 0 && cols <= 2048, "cols must be a multiple of 8, <= 2048");
   const int grid = ln_grid(rows);
+  if (!want_params && !dx_colsum) partial = nullptr;  // nothing to reduce: the kernel stops after dx, no reduce launches
   // VAR 2 (non-temporal dy / x / dres loads and dx stores) for tensors the caches cannot keep; WFT_LN_BWD_VAR forces one
   static int forced = -2;
   if (forced == -2) { const char* e = getenv("WFT_LN_BWD_VAR"); forced = e ? atoi(e) : -1; }
@@ -368,6 +375,10 @@ extern "C" int wft_layernorm_bwd(const wft_bf16* dy, const wft_bf16* x, const fl
 #undef LN_BWD_T
 #undef LN_BWD_F
 #undef LN_BWD_LAUNCH
+  if (!partial) {
+    WFT_CHECK_LAUNCH();
+    return WFT_OK;
+  }
   const int nset = dx_colsum ? 3 : 2;
   float* mid = (float*)partial + (long)grid * nset * cols;
   hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((cols + 63) / 64, LN_RED_CHUNKS), dim3(256), 0, (hipStream_t)stream,

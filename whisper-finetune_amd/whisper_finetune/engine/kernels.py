@@ -183,9 +183,9 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, mask=None):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, mask=None, want_colsum=False):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, mask=None, want_colsum=False, want_params=True):
     """returns dx bf16, dgamma f32, dbeta f32 (fresh tensors, each its own allocation so that autograd can keep them as
-    the .grad without a copy) [, colsum(dx) f32 if want_colsum]."""
+    the .grad without a copy; None, None with want_params=False: frozen LayerNorm parameters) [, colsum(dx) f32 if want_colsum]."""
     _chk(dy, BF16, "dy"); _chk(x, BF16, "x")
     dy = dy.contiguous(); x = x.contiguous()
     if dres is not None:
@@ -194,10 +194,11 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, mask=None, want_colsum=Fa
     cols = x.shape[-1]
     rows = x.numel() // cols
     lib = L.load()
-    ws = torch.empty(lib.wft_layernorm_bwd_workspace(rows, cols), dtype=torch.uint8, device=x.device)
+    need_ws = want_params or want_colsum
+    ws = torch.empty(lib.wft_layernorm_bwd_workspace(rows, cols), dtype=torch.uint8, device=x.device) if need_ws else None
     dx = torch.empty_like(x)
-    dgamma = torch.empty(cols, dtype=F32, device=x.device)
-    dbeta = torch.empty(cols, dtype=F32, device=x.device)
+    dgamma = torch.empty(cols, dtype=F32, device=x.device) if want_params else None
+    dbeta = torch.empty(cols, dtype=F32, device=x.device) if want_params else None
     dxs = torch.empty(cols, dtype=F32, device=x.device) if want_colsum else None
     rpb, t0, t1, c0, c1 = mask if mask is not None else (0, 0, 0, 0, 0)
     L.check(

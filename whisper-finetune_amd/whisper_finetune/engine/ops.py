@@ -459,6 +459,7 @@ class LinearFn(torch.autograd.Function):
             y = K.gemm_nt(x, W, bias=bias, residual=residual)
         ctx.cfg = cfg
         ctx.has_res = residual is not None
+        ctx.want_cs = BIAS_GRADS[0]
         ctx.dims = (n, k, npad, kpad)
         ctx.save_for_backward(x, gelu_pre, out_pre, *params)
         if cfg.gelu_out:
@@ -489,9 +490,10 @@ class LinearFn(torch.autograd.Function):
             if gelu_pre is not None:
                 # dpre is the dy of the Linear that produced gelu_pre: its bias gradient (column sums) comes out of this
                 # GEMM's epilogue (see _publish_colsum / _fused_colsum)
-                cs = torch.empty(WT.shape[0], dtype=F32, device=dy.device)
+                cs = torch.empty(WT.shape[0], dtype=F32, device=dy.device) if ctx.want_cs else None
                 dpre = K.gemm_nt(dy, WT, epilogue=L.EPI_MUL_AUX if _GELU_PAIR else L.EPI_DGELU, aux=gelu_pre, colsum=cs)
-                _publish_colsum(dpre, cs)
+                if cs is not None:
+                    _publish_colsum(dpre, cs)
             else:
                 dx = K.gemm_nt(dy, WT)
         out: List[Optional[torch.Tensor]] = [dx, dy if ctx.has_res else None, dpre, None]
@@ -595,6 +597,10 @@ def _stacked_masks(specs):
 
 
 _COLSUMS = {}  # data_ptr -> (producing tensor, colsum)
+# Does any bias of the running model take a gradient?  Set by the model at the start of every forward (Whisper.forward /
+# forward_loss).  False in a LoRA run (frozen base): the producer kernels then skip the fused bias-gradient column sums and
+# their reduce launches (LayerNorm backward, attention backward, the DGELU / MUL_AUX GEMM epilogue).
+BIAS_GRADS = [True]
 # whisper's key projection has no bias; a model that gives it one (not whisper) must set this so that the fused q/k/v column
 # sums (which leave the k slice at zero) are not used for it
 _K_HAS_BIAS = [False]
@@ -674,16 +680,19 @@ class LayerNormFn(torch.autograd.Function):
         y, mean, rstd = K.layernorm_fwd(x.reshape(-1, shape[-1]), gamma.detach(), beta.detach(), eps, mask)
         ctx.save_for_backward(x, gamma, mean, rstd)
         ctx.mask = mask
+        ctx.want_cs = BIAS_GRADS[0]
         return y.view(shape)
 
     @staticmethod
     def backward(ctx, dy):
         x, gamma, mean, rstd = ctx.saved_tensors
         shape = x.shape
-        dx, dg, db, cs = K.layernorm_bwd(dy.reshape(-1, shape[-1]).to(BF16), x.reshape(-1, shape[-1]), gamma.detach(), mean,
-                                         rstd, None, ctx.mask, want_colsum=True)
-        dx = dx.view(shape)
-        _publish_colsum(dx, cs)  # dx is the dy of the Linear that wrote x: its bias gradient, for free
+        want_cs, want_p = ctx.want_cs, ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        res = K.layernorm_bwd(dy.reshape(-1, shape[-1]).to(BF16), x.reshape(-1, shape[-1]), gamma.detach(), mean,
+                              rstd, None, ctx.mask, want_colsum=want_cs, want_params=want_p)
+        dx, dg, db = res[0].view(shape), res[1], res[2]
+        if want_cs:
+            _publish_colsum(dx, res[3])  # dx is the dy of the Linear that wrote x: its bias gradient, for free
         return dx, dg, db, None, None
 
 
@@ -698,6 +707,7 @@ class LayerNormForkFn(torch.autograd.Function):
         y, mean, rstd = K.layernorm_fwd(x.reshape(-1, shape[-1]), gamma.detach(), beta.detach(), eps, mask)
         ctx.save_for_backward(x, gamma, mean, rstd)
         ctx.mask = mask
+        ctx.want_cs = BIAS_GRADS[0]
         return y.view(shape), x.view_as(x)
 
     @staticmethod
@@ -707,10 +717,12 @@ class LayerNormForkFn(torch.autograd.Function):
         if dy is None:
             return dres, None, None, None, None
         dr = None if dres is None else dres.reshape(-1, shape[-1]).to(BF16)
-        dx, dg, db, cs = K.layernorm_bwd(dy.reshape(-1, shape[-1]).to(BF16), x.reshape(-1, shape[-1]), gamma.detach(), mean,
-                                         rstd, dr, ctx.mask, want_colsum=True)
-        dx = dx.view(shape)
-        _publish_colsum(dx, cs)
+        want_cs, want_p = ctx.want_cs, ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        res = K.layernorm_bwd(dy.reshape(-1, shape[-1]).to(BF16), x.reshape(-1, shape[-1]), gamma.detach(), mean,
+                              rstd, dr, ctx.mask, want_colsum=want_cs, want_params=want_p)
+        dx, dg, db = res[0].view(shape), res[1], res[2]
+        if want_cs:
+            _publish_colsum(dx, res[3])
         return dx, dg, db, None, None
 
 
@@ -726,6 +738,7 @@ class SelfAttnFn(torch.autograd.Function):
         o, lse = K.attn_fwd(q, k, v, n_head, causal, scale)
         ctx.save_for_backward(qkv, o, lse)
         ctx.cfg = (n_head, causal, scale)
+        ctx.want_cs = BIAS_GRADS[0]
         return o
 
     @staticmethod
@@ -734,10 +747,11 @@ class SelfAttnFn(torch.autograd.Function):
         n_head, causal, scale = ctx.cfg
         d = qkv.shape[-1] // 3
         dqkv = torch.empty_like(qkv)
-        cs = torch.zeros(3 * d, dtype=F32, device=qkv.device)  # [q | k (no bias in whisper: stays 0) | v]
+        want_cs = ctx.want_cs
+        cs = torch.zeros(3 * d, dtype=F32, device=qkv.device) if want_cs else None  # [q | k (no bias in whisper: stays 0) | v]
         K.attn_bwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], o, lse, do.to(BF16), n_head, causal, scale,
-                   dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:], colsums=(cs[:d], cs[2 * d:]))
-        if not _K_HAS_BIAS[0]:
+                   dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:], colsums=(cs[:d], cs[2 * d:]) if want_cs else None)
+        if want_cs and not _K_HAS_BIAS[0]:
             _publish_colsum(dqkv, cs)  # bias gradients of the fused q/k/v projection, summed in the kernels' epilogues
         return dqkv, None, None
 
@@ -752,6 +766,7 @@ class CrossAttnFn(torch.autograd.Function):
         o, lse = K.attn_fwd(q, kv[..., :d], kv[..., d:], n_head, False, scale)
         ctx.save_for_backward(q, kv, o, lse)
         ctx.cfg = (n_head, scale)
+        ctx.want_cs = BIAS_GRADS[0]
         return o
 
     @staticmethod
@@ -761,13 +776,15 @@ class CrossAttnFn(torch.autograd.Function):
         d = q.shape[-1]
         dq = torch.empty_like(q)
         dkv = torch.empty_like(kv)
-        cs_q = torch.empty(d, dtype=F32, device=q.device)
-        cs_kv = torch.zeros(2 * d, dtype=F32, device=q.device)  # [k (no bias) | v]
+        want_cs = ctx.want_cs
+        cs_q = torch.empty(d, dtype=F32, device=q.device) if want_cs else None
+        cs_kv = torch.zeros(2 * d, dtype=F32, device=q.device) if want_cs else None  # [k (no bias) | v]
         K.attn_bwd(q, kv[..., :d], kv[..., d:], o, lse, do.to(BF16), n_head, False, scale, dq=dq, dk=dkv[..., :d], dv=dkv[..., d:],
-                   colsums=(cs_q, cs_kv[d:]))
-        _publish_colsum(dq, cs_q)
-        if not _K_HAS_BIAS[0]:
-            _publish_colsum(dkv, cs_kv)
+                   colsums=(cs_q, cs_kv[d:]) if want_cs else None)
+        if want_cs:
+            _publish_colsum(dq, cs_q)
+            if not _K_HAS_BIAS[0]:
+                _publish_colsum(dkv, cs_kv)
         return dq, dkv, None
 
 

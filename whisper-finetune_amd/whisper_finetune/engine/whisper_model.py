@@ -368,6 +368,9 @@ class Whisper(nn.Module):
         """logits f32 [B, S, V] — or, when `targets` is given (engine extension used by train_step, also
         through a DDP wrapper), the fused label-smoothed cross-entropy loss."""
         ops.reset_colsums()  # stale fused bias-gradient entries of an earlier backward pass (engine/ops.py)
+        # a hint for the producer kernels (captured per autograd node at forward time): with every bias frozen (a LoRA run)
+        # nobody will ask for the fused bias-gradient column sums
+        ops.BIAS_GRADS[0] = any(p.requires_grad for n, p in self.named_parameters() if n.endswith("bias"))
         if targets is not None:
             return self.forward_loss(mel, tokens, targets, label_smoothing)
         return self.decoder(tokens, self.encoder(mel))
