@@ -231,9 +231,19 @@ __device__ __forceinline__ void nt_wait_ring(int h, u32x4& q) {
 #undef WFT_VM_CASE
 }
 
+// WFT_NT_RING slots of 32 KiB (A [256][32] | B [256][32]).  5 (round 3): all 160 KiB of LDS are ring, the LDS-DMA runs FOUR slabs
+// ahead of the reads (3.1 us instead of 2.3: in-kernel stamps showed the main loop of tiles that open a fresh A panel 25 %
+// slower than the others — HBM misses longer than the lookahead), slot numbers run on across tiles, and the staged epilogue
+// borrows the one slot that is free at the seam (the slot of the tile's last slab: the next tile's slabs 0-3 sit in the other
+// four, slab 4 is staged into it by the next tile's first L-unit, behind the tile-start barrier).  4: the round-2 layout
+// (lookahead 3, a separate 32 KiB staging area).
+#ifndef WFT_NT_RING
+#define WFT_NT_RING 5
+#endif
 template <int EPI, bool C_F32>
 __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
-  extern __shared__ __attribute__((aligned(16))) char dsmem[];  // 128 KiB ring + 32 KiB epilogue staging
+  constexpr int NSLOT = WFT_NT_RING, LA = NSLOT - 1;  // ring slots, lookahead in slabs
+  extern __shared__ __attribute__((aligned(16))) char dsmem[];  // the ring (+ 32 KiB epilogue staging when NSLOT == 4)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -275,8 +285,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
     }
   };
   const unsigned stage_dst = __builtin_amdgcn_readfirstlane(lds_addr_of(dsmem) + (grp_b ? 16384 : 0) + (wave & 3) * 4096);
-  auto stage = [&](int u) {  // this wave's 4 KiB of slab u -> ring slot u & 3
-    const unsigned dst = stage_dst + (u & 3) * 32768;
+  auto stage = [&](int u, int slot_dst) {  // this wave's 4 KiB of slab u of the tile `sbase` points at -> ring slot slot_dst
+    const unsigned dst = stage_dst + slot_dst * 32768;
     const unsigned long long sb = (unsigned long long)sbase + (unsigned long long)u * 64;  // wave-uniform
 #pragma unroll
     for (int j = 0; j < 4; ++j) glds16_saddr(soff[j], sb, dst + j * 1024);
@@ -287,10 +297,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
   const int coff = (fg ^ nt_g(frow)) << 4;
   const int a_off = (wm * 128 + frow) * 64 + coff;
   const int b_off = 16384 + (wn * 64 + frow) * 64 + coff;
-  auto prefetch = [&]() {  // shares of slabs 0..2 of the tile `src` points at
-    stage(0);
-    if (nslab > 1) stage(1);
-    if (nslab > 2) stage(2);
+  int slot = 0;  // ring slot of the slab the next L-unit reads; runs on across tiles (wave-uniform scalar)
+  auto slot_add = [&](int s_, int d) { const int x = s_ + d; return x >= NSLOT ? x - NSLOT : x; };
+  auto prefetch = [&]() {  // shares of slabs 0 .. LA-1 of the tile `src` points at, into the slots the next tile will read
+#pragma unroll
+    for (int j = 0; j < LA; ++j)
+      if (j < nslab) stage(j, slot_add(slot, j));
   };
 
   int t = blockIdx.x;
@@ -311,9 +323,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 af[8], bq[4];
 
-    // slab 0 complete (its 4 glds are older than everything issued since: epilogue stores, slabs 1-2)
-    if (nslab > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (nslab > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    // slab 0 complete (its 4 glds are older than everything issued since: epilogue stores, slabs 1 .. LA-1)
+    if (nslab >= LA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (LA - 1)) : "memory");
+    else if (nslab == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nslab == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (grp_b) __builtin_amdgcn_s_barrier();  // group B runs half a period behind group A
@@ -323,28 +336,32 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
     // LDS-DMA pieces are issued beside the partner group's MFMAs like every other slab, not in the epilogue where both
     // groups pay their issue cost with nothing to hide it (stamps: 1-2 us per tile), and the waits never drain.
     const bool more = t + (int)gridDim.x < total;
-    const bool cont = more && (nslab & 3) == 0 && nslab >= 8 && p.diag != 8;
+    const bool cont = more && (NSLOT == 5 || (nslab & 3) == 0) && nslab >= 8 && p.diag != 8;  // (4 slots: slot = u & 3 needs nslab % 4 == 0)
     for (int u = 0; u < nslab; ++u) {
       // ---------------- L-unit (fragment reads first: their latency hides behind the LDS-DMA issue)
       {
-        const char* sl = dsmem + (u & 3) * 32768;
+        const char* sl = dsmem + slot * 32768;
 #pragma unroll
         for (int j = 0; j < 4; ++j) bq[j] = *(const bf16x8*)(sl + b_off + j * 1024);
 #pragma unroll
         for (int i = 0; i < 8; ++i) af[i] = *(const bf16x8*)(sl + a_off + i * 1024);
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (u + 3 < nslab) {
-        stage(u + 3);
-      } else if (cont) {
-        if (u + 3 == nslab) set_src(t + gridDim.x);  // this tile's source addresses are not needed any more
-        stage(u + 3 - nslab);
+      {
+        const int sdst = slot == 0 ? NSLOT - 1 : slot - 1;  // slot (u + LA) mod NSLOT: slab u - 1 has just left it
+        if (u + LA < nslab) {
+          stage(u + LA, sdst);
+        } else if (cont) {
+          if (u + LA == nslab) set_src(t + gridDim.x);  // this tile's source addresses are not needed any more
+          stage(u + LA - nslab, sdst);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      // slab u+1's share (issued three L-units ago) must have landed before the partner group reads it
+      // slab u+1's share (issued LA L-units ago) must have landed before the partner group reads it
       const int ahead = nslab - 1 - u;
-      if (ahead >= 3 || cont) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      if (ahead >= LA || cont) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (LA - 1)) : "memory");
+      else if (ahead == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else if (ahead == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -359,8 +376,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
+      slot = slot + 1 == NSLOT ? 0 : slot + 1;
     }
     if (!grp_b) __builtin_amdgcn_s_barrier();  // group A idles through group B's last C-unit
+    const int free_slot = slot == 0 ? NSLOT - 1 : slot - 1;  // the tile's last slab has left it; nothing is staged into it before the next tile's first L-unit
 
     // the ring is free: put the next tile's first three slabs in flight, then write this tile out
     const bool staged = !C_F32 && p.diag != 6;
@@ -389,7 +408,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
       // most N younger operations outstanding" is exact when every operation of the body is known.  The two bodies are
       // separate copies of the code: a register that an asm load is still filling must never be copied, and a wait that
       // exists on one side of a branch only makes hipcc copy the ring at the join.
-      char* lds = dsmem + 131072 + wave * 4096;
+      char* lds = dsmem + (NSLOT == 4 ? 131072 : free_slot * 32768) + wave * 4096;
       const int er = lane >> 3, ec = (lane & 7) * 8;  // row within an 8-row group, first of this lane's 8 columns
       const int ncol = n0 + wn * 64 + ec;
       auto body = [&](auto cnt_c) {
