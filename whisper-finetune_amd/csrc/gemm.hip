@@ -231,14 +231,16 @@ __device__ __forceinline__ void nt_wait_ring(int h, u32x4& q) {
 #undef WFT_VM_CASE
 }
 
-// WFT_NT_RING slots of 32 KiB (A [256][32] | B [256][32]).  5 (round 3): all 160 KiB of LDS are ring, the LDS-DMA runs FOUR slabs
-// ahead of the reads (3.1 us instead of 2.3: in-kernel stamps showed the main loop of tiles that open a fresh A panel 25 %
-// slower than the others — HBM misses longer than the lookahead), slot numbers run on across tiles, and the staged epilogue
-// borrows the one slot that is free at the seam (the slot of the tile's last slab: the next tile's slabs 0-3 sit in the other
-// four, slab 4 is staged into it by the next tile's first L-unit, behind the tile-start barrier).  4: the round-2 layout
-// (lookahead 3, a separate 32 KiB staging area).
+// WFT_NT_RING slots of 32 KiB (A [256][32] | B [256][32]), LDS-DMA running WFT_NT_RING - 1 slabs ahead of the reads.
+// 4 (default): lookahead 3 and a separate 32 KiB staging area for the epilogue.  5 (round 3, built and measured): all 160 KiB are
+// ring, lookahead 4 (3.1 us instead of 2.3), slot numbers run on across tiles and the staged epilogue borrows the one slot that
+// is free at the seam (the slot of the tile's last slab: the next tile's slabs 0-3 sit in the other four, slab 4 is staged into
+// it by the next tile's first L-unit, behind the tile-start barrier).  With operands streamed from HBM (a GEMM run back to back
+// on 261 MB activations) the deeper lookahead is worth +3-6 % — in-kernel stamps had shown tiles that open a fresh A panel
+// 25 % slower than the others; inside the training step the operands were written just before and come from the Infinity
+// Cache: 700.1 vs 701.7 ms per step, no gain (profiles/r03_nt256_ring5_ab.log, r03_step_ring_ab.log).
 #ifndef WFT_NT_RING
-#define WFT_NT_RING 5
+#define WFT_NT_RING 4
 #endif
 template <int EPI, bool C_F32>
 __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
@@ -1142,8 +1144,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_rank_kernel(GemmP p) {
 // the A part, group B the B part, counted vmcnt(8).  Fragments are transposed LDS reads
 // (ds_read_b64_tr_b16) with the pair swizzle of the 128 kernel.  Split-K partials are added to C with
 // fp32 atomics issued as contiguous 256-byte half rows staged through LDS.
+#ifndef WFT_TN_RING
+#define WFT_TN_RING 4  // ring slots of 32 KiB (lookahead = slots - 1); 5 measured +-0.5 % here (profiles/r03_tn_ring5_ab.log): the long reduction loop of one tile per workgroup is not stall-bound the way the NT kernel's fresh operand panels are
+#endif
 template <bool C_F32>
 __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmP p) {
+  constexpr int NSLOT = WFT_TN_RING, LA = NSLOT - 1;
   extern __shared__ __attribute__((aligned(16))) char dsmem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1194,17 +1200,18 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmP p) {
   // (batch item, slab-in-item) of the next slab to stage / to read, advanced incrementally (no division in the loop)
   int ld_b = s_begin / spb, ld_t = s_begin - ld_b * spb;
   int rd_t = ld_t;
-  auto stage = [&](int u) {  // local slab index u -> ring slot u & 3; rows past R are clamped (masked at read time)
+  int ld_slot = 0, rd_slot = 0;  // ring slots of the next slab to stage / to read (stage() is called in slab order)
+  auto stage = [&](int u) {  // local slab index u -> ring slot u mod NSLOT; rows past R are clamped (masked at read time)
     const unsigned short* base = gbase + (long)ld_b * gbs + col0;
     if (ld_t * 32 + 32 <= R) {
       const unsigned long long b64 = (unsigned long long)(base + (long)ld_t * 32 * gld);
       const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b64), hi = __builtin_amdgcn_readfirstlane((unsigned)(b64 >> 32));
       const unsigned long long sb = ((unsigned long long)hi << 32) | lo;
-      const unsigned dsts = stage_dst_s + (u & 3) * 32768;
+      const unsigned dsts = stage_dst_s + ld_slot * 32768;
 #pragma unroll
       for (int j = 0; j < 4; ++j) glds16_saddr(soff[j], sb, dsts + j * 1024);
     } else {
-      char* dst = stage_dst + (u & 3) * 32768;
+      char* dst = stage_dst + ld_slot * 32768;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int r = (wave & 3) * 8 + j * 2 + rr;
@@ -1215,6 +1222,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmP p) {
       }
     }
     if (++ld_t == spb) { ld_t = 0; ++ld_b; }
+    ld_slot = ld_slot + 1 == NSLOT ? 0 : ld_slot + 1;
   };
   const int rem_last = R - (spb - 1) * 32;  // valid rows of the last slab of a batch item (32 = full)
 
@@ -1237,11 +1245,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmP p) {
   };
   s16x4 qh[8][2], ph[4][2];  // raw halves of the fragments (inline-asm reads: waited for by hand below)
 
-  stage(0);
-  if (nslab > 1) stage(1);
-  if (nslab > 2) stage(2);
-  if (nslab > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if (nslab > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < LA; ++j)
+    if (j < nslab) stage(j);
+  if (nslab >= LA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (LA - 1)) : "memory");
+  else if (nslab == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (nslab == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (grp_b) __builtin_amdgcn_s_barrier();
@@ -1249,9 +1258,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmP p) {
   bf16x8 qf[8], pf[4];
   for (int u = 0; u < nslab; ++u) {
     // ---------------- L-unit
-    if (u + 3 < nslab) stage(u + 3);
+    if (u + LA < nslab) stage(u + LA);
     {
-      const unsigned sa = lds0 + (u & 3) * 32768;
+      const unsigned sa = lds0 + rd_slot * 32768;
       const unsigned sb = sa + 16384;
       // the second 4-row group of a fragment is +4 rows = +2048 B: in the instruction's immediate, not a second address
 #pragma unroll
@@ -1295,7 +1304,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmP p) {
     }
     if (++rd_t == spb) rd_t = 0;
     const int ahead = nslab - 1 - u;
-    if (ahead >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (ahead >= LA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (LA - 1)) : "memory");
+    else if (ahead == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (ahead == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -1310,6 +1320,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmP p) {
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
+    rd_slot = rd_slot + 1 == NSLOT ? 0 : rd_slot + 1;
   }
   if (!grp_b) __builtin_amdgcn_s_barrier();
 
@@ -1694,9 +1705,9 @@ extern "C" int wft_gemm_tn_bf16(const wft_gemm_args* a, void* stream) {
       (void)hipMemset2DAsync(a->C, (size_t)a->ldc * 4, 0, (size_t)a->N * 4, (size_t)a->M, s);
     static DynLdsOnce once;
     auto kfn = gemm_tn256_kernel<true>;
-    once.set(kfn, 131072);
+    once.set(kfn, WFT_TN_RING * 32768);
     p.nsplit = g_diag == 20 ? -nsplit : nsplit;  // (WFT_GEMM_DIAG=20: round 2's tile-major placement, A/B runs)
-    hipLaunchKernelGGL(kfn, dim3((unsigned)(t256 * nsplit)), dim3(512), 131072, s, p);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)(t256 * nsplit)), dim3(512), WFT_TN_RING * 32768, s, p);
     if (use_ws) {
       const long total = a->M * (a->N / 4);
       long g = (total + 255) / 256;
