@@ -218,6 +218,14 @@ int64_t wft_gemm_nt_colsum_workspace_bytes(const wft_gemm_args* args);
  *  Uses the same wft_gemm_args: M:=P, N:=Q, K:=R; bias/residual/aux ignored.
  *  batch > 1 sums over the batch as extra reduction (conv weight grads).     */
 int wft_gemm_tn_bf16(const wft_gemm_args* args, void* stream);
+/* Two independent rank-r products (p_valid > 0) in ONE launch of the load-stream kernels — the backward of an adapted Linear
+ * group in the reference's parametrization (src/whisper_finetune/model/lora.py:30-71 via minLoRA; loss.backward() at
+ * model/model_utils.py:63-72) needs {u = x (sA*m)^T, du = dy (sB)} and then {dA = du^T x, dB^T = u^T dy}: each pair is one call.
+ * Same arguments, same results (bit for bit) as two calls of wft_gemm_nt_bf16 / wft_gemm_tn_bf16, which is also the fallback
+ * for anything the load-stream kernels do not take.  The TN pair needs a separate workspace per product
+ * (wft_gemm_tn_workspace_bytes each); its two split-K reduces (column scale / block layout included) are one launch too.   */
+int wft_gemm_nt_rank_pair_bf16(const wft_gemm_args* args0, const wft_gemm_args* args1, void* stream);
+int wft_gemm_tn_rank_pair_bf16(const wft_gemm_args* args0, const wft_gemm_args* args1, void* stream);
 int64_t wft_gemm_tn_workspace_bytes(const wft_gemm_args* args);
 
 /* -------------------------------------------------------------- Attention */

@@ -535,6 +535,36 @@ def test_gemm_tn_adapter_gradient_outputs(R, Q, nb, r):
         K.gemm_tn(a, b, col_scale=scale)  # only for rank-r operands
 
 
+@pytest.mark.parametrize("M,Kx,Ny,nb,r", [(48000, 1280, 1280, 1, 16), (4096, 1280, 3840, 3, 16), (3001, 384, 1280, 2, 8), (130, 5120, 1280, 1, 64)])
+def test_rank_pair_launches_are_bit_identical_to_the_single_ones(M, Kx, Ny, nb, r):
+    """wft_gemm_nt_rank_pair_bf16 / wft_gemm_tn_rank_pair_bf16: the four rank-r products of an adapted group's backward as two
+    paired launches (+ one reduce launch) give exactly what the four single calls give — ragged M, one to three adapters,
+    column scale and block layout included; unequal rank blocks fall back to the single entry points."""
+    g = torch.Generator().manual_seed(M + Kx + Ny)
+    rtot = nb * r
+    x = bf(torch.randn(M, Kx, generator=g)).to(DEV); dy = bf(torch.randn(M, Ny, generator=g)).to(DEV)
+    Am = torch.zeros(128, Kx); Am[:rtot] = torch.randn(rtot, Kx, generator=g) * 0.1
+    BbT = torch.zeros(128, Ny); BbT[:rtot] = torch.randn(rtot, Ny, generator=g) * 0.1
+    Am, BbT = bf(Am).to(DEV), bf(BbT).to(DEV)
+    pvb = 16 * ((rtot + 15) // 16)
+    du1, u1 = K.gemm_nt(dy, BbT, p_valid=rtot), K.gemm_nt(x, Am, p_valid=rtot)
+    du2, u2 = K.gemm_nt_rank_pair(dy, BbT, x, Am, rtot)
+    assert torch.equal(du1[:, :pvb], du2[:, :pvb]) and torch.equal(u1[:, :pvb], u2[:, :pvb])
+    mask = (torch.rand(nb, Kx, generator=g) < 0.9).float().mul(1 / 0.9).to(DEV)
+    n0 = Ny // nb
+    kw_a = dict(a=du1, b=x, p_valid=rtot, col_scale=mask, scale_rows=r if nb > 1 else 0)
+    kw_b = dict(a=u1, b=dy, p_valid=rtot, block_n=n0, block_r=r)
+    dA1, dB1 = K.gemm_tn(**kw_a), K.gemm_tn(**kw_b)
+    dA2, dB2 = K.gemm_tn_rank_pair(kw_a, kw_b)
+    assert torch.equal(dA1, dA2) and torch.equal(dB1, dB2)
+    for _ in range(2):
+        dA3, dB3 = K.gemm_tn_rank_pair(kw_a, kw_b)
+        assert torch.equal(dA3, dA2) and torch.equal(dB3, dB2)
+    # different rank blocks in the two products: the library falls back to two single launches
+    du4, u4 = K.gemm_nt_rank_pair(dy, BbT, x, Am, rtot) if rtot > 16 else (du2, u2)
+    assert torch.equal(du4[:, :pvb], du2[:, :pvb])
+
+
 @pytest.mark.parametrize("M,Kd,rc", [(48000, 1280, 16), (4096, 5120, 48), (3001, 384, 64), (100, 128, 32), (1, 64, 16)])
 def test_gemm_nt_p_valid_writes_only_the_rank_columns(M, Kd, rc):
     """u = x (sA*mask)^T / du = dy (sB): the rank-r operand sits in the first rows of a 128-row zero-padded buffer; p_valid selects the

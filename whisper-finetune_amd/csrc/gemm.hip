@@ -850,7 +850,13 @@ __device__ __forceinline__ bf16x8 lds_b128_asm(unsigned lds_byte_addr) {
   return r;
 }
 template <int PB>
-__global__ __launch_bounds__(256, 2) void gemm_nt_rank_kernel(GemmP p) {
+__global__ __launch_bounds__(256, 2) void gemm_nt_rank_kernel(GemmP pa, GemmP pb, int na) {
+  // TWO independent products in one launch (round 3: u = x (sA*m)^T and du = dy (sB) of one adapted Linear group — each alone is
+  // 375 workgroups at 32 clips, 1.46 rounds of the chip): workgroups >= na work on the second parameter set.  A single product
+  // passes na = gridDim.x.
+  const bool second = (int)blockIdx.x >= na;  // workgroup-uniform
+  const GemmP& p = second ? pb : pa;
+  const int bid = (int)blockIdx.x - (second ? na : 0);
   constexpr int NST = PB <= 2 ? 4 : 3;
   constexpr int BBYTES = 2048 * PB;
   constexpr int SBYTES = 16384 + BBYTES;  // stage = A part, then B part
@@ -859,7 +865,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_rank_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char dsmem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m0 = blockIdx.x << 7;
+  const int m0 = bid << 7;
   const int lr = lane >> 3, lc = lane & 7;
   // per-lane source pointers of the staging instructions (row of the piece, swizzled 16-byte chunk), advanced by 64 k per step
   const unsigned short* asrc[4];
@@ -966,7 +972,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_rank_kernel(GemmP p) {
 //   * 1-D grid, split-major through xcd_remap: the q-tiles of one split run on one XCD and share its A rows in that L2.
 // All four waves multiply: wave w owns q columns [32 w, 32 w + 32) of the tile and all PB p-blocks.
 template <int PB>
-__global__ __launch_bounds__(256, 2) void gemm_tn_rank_kernel(GemmP p) {
+__global__ __launch_bounds__(256, 2) void gemm_tn_rank_kernel(GemmP pa, GemmP pb, int na) {
+  // two products in one launch (dA = du^T x and dB^T = u^T dy of one adapted group): workgroups >= na take the second set
+  const bool second = (int)blockIdx.x >= na;
+  const GemmP& p = second ? pb : pa;
+  const int bid = (int)blockIdx.x - (second ? na : 0);
   constexpr int NST = PB <= 2 ? 4 : 3;
   constexpr int APITCH = 32 * PB;        // bytes per A row in LDS
   constexpr int ABYTES = 64 * APITCH;    // a stage's A part
@@ -979,7 +989,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_rank_kernel(GemmP p) {
   const int Q = p.N, R = p.K;
   const int tiles_q = Q >> 7;
   const int nsplit = p.nsplit;
-  const int sid = xcd_remap(blockIdx.x, tiles_q * nsplit);
+  const int sid = xcd_remap(bid, tiles_q * nsplit);
   const int split = sid / tiles_q, tq = sid - split * tiles_q;
   const int q0 = tq << 7;
 
@@ -1384,12 +1394,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmP p) {
 // Rows P .. Pz-1 of C (the padding rows of a rank-r operand, absent from the workspace) are written as zero.
 // col_scale / blk_n: the LoRA adapter-gradient forms of wft_gemm_args (tn_col_scale, tn_block_n): a per-(row group, column)
 // factor, and the transposed block-diagonal output.
-__global__ __launch_bounds__(256) void tn_splitk_reduce_kernel(const float* ws, float* C, long ldc, int P, int Q, int nsplit,
-                                                                int accumulate, int Pz, const float* col_scale, int scale_rows,
-                                                                int blk_n, int blk_r, int Pv) {
+struct TnReduceP {
+  const float* ws; float* C; long ldc; int P, Q, nsplit, accumulate, Pz; const float* col_scale; int scale_rows, blk_n, blk_r, Pv;
+};
+__device__ __forceinline__ void tn_splitk_reduce_body(const float* ws, float* C, long ldc, int P, int Q, int nsplit,
+                                                      int accumulate, int Pz, const float* col_scale, int scale_rows,
+                                                      int blk_n, int blk_r, int Pv, long bid, long nblk) {
   const long nq4 = Q >> 2;
   const long total = (long)(Pz > P ? Pz : P) * nq4;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+  for (long i = bid * 256 + threadIdx.x; i < total; i += nblk * 256) {
     const long pp = i / nq4, q4 = (i - pp * nq4) * 4;
     float* cp = C + pp * ldc + q4;
     if (col_scale && blk_n == 0 && pp >= Pv) continue;  // col-scale form: C has p_valid rows, nothing is written below them
@@ -1423,6 +1436,19 @@ __global__ __launch_bounds__(256) void tn_splitk_reduce_kernel(const float* ws, 
       *(f32x4*)cp = s;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void tn_splitk_reduce_kernel(const float* ws, float* C, long ldc, int P, int Q, int nsplit,
+                                                                int accumulate, int Pz, const float* col_scale, int scale_rows,
+                                                                int blk_n, int blk_r, int Pv) {
+  tn_splitk_reduce_body(ws, C, ldc, P, Q, nsplit, accumulate, Pz, col_scale, scale_rows, blk_n, blk_r, Pv, (long)blockIdx.x, (long)gridDim.x);
+}
+// both adapter gradients of a group (dA with its column scale, dB in block layout) in ONE launch: workgroups >= g0 take r1
+__global__ __launch_bounds__(256) void tn_splitk_reduce_pair_kernel(TnReduceP r0, TnReduceP r1, int g0) {
+  const bool second = (int)blockIdx.x >= g0;
+  const TnReduceP& r = second ? r1 : r0;
+  tn_splitk_reduce_body(r.ws, r.C, r.ldc, r.P, r.Q, r.nsplit, r.accumulate, r.Pz, r.col_scale, r.scale_rows, r.blk_n, r.blk_r, r.Pv,
+                        (long)blockIdx.x - (second ? g0 : 0), (long)(second ? (int)gridDim.x - g0 : g0));
 }
 
 // ---------------------------------------------------------------------------------- host
@@ -1584,7 +1610,7 @@ extern "C" int wft_gemm_nt_bf16(const wft_gemm_args* a, void* stream) {
     static DynLdsOnce once;                                                                       \
     auto kfn = gemm_nt_rank_kernel<PBV>;                                                          \
     once.set(kfn, bytes);                                                                         \
-    hipLaunchKernelGGL(kfn, g1, dim3(256), bytes, s, p);                                          \
+    hipLaunchKernelGGL(kfn, g1, dim3(256), bytes, s, p, p, (int)g1.x);                            \
   }
     if (npb == 1) WFT_NT_RANK_LAUNCH(1)
     else if (npb == 2) WFT_NT_RANK_LAUNCH(2)
@@ -1739,7 +1765,7 @@ extern "C" int wft_gemm_tn_bf16(const wft_gemm_args* a, void* stream) {
     static DynLdsOnce once;                                                                       \
     auto kfn = gemm_tn_rank_kernel<PBV>;                                                          \
     once.set(kfn, bytes);                                                                         \
-    hipLaunchKernelGGL(kfn, g1, block, bytes, s, p);                                              \
+    hipLaunchKernelGGL(kfn, g1, block, bytes, s, p, p, (int)g1.x);                                \
   }
     if (pb == 1) WFT_RANK_LAUNCH(1)
     else if (pb == 2) WFT_RANK_LAUNCH(2)
@@ -1760,6 +1786,105 @@ extern "C" int wft_gemm_tn_bf16(const wft_gemm_args* a, void* stream) {
                        (long)a->ldc, (int)tn_ws_rows(a), (int)a->N, nsplit, a->accumulate, (int)a->M, a->tn_col_scale,
                        a->tn_scale_rows, a->tn_block_n, a->tn_block_r, pb > 0 ? a->p_valid : (int)a->M);
   }
+  WFT_CHECK_LAUNCH();
+  return WFT_OK;
+}
+
+
+// ---------------------------------------------------------------------------------- paired rank-r launches (round 3)
+// The four rank-r products of one adapted Linear group's backward are two independent pairs: {u = x (sA*m)^T, du = dy (sB)} and
+// {dA = du^T x, dB^T = u^T dy}.  Each pair goes out as ONE launch of the load-stream kernel (and the two split-K reduces of the
+// second pair as one): half the launches, and a grid that fills the chip (an NT rank product alone is 1.46 rounds of 256 CUs at
+// 32 clips).  Same arithmetic per product as the single entry points: bit-identical results.  Anything the load-stream kernels do
+// not take falls back to two calls of the single entry point.
+static int nt_rank_pb(const wft_gemm_args* a) {
+  return (!a->c_is_f32 && a->N == 128 && a->batch == 1 && a->p_valid > 0 && a->p_valid <= 64 && a->epilogue == WFT_EPI_NONE &&
+          !a->bias && !a->residual && !a->aux && !a->colsum && a->valid_rows_period == 0 && g_diag != 9 && a->M >= 1 && a->K >= 64 &&
+          a->K % 64 == 0 && a->lda % 8 == 0 && a->ldb % 8 == 0 && a->ldc % 4 == 0 && a->A && a->B && a->C &&
+          (((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C) & 15) == 0 && a->M < (1ll << 31) && a->K < (1ll << 31))
+             ? (a->p_valid + 15) / 16 : 0;
+}
+extern "C" int wft_gemm_nt_rank_pair_bf16(const wft_gemm_args* a0, const wft_gemm_args* a1, void* stream) {
+  WFT_CHECK_ARG(a0 && a1, "null pointer");
+  const int pb0 = nt_rank_pb(a0), pb1 = nt_rank_pb(a1);
+  if (pb0 == 0 || pb0 != pb1 || g_diag == 21) {  // (WFT_GEMM_DIAG=21: always two launches, A/B runs)
+    const int rc = wft_gemm_nt_bf16(a0, stream);
+    return rc != WFT_OK ? rc : wft_gemm_nt_bf16(a1, stream);
+  }
+  GemmP p0, p1;
+  fill_params(a0, p0);
+  fill_params(a1, p1);
+  const int n0 = (int)((a0->M + 127) / 128), n1 = (int)((a1->M + 127) / 128);
+  hipStream_t s = (hipStream_t)stream;
+#define WFT_NT_RANK_PAIR(PBV)                                                                     \
+  {                                                                                               \
+    constexpr int nst = (PBV) <= 2 ? 4 : 3;                                                       \
+    constexpr int bytes = nst * (16384 + 2048 * (PBV));                                           \
+    static DynLdsOnce once;                                                                       \
+    auto kfn = gemm_nt_rank_kernel<PBV>;                                                          \
+    once.set(kfn, bytes);                                                                         \
+    hipLaunchKernelGGL(kfn, dim3((unsigned)(n0 + n1)), dim3(256), bytes, s, p0, p1, n0);          \
+  }
+  if (pb0 == 1) WFT_NT_RANK_PAIR(1)
+  else if (pb0 == 2) WFT_NT_RANK_PAIR(2)
+  else if (pb0 == 3) WFT_NT_RANK_PAIR(3)
+  else WFT_NT_RANK_PAIR(4)
+#undef WFT_NT_RANK_PAIR
+  WFT_CHECK_LAUNCH();
+  return WFT_OK;
+}
+
+// both through the workspace + reduce (what the adapter-gradient forms tn_col_scale / tn_block_n always do)
+static bool tn_rank_pair_ok(const wft_gemm_args* a) {
+  return a->A && a->B && a->C && a->c_is_f32 && tn128_pb(a) > 0 && !tn_uses_256(a) && a->N >= 128 && a->N % 128 == 0 && a->K >= 1 &&
+         a->batch >= 1 && a->lda % 8 == 0 && a->ldb % 8 == 0 && a->ldc % 4 == 0 &&
+         (((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C | (uintptr_t)a->workspace | (uintptr_t)a->tn_col_scale) & 15) == 0 &&
+         a->workspace && a->workspace_bytes >= (int64_t)tn128_nsplit(a) * tn_ws_rows(a) * a->N * 4 && a->tn_scale_rows >= 0 &&
+         (a->tn_block_n == 0 || (a->tn_block_n % 4 == 0 && a->N % a->tn_block_n == 0 && a->tn_block_r >= 1 &&
+                                 (a->N / a->tn_block_n) * (int64_t)a->tn_block_r <= 16 * tn128_pb(a))) &&
+         a->N < (1ll << 31) && a->K < (1ll << 31) && g_diag != 9 && g_diag != 21;
+}
+extern "C" int wft_gemm_tn_rank_pair_bf16(const wft_gemm_args* a0, const wft_gemm_args* a1, void* stream) {
+  WFT_CHECK_ARG(a0 && a1, "null pointer");
+  if (!tn_rank_pair_ok(a0) || !tn_rank_pair_ok(a1) || tn128_pb(a0) != tn128_pb(a1)) {
+    const int rc = wft_gemm_tn_bf16(a0, stream);
+    return rc != WFT_OK ? rc : wft_gemm_tn_bf16(a1, stream);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const wft_gemm_args* as[2] = {a0, a1};
+  GemmP p[2];
+  TnReduceP r[2];
+  int nb[2], gr[2];
+  for (int i = 0; i < 2; ++i) {
+    const wft_gemm_args* a = as[i];
+    fill_params(a, p[i]);
+    const int nsplit = tn128_nsplit(a);
+    p[i].ws = (float*)a->workspace;
+    p[i].nsplit = nsplit;
+    nb[i] = (int)((a->N / 128) * nsplit);
+    const long total = a->M * (a->N / 4);
+    long g = (total + 255) / 256;
+    if (g > 2048) g = 2048;
+    gr[i] = (int)g;
+    r[i] = TnReduceP{(const float*)a->workspace, (float*)a->C, (long)a->ldc, (int)tn_ws_rows(a), (int)a->N, nsplit, a->accumulate,
+                     (int)a->M, a->tn_col_scale, a->tn_scale_rows, a->tn_block_n, a->tn_block_r, a->p_valid};
+  }
+  const int pb = tn128_pb(a0);
+#define WFT_TN_RANK_PAIR(PBV)                                                                     \
+  {                                                                                               \
+    constexpr int nst = (PBV) <= 2 ? 4 : 3;                                                       \
+    constexpr int bytes = nst * (16384 + 2048 * (PBV));                                           \
+    static DynLdsOnce once;                                                                       \
+    auto kfn = gemm_tn_rank_kernel<PBV>;                                                          \
+    once.set(kfn, bytes);                                                                         \
+    hipLaunchKernelGGL(kfn, dim3((unsigned)(nb[0] + nb[1])), dim3(256), bytes, s, p[0], p[1], nb[0]); \
+  }
+  if (pb == 1) WFT_TN_RANK_PAIR(1)
+  else if (pb == 2) WFT_TN_RANK_PAIR(2)
+  else if (pb == 3) WFT_TN_RANK_PAIR(3)
+  else WFT_TN_RANK_PAIR(4)
+#undef WFT_TN_RANK_PAIR
+  hipLaunchKernelGGL(tn_splitk_reduce_pair_kernel, dim3((unsigned)(gr[0] + gr[1])), dim3(256), 0, s, r[0], r[1], gr[0]);
   WFT_CHECK_LAUNCH();
   return WFT_OK;
 }

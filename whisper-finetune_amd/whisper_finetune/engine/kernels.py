@@ -215,7 +215,8 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, mask=None, want_colsum=Fa
 def gemm_nt(a, b, *, M=None, N=None, K=None, lda=None, ldb=None, out=None, out_f32=False, accumulate=False,
             bias=None, residual=None, aux=None, epilogue=L.EPI_NONE, alpha=1.0, batch=1,
             strideA=0, strideB=0, strideC=0, strideR=0, strideAux=0, ldc=None,
-            valid_rows_period=0, valid_rows=0, residual_first=False, ldaux=None, ldr=None, beta=1.0, colsum=None, p_valid=0):
+            valid_rows_period=0, valid_rows=0, residual_first=False, ldaux=None, ldr=None, beta=1.0, colsum=None, p_valid=0,
+            _args_only=False):
     """C[M,N] = alpha * A[M,K] @ B[N,K]^T (+bias) (epilogue) (+residual).
 
     a: bf16, row m at a.data_ptr() + m*lda; b: bf16 [N, K] (ldb).  Defaults take the shapes
@@ -266,6 +267,8 @@ def gemm_nt(a, b, *, M=None, N=None, K=None, lda=None, ldb=None, out=None, out_f
         if need > 0:
             ws = _tn_workspace(a.device, need, slot="nt_colsum")
             args.workspace, args.workspace_bytes = ws.data_ptr(), ws.numel()
+    if _args_only:  # (paired launches: gemm_nt_rank_pair)
+        return args, out
     if PROFILE_NT is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
@@ -279,7 +282,8 @@ def gemm_nt(a, b, *, M=None, N=None, K=None, lda=None, ldb=None, out=None, out_f
 
 
 def gemm_tn(a, b, *, P=None, Q=None, R=None, lda=None, ldb=None, out=None, out_f32=True, accumulate=False,
-            alpha=1.0, batch=1, strideA=0, strideB=0, p_valid=0, col_scale=None, scale_rows=0, block_n=0, block_r=0):
+            alpha=1.0, batch=1, strideA=0, strideB=0, p_valid=0, col_scale=None, scale_rows=0, block_n=0, block_r=0,
+            _args_only=False, _ws_slot="tn"):
     """C[P,Q] (+)= alpha * A[R,P]^T @ B[R,Q]  (weight gradients).  p_valid (P = 128 only): columns >= p_valid of A are zero
     padding (a rank-r LoRA operand): the reduction runs in the load-stream kernel for rank-r operands (gemm.hip
     gemm_tn_rank_kernel — 4-stage LDS-DMA ring, compact A, compact split-K workspace), bit-identical to the general path.
@@ -325,10 +329,31 @@ def gemm_tn(a, b, *, P=None, Q=None, R=None, lda=None, ldb=None, out=None, out_f
     lib = L.load()
     need = lib.wft_gemm_tn_workspace_bytes(C.byref(args))
     if need > 0:
-        ws = _tn_workspace(a.device, need)
+        ws = _tn_workspace(a.device, need, slot=_ws_slot)
         args.workspace, args.workspace_bytes = ws.data_ptr(), ws.numel()
+    if _args_only:  # (paired launches: gemm_tn_rank_pair)
+        return args, out
     L.check(lib.wft_gemm_tn_bf16(C.byref(args), L.stream_ptr()), "wft_gemm_tn_bf16")
     return out
+
+
+def gemm_nt_rank_pair(a0, b0, a1, b1, p_valid: int):
+    """(a0 @ b0^T, a1 @ b1^T) for two rank-r operands b0, b1 ([128, K] padded buffers, p_valid data rows) in ONE launch of the
+    load-stream kernel (wft_gemm_nt_rank_pair_bf16): u = x (sA*m)^T and du = dy (sB) of an adapted Linear group's backward."""
+    args0, out0 = gemm_nt(a0, b0, p_valid=p_valid, _args_only=True)
+    args1, out1 = gemm_nt(a1, b1, p_valid=p_valid, _args_only=True)
+    L.check(L.load().wft_gemm_nt_rank_pair_bf16(C.byref(args0), C.byref(args1), L.stream_ptr()), "wft_gemm_nt_rank_pair_bf16")
+    return out0, out1
+
+
+def gemm_tn_rank_pair(kw0: dict, kw1: dict):
+    """Two gemm_tn(**kw) products with rank-r A operands (p_valid) in ONE launch plus ONE split-K reduce launch
+    (wft_gemm_tn_rank_pair_bf16): dA = (du^T x) * mask and dB = u^T dy of an adapted Linear group.  Each product has its own
+    workspace."""
+    args0, out0 = gemm_tn(**kw0, _args_only=True, _ws_slot="tn")
+    args1, out1 = gemm_tn(**kw1, _args_only=True, _ws_slot="tn_b")
+    L.check(L.load().wft_gemm_tn_rank_pair_bf16(C.byref(args0), C.byref(args1), L.stream_ptr()), "wft_gemm_tn_rank_pair_bf16")
+    return out0, out1
 
 
 _TN_WS = {}

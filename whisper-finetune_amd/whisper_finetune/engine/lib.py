@@ -97,6 +97,8 @@ SIGNATURES = {
     "wft_gemm_nt_variant": [C.POINTER(GemmArgs)],
     "wft_gemm_nt_colsum_workspace_bytes": [C.POINTER(GemmArgs)],
     "wft_gemm_tn_bf16": [C.POINTER(GemmArgs), c_vp],
+    "wft_gemm_nt_rank_pair_bf16": [C.POINTER(GemmArgs), C.POINTER(GemmArgs), c_vp],
+    "wft_gemm_tn_rank_pair_bf16": [C.POINTER(GemmArgs), C.POINTER(GemmArgs), c_vp],
     "wft_gemm_tn_workspace_bytes": [C.POINTER(GemmArgs)],
     "wft_attn_fwd_bf16": [C.POINTER(AttnArgs), c_vp],
     "wft_attn_bwd_bf16": [C.POINTER(AttnArgs), c_vp],

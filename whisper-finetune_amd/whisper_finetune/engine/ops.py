@@ -417,6 +417,8 @@ class _LinearCfg:
 _LORA_PVALID = os.environ.get("WFT_LORA_PVALID", "1") != "0"
 # WFT_LORA_FUSED_OUT=0: adapter gradients sliced / masked / transposed by torch ops after the GEMMs (A/B runs)
 _LORA_FUSED_OUT = os.environ.get("WFT_LORA_FUSED_OUT", "1") != "0"
+# WFT_LORA_PAIR=0: the four rank-r products of a group's backward as four launches + two reduces instead of two + one (A/B runs)
+_LORA_PAIR = os.environ.get("WFT_LORA_PAIR", "1") != "0"
 # WFT_GELU_PAIR=0: keep the pre-activation and evaluate gelu' in the backward-data GEMM's epilogue (A/B runs)
 _GELU_PAIR = os.environ.get("WFT_GELU_PAIR", "1") != "0"
 
@@ -545,6 +547,15 @@ class LinearFn(torch.autograd.Function):
             fused = (_LORA_FUSED_OUT and pv > 0 and len(specs) == n_w and all(a_need) and all(b2_need) and kpad == k
                      and npad == n and all(s.A.shape[0] == r0 for s in specs) and all(w.shape[0] == n0 for w in weights)
                      and all((s.mask is None) == (specs[0].mask is None) for s in specs))
+            if fused and _LORA_PAIR:
+                # the four rank-r products as two paired launches (+ one reduce launch for both gradients): 3 launches, not 6
+                du, u = K.gemm_nt_rank_pair(dy, BbT, x, Am, pv)          # dy @ (s*B) | x @ (s*A*mask)^T (carries the scaling)
+                dA_full, dB_blocks = K.gemm_tn_rank_pair(
+                    dict(a=du, b=x, p_valid=pv, col_scale=_stacked_masks(specs), scale_rows=r0 if n_w > 1 else 0),
+                    dict(a=u, b=dy, p_valid=pv, block_n=n0, block_r=r0))
+                out.extend(dA_full[i * r0:(i + 1) * r0] for i in range(n_w))
+                out.extend(dB_blocks[i * n0 * r0:(i + 1) * n0 * r0].view(n0, r0) for i in range(n_w))
+                return tuple(out)
             if fused:
                 du = K.gemm_nt(dy, BbT, p_valid=pv)                      # [M, Rpad] = dy @ (s*B)
                 dA_full = K.gemm_tn(du, x, p_valid=pv, col_scale=_stacked_masks(specs), scale_rows=r0 if n_w > 1 else 0)
