@@ -33,6 +33,7 @@ struct GemmP {
   float* ws;  // split-K partial tiles [nsplit][P][Q] fp32 (TN, optional)
   float* cs_part;  // NT256: per-(row tile, wave row) column-sum partials [2*tiles_m][N] fp32, or NULL
   int nsplit;  // gemm_tn_rank_kernel: split-K factor (its grid is 1-D)
+  int band;  // NT256: tile-order band width in column tiles (WFT_NT256_BAND, default 5)
   int diag;  // WFT_GEMM_DIAG, NT256 A/B switches: 6 skips the staged epilogue (timing only), 7 = general epilogue body everywhere, 8 = no continuous staging
 };
 
@@ -40,8 +41,7 @@ struct GemmP {
 // runs at a time (consecutive sids) then cover a ~6 x 5 patch = 11 operand panels instead of 2 x 20 = 22 for a
 // wide N.  Measured before: FETCH_SIZE of the 48000x5120x1280 GEMM was 8x its algorithmic A+B bytes (every XCD
 // re-streamed all of B every round).
-__device__ __forceinline__ void band_coords(int sid, int tiles_r, int tiles_c, int& tr, int& tc) {
-  const int W = 5;
+__device__ __forceinline__ void band_coords(int sid, int tiles_r, int tiles_c, int& tr, int& tc, int W = 5) {
   const int band = sid / (tiles_r * W);
   const int c0 = band * W;
   const int w = (tiles_c - c0) < W ? (tiles_c - c0) : W;
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
   auto set_src = [&](int t) {  // PERSISTENT: tile t of this workgroup's sequence
     const int bz = t / tiles, sid = xcd_remap(t - bz * tiles, tiles);
     int tm, tn;
-    band_coords(sid, tiles_m, tiles_n, tm, tn);
+    band_coords(sid, tiles_m, tiles_n, tm, tn, p.band);
     const unsigned long long b64 = !grp_b ? (unsigned long long)(p.A + (long)bz * p.sA + (long)(tm << 8) * p.lda)
                                           : (unsigned long long)(p.B + (long)bz * p.sB + (long)(tn << 8) * p.ldb);
     // pin the base to SGPRs (it is wave-uniform by construction; the compiler does not prove it through the tile loop)
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmP p) {
   for (; t < total; t += gridDim.x) {
     const int bz = t / tiles, sid = xcd_remap(t - bz * tiles, tiles);
     int tm, tn;
-    band_coords(sid, tiles_m, tiles_n, tm, tn);
+    band_coords(sid, tiles_m, tiles_n, tm, tn, p.band);
     const int m0 = tm << 8, n0 = tn << 8;
 
     f32x4 acc[8][4];
@@ -1457,8 +1457,9 @@ static int g_diag = 0;
 // they can occupy half of the CUs (NT: >= 128 tiles) / have >= 50 output tiles to split (TN).  Tunable: WFT_NT256_MIN_TILES, WFT_TN256_MIN_STEPS.
 static int g_nt256_min_tiles = 128, g_tn256_min_steps = 64;
 static bool g_nt256_persistent = true;
+static int g_nt256_band = 5;
 static bool g_force_128 = false;  // debugging / A-B switch: WFT_GEMM_FORCE_128=1
-static struct EnvInit { EnvInit() { const char* e = getenv("WFT_GEMM_FORCE_128"); g_force_128 = e && e[0] == '1'; const char* d = getenv("WFT_GEMM_DIAG"); g_diag = d ? atoi(d) : 0; const char* t1 = getenv("WFT_NT256_MIN_TILES"); if (t1) g_nt256_min_tiles = atoi(t1); const char* t2 = getenv("WFT_TN256_MIN_STEPS"); if (t2) g_tn256_min_steps = atoi(t2); const char* pe = getenv("WFT_NT256_PERSISTENT"); if (pe) g_nt256_persistent = pe[0] != '0'; } } g_env_init;
+static struct EnvInit { EnvInit() { const char* e = getenv("WFT_GEMM_FORCE_128"); g_force_128 = e && e[0] == '1'; const char* d = getenv("WFT_GEMM_DIAG"); g_diag = d ? atoi(d) : 0; const char* t1 = getenv("WFT_NT256_MIN_TILES"); if (t1) g_nt256_min_tiles = atoi(t1); const char* t2 = getenv("WFT_TN256_MIN_STEPS"); if (t2) g_tn256_min_steps = atoi(t2); const char* pe = getenv("WFT_NT256_PERSISTENT"); if (pe) g_nt256_persistent = pe[0] != '0'; const char* bw = getenv("WFT_NT256_BAND"); if (bw && atoi(bw) > 0) g_nt256_band = atoi(bw); } } g_env_init;
 
 static int fill_params(const wft_gemm_args* a, GemmP& p) {
   p.A = a->A; p.lda = a->lda; p.sA = a->strideA;
@@ -1474,6 +1475,7 @@ static int fill_params(const wft_gemm_args* a, GemmP& p) {
   p.period = a->valid_rows_period; p.valid = a->valid_rows;
   p.res_first = a->residual_first;
   p.diag = g_diag;
+  p.band = g_nt256_band;
   p.ws = nullptr;
   p.cs_part = nullptr;
   return 0;
