@@ -28,6 +28,7 @@ and, on the default (headline) invocation, extra keys measured in the same proce
                              timestamp tokens every 16th position, B = 64 — SURVEY.md §8d config 5),
   "entrypoint_loop":         scripts/finetune.py's real loop (SyntheticDataset -> DataLoader workers -> GpuMelLoader ->
                              train_step, tools/e2e_entrypoint.py) at B = 32 next to the same batches replayed from HBM.
+  "cpu_baseline_small_models": the oracle's step for whisper-tiny / whisper-base (B = 2) on all host cores and on one.
 `ms_per_step` is the mean over the K timed steps (the contract's clock); `ms_per_step_median` is the median of the per-step
 wall times inside that region (train_step ends with loss.item()).  `--no-extras` prints the headline only.
 """
@@ -172,6 +173,35 @@ def cpu_baseline(model_name: str, S: int, budget_s: float = 30.0):
         "sample": f"1 synthetic 30 s clip, whisper-{name} fp32, S={S}: log-mel + forward + CE + backward "
                   f"(no optimizer step), {dt:.1f} s on {cores} torch threads ({os.cpu_count()} logical CPUs)",
     }
+
+
+def cpu_baseline_small(budget_s: float = 40.0):
+    """the oracle's forward + backward + AdamW step for whisper-tiny and whisper-base at B = 2, S = 128 on all host
+    cores (capped at 64 threads, as cpu_baseline) and on ONE core, while the time budget lasts."""
+    sys.path.insert(0, str(ROOT))
+    from oracle import whisper_oracle as O
+
+    out, t_start = [], time.perf_counter()
+    all_cores = min(os.cpu_count() or 1, 64)
+    for name in ("tiny", "base"):
+        for cores in (all_cores, 1):
+            if time.perf_counter() - t_start > budget_s:
+                return out
+            torch.set_num_threads(cores)
+            dims = O.DIMS[name]
+            params = {k: v.requires_grad_(k != "encoder.positional_embedding") for k, v in O.init_params(dims, seed=0).items()}
+            opt = torch.optim.AdamW([p for p in params.values() if p.requires_grad], lr=1e-5)
+            audio, y_in, y_out = O.synthetic_batch(dims, 2, 128)
+            t0 = time.perf_counter()
+            mel = O.log_mel_spectrogram(audio, dims.n_mels)
+            loss = O.cross_entropy(O.Oracle(dims, params).forward(mel, y_in), y_out, 0.1)
+            loss.backward()
+            opt.step()
+            dt = time.perf_counter() - t0
+            out.append({"model": name, "cores": cores, "value": round(60.0 / dt, 2), "unit": "audio-s/s", "kind": "port",
+                        "sample": f"2 synthetic 30 s clips, fp32, S=128: log-mel + forward + CE + backward + AdamW, {dt:.2f} s"})
+    torch.set_num_threads(all_cores)
+    return out
 
 
 class Case:
@@ -465,6 +495,11 @@ def main():
             except Exception as exc:  # the baseline is informative; never lose the GPU number over it
                 out["cpu_baseline"] = {"value": None, "unit": "audio-s/s", "cores": torch.get_num_threads(), "kind": "port",
                                        "sample": f"failed: {exc!r}"}
+            if extras:
+                try:
+                    out["cpu_baseline_small_models"] = cpu_baseline_small()
+                except Exception as exc:
+                    out["cpu_baseline_small_models"] = [{"failed": repr(exc)}]
         else:
             out["cpu_baseline"] = None
     if ddp:
