@@ -625,13 +625,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
 // (global_load_lds_dword: no VGPR round trip, so no compiler-inserted vmcnt(0) in front of an LDS store — that wait used
 // to drain the prefetch of the next tile at the START of every tile).  Transposed Q^T / dO^T reads are inline asm
 // issued ahead of the S / dP MFMAs of their 32-query half (hipcc drains all LDS-DMA before a ds_read_tr builtin).
-#define DKDV_BUF (16384 + 512)
+// Query tile of the dK/dV sweep: DKDV_Q queries per stage and barrier.  128 (round 3): half the __syncthreads and half the
+// LDS-DMA issue phases per MFMA of the 64-query tiles (in-kernel stamps of round 1: 435 + 325 of 4 819 cycles per 64-query tile).
+#ifndef DKDV_Q
+#define DKDV_Q 128
+#endif
+#define DKDV_BUF (2 * DKDV_Q * 128 + 2 * DKDV_Q * 4)  // Q [DKDV_Q][64] bf16 | dO | -lse/scale f32 [DKDV_Q] | -delta
 __device__ __forceinline__ void glds4(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const WFT_GLB void*)gsrc, (WFT_LDS void*)lds_wave_base, 4, 0, 0);
 }
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
-  // [buf 2][Q 8K | dO 8K | lse2 256 B | delta 256 B]
-  __shared__ __attribute__((aligned(16))) char smem[2 * DKDV_BUF];
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [buf 2][Q | dO | -lse/scale | -delta], 2 * DKDV_BUF bytes
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: conditions on it are scalar branches, not exec masks
   const int r = lane & 31, h = lane >> 5;
@@ -657,30 +661,40 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
   const AttOffs offs = att_offsets(lane);
   const AttStage stQ = att_stage_init(p.ldq, wave, lane), stDO = att_stage_init(p.lddo, wave, lane);
   const unsigned lds0 = lds_addr_of(smem);
-  unsigned tra[2][2];
+  // one base register set per buffer (the offsets inside a buffer ride in the instructions' 16-bit immediates)
+  unsigned tra[2][2][2];
 #pragma unroll
-  for (int db = 0; db < 2; ++db)
+  for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-    for (int t = 0; t < 2; ++t) tra[db][t] = lds0 + offs.tr[db][t];
-  unsigned rowa[4];
+    for (int db = 0; db < 2; ++db)
 #pragma unroll
-  for (int s = 0; s < 4; ++s) rowa[s] = lds0 + offs.row[s];
-  const unsigned rca = lds0 + 16384 + 16 * h;  // this lane's first row constant: query 4 h of a 32-query half (+ 32 a via immediates)
+      for (int t = 0; t < 2; ++t) tra[cb][db][t] = lds0 + cb * DKDV_BUF + offs.tr[db][t];
+  unsigned rowa[2][4];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) rowa[cb][s] = lds0 + cb * DKDV_BUF + offs.row[s];
+  const unsigned rca = lds0 + 16 * h;  // this lane's first row constant: query 4 h of a 32-query half (+ buffer, + 32 a via immediates)
   const float c = p.scale * LOG2E;
   const f32x2 c2 = {c, c};
-  const int nqt = (p.Tq + 63) >> 6;
-  const int qt0 = p.causal ? (k0 >> 6) : 0;  // first query tile that can see key k0
+  const int nqt = (p.Tq + DKDV_Q - 1) / DKDV_Q;
+  const int qt0 = p.causal ? (k0 / DKDV_Q) : 0;  // first query tile that can see key k0
   const f32x16 zero16 = f32x16{0};
   f32x16 dkacc[2], dvacc[2];
   dkacc[0] = zero16; dkacc[1] = zero16;
   dvacc[0] = zero16; dvacc[1] = zero16;
 
   auto stage_q = [&](char* base, int qt) {
-    att_stage2(stQ, qb, p.ldq, base, stDO, dob, p.lddo, base + 8192, qt * 64, p.Tq, wave, lane);
-    if (wave < 2) {  // wave 0: 64 lse2 values, wave 1: 64 delta values (rows clamped; out-of-range rows are masked later)
-      int qq = qt * 64 + lane;
+#pragma unroll
+    for (int cq = 0; cq < DKDV_Q / 64; ++cq)
+      if (qt * DKDV_Q + cq * 64 < p.Tq)  // (a 64-row chunk wholly past the sequence end is neither staged nor read)
+        att_stage2(stQ, qb, p.ldq, base + cq * 8192, stDO, dob, p.lddo, base + DKDV_Q * 128 + cq * 8192, qt * DKDV_Q + cq * 64, p.Tq, wave, lane);
+    // row constants: wave w stages 64 values — even waves -lse/scale, odd waves -delta, of queries 64 (w >> 1) .. (rows clamped;
+    // out-of-range rows are masked later)
+    if (wave < DKDV_Q / 32) {
+      int qq = qt * DKDV_Q + (wave >> 1) * 64 + lane;
       qq = qq < p.Tq ? qq : p.Tq - 1;
-      glds4((wave == 0 ? lse_b : dlt_b) + qq, base + 16384 + wave * 256);
+      glds4(((wave & 1) == 0 ? lse_b : dlt_b) + qq, base + 2 * DKDV_Q * 128 + (wave & 1) * (DKDV_Q * 4) + (wave >> 1) * 256);
     }
   };
 
@@ -690,14 +704,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
   }
   auto tile = [&](auto cur_tag, int qt) {
     constexpr int CUR = decltype(cur_tag)::value;
-    const int qq0 = qt * 64;
+    const int qq0 = qt * DKDV_Q;
     if (qt + 1 < nqt) stage_q(smem + (CUR ^ 1) * DKDV_BUF, qt + 1);
-    const char* q_l = smem + CUR * DKDV_BUF;
-    const char* do_l = q_l + 8192;
-    if (!(p.causal && kw0 > qq0 + 63)) {
-      static_for<2>([&](auto qb_tag) {
+    if (!(p.causal && kw0 > qq0 + DKDV_Q - 1)) {
+      static_for<DKDV_Q / 32>([&](auto qb_tag) {
         constexpr int QB2 = decltype(qb_tag)::value;
         constexpr int qb2 = QB2;
+        // a 32-query half that lies entirely past the sequence end or above the causal diagonal contributes nothing
+        if (qq0 + 32 * qb2 >= p.Tq || (p.causal && kw0 > qq0 + 32 * qb2 + 31)) return;
         // transposed fragments of this 32-query half: in flight under the S / dP MFMAs and the exponentials
         s16x4 dot[2][2][2], qt_[2][2][2];
         static_for<2>([&](auto ks_tag) {
@@ -706,8 +720,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
           for (int db = 0; db < 2; ++db)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-              dot[ks][db][t] = att_tr_asm<CUR * DKDV_BUF + 8192 + (2 * QB2 + ks) * 2048>(tra[db][t]);
-              qt_[ks][db][t] = att_tr_asm<CUR * DKDV_BUF + (2 * QB2 + ks) * 2048>(tra[db][t]);
+              dot[ks][db][t] = att_tr_asm<DKDV_Q * 128 + (2 * QB2 + ks) * 2048>(tra[CUR][db][t]);
+              qt_[ks][db][t] = att_tr_asm<(2 * QB2 + ks) * 2048>(tra[CUR][db][t]);
             }
         });
         // all eight Q / dO row fragments of the half in one batch behind the transposed reads: ONE LDS round trip in front of
@@ -715,16 +729,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
         bf16x8 aq[4], ad[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          aq[s] = att_row_asm<CUR * DKDV_BUF + QB2 * 4096>(rowa[s]);
-          ad[s] = att_row_asm<CUR * DKDV_BUF + 8192 + QB2 * 4096>(rowa[s]);
+          aq[s] = att_row_asm<QB2 * 4096>(rowa[CUR][s]);
+          ad[s] = att_row_asm<DKDV_Q * 128 + QB2 * 4096>(rowa[CUR][s]);
         }
         // the half's row constants -lse / scale and -delta: the 16 values a lane needs (queries 8 a + 4 h + e) are laid out
         // exactly like the f32x16 C operand, so they ARE the initial accumulators of the S and dP chains (no VALU at all)
         f32x4 l4[4], d4[4];
         static_for<4>([&](auto a_tag) {
           constexpr int a = decltype(a_tag)::value;
-          l4[a] = att_f4_asm<CUR * DKDV_BUF + 128 * QB2 + 32 * a>(rca);
-          d4[a] = att_f4_asm<CUR * DKDV_BUF + 256 + 128 * QB2 + 32 * a>(rca);
+          l4[a] = att_f4_asm<2 * DKDV_Q * 128 + 128 * QB2 + 32 * a>(rca + CUR * DKDV_BUF);
+          d4[a] = att_f4_asm<2 * DKDV_Q * 128 + DKDV_Q * 4 + 128 * QB2 + 32 * a>(rca + CUR * DKDV_BUF);
         });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -898,7 +912,16 @@ extern "C" int wft_attn_bwd_bf16(const wft_attn_args* a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)(((a->Tq + 255) / 256) * a->H * a->B)), dim3(256), 0, s, p);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(((a->Tq + 127) / 128) * a->H * a->B)), dim3(256), 0, s, p);
-  hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3((unsigned)(((a->Tk + 127) / 128) * a->H * a->B)), dim3(256), 0, s, p);
+  {
+    static bool lds_set[64] = {false};  // hipFuncSetAttribute is per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!lds_set[dev]) {
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DKDV_BUF);
+      lds_set[dev] = true;
+    }
+  }
+  hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3((unsigned)(((a->Tk + 127) / 128) * a->H * a->B)), dim3(256), 2 * DKDV_BUF, s, p);
   if (p.cs_q) {
     const int n = a->H * 64;
     const long rq = (long)a->B * ((a->Tq + 31) / 32), rk = (long)a->B * ((a->Tk + 31) / 32);
