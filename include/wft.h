@@ -343,8 +343,8 @@ int wft_sumsq_f32(const float* g, int64_t n, float* out, void* stream);
  *   chunk_start[t]    int32  index of tensor t's first WFT_MT_CHUNK-element chunk; chunk_start[n] =
  *                            total_chunks = sum_t ceil(numel[t] / WFT_MT_CHUNK)                        */
 #define WFT_MT_CHUNK 65536
-/* out[0] = sum over all tensors of g^2 (tab row 0 = g, f32).  partial: f32 [total_chunks] scratch.
- * Two fixed-order stages: bitwise reproducible.                                                */
+/* out[0] = sum over all tensors of g^2 (tab row 0 = g, f32; a zero address = no gradient this step, contributes
+ * nothing).  partial: f32 [total_chunks] scratch.  Two fixed-order stages: bitwise reproducible.   */
 int wft_mt_sumsq_f32(const void* tab, const int64_t* numel, const int32_t* chunk_start, int n,
                      int total_chunks, float* partial, float* out, void* stream);
 /* torch.optim.AdamW step for every tensor (tab rows: 0 p, 1 g, 2 exp_avg, 3 exp_avg_sq; all f32).
@@ -366,7 +366,9 @@ int wft_mt_adamw(const void* tab, const int64_t* numel, const int32_t* chunk_sta
  * parameters of one shape; the functions below are the element-wise / layout steps around them.
  * Tables as above with n = n_mats same-shape [rows, cols] matrices (tab rows: 0 p, 1 g, 2 momentum).   */
 /* Step 1: momentum + nesterov; g is overwritten with u (as grad.lerp_ does); U [n][rows][cols] = bf16(u);
- * partial [n][ceil(rows*cols / WFT_MT_CHUNK)] = per-chunk sum of bf16(u)^2.  sumsq/max_norm as above.   */
+ * partial [n][ceil(rows*cols / WFT_MT_CHUNK)] = per-chunk sum of bf16(u)^2.  sumsq/max_norm as above.
+ * A zero entry in table row 1 is a parameter without a gradient this step: treated as an all-zero gradient (the package
+ * materialises one: muon.py "force synchronization"), nothing is written back for it.   */
 int wft_muon_momentum_mt(const void* tab, int n_mats, int64_t numel, float beta, int nesterov,
                          wft_bf16* U, float* partial, const float* sumsq, float max_norm, void* stream);
 /* Step 2: normalise (norm rounded to bf16 like torch's bf16 .norm()) and lay out for the GEMMs:

@@ -333,3 +333,36 @@ def test_optimizer_post_hook_only_counts_optimizers_that_own_shadowed_parameters
     ops.note_shadowed([other])          # shadowed later: the cached classification is refreshed
     opt_other.step()
     assert ops._SHADOW_EPOCH[0] == e0 + 2
+
+
+def test_flat_train_walk_sets_every_flag_and_defers_to_overriding_modules():
+    """Whisper.train(): one flat walk instead of nn.Module.train's recursion (train_step calls it every step); the stock path is
+    taken as soon as a sub-module brings its own train()."""
+    from whisper_finetune.engine.whisper_model import ModelDimensions
+
+    m = Whisper(ModelDimensions(80, 150, 128, 2, 3, 100, 16, 128, 2, 1))
+    mods = list(m.modules())
+    assert len(mods) > 50
+    assert m.eval() is m and not any(x.training for x in mods)
+    assert m.train() is m and all(x.training for x in mods)
+    m.train(False)
+    assert not any(x.training for x in m.modules())
+    with pytest.raises(ValueError):
+        m.train("yes")
+
+    calls = []
+
+    class Odd(torch.nn.Module):
+        def train(self, mode=True):
+            calls.append(mode)
+            return super().train(mode)
+
+    m.encoder.blocks[0].add_module("odd", Odd())
+    m.train()
+    assert calls == [True] and all(x.training for x in m.modules())
+    m.eval()
+    assert calls == [True, False] and not any(x.training for x in m.modules())
+    # the cached bias list of Whisper.forward's hint is dropped with the compute-dtype call the entrypoint makes after module swaps
+    m.__dict__["_wft_bias_params"] = []
+    m.set_compute_dtype("bf16")
+    assert "_wft_bias_params" not in m.__dict__

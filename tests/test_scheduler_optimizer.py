@@ -180,6 +180,65 @@ def test_wft_muon_with_aux_adam_matches_the_restated_package():
 
 
 @pytest.mark.gpu
+def test_muon_parameter_without_a_gradient_steps_like_one_with_a_zero_gradient():
+    """muon.py hands a parameter that took no gradient (a block stochastic depth skipped) torch.zeros_like(p); the optimizer here
+    passes a NULL table row instead (no allocation, no fill): parameters and momentum buffers must come out bit-identical, with
+    and without the fused clip, and the missing gradient must stay missing."""
+    from whisper_finetune.model.optimizer import WftMuonWithAuxAdam
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    shapes = [(128, 384), (128, 384), (128, 384), (320, 16), (320, 16)]
+    ws = [torch.randn(s) * 0.05 for s in shapes]
+    runs = []
+    for materialise in (False, True):
+        ps = [torch.nn.Parameter(w.clone().to(dev)) for w in ws]
+        opt = WftMuonWithAuxAdam([{"params": ps, "use_muon": True, "lr": 3e-3, "momentum": 0.95, "weight_decay": 0.01}])
+        g = torch.Generator().manual_seed(5)
+        for it in range(3):
+            for i, p in enumerate(ps):
+                grad = torch.randn(p.shape, generator=g) * 0.02
+                missing = (i + it) % 3 == 1  # a different subset every step; momentum exists from earlier steps for some
+                p.grad = (torch.zeros_like(p) if materialise else None) if missing else grad.to(dev)
+            if it == 1:
+                opt.fuse_clip_grad_norm(0.05)
+            opt.step()
+            if not materialise:
+                assert [p.grad is None for p in ps] == [(i + it) % 3 == 1 for i in range(len(ps))]
+        runs.append(([p.detach().clone() for p in ps], [opt.state[p]["momentum_buffer"].clone() for p in ps]))
+    for a, b in zip(runs[0][0] + runs[0][1], runs[1][0] + runs[1][1]):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_pointer_tables_reach_the_device_unchanged_and_staging_buffers_are_recycled():
+    """kernels.upload_table: pinned staging + stream-ordered copy instead of torch.tensor(list, device=...) (which drains the
+    stream and stalls the host, 13 times per Muon step before)."""
+    from whisper_finetune.engine import kernels as K
+
+    dev = torch.device("cuda:0")
+    big = torch.empty(1 << 26, device=dev)
+    outs = []
+    for rep in range(40):
+        big.normal_()  # keep the stream busy: the copies queue behind real work
+        vals = [(rep * 1000003 + i * 7919) % (1 << 47) for i in range(1 + (rep * 37) % 700)]
+        outs.append((vals, K.upload_table(vals, torch.int64, dev)))
+        vals32 = [i - rep for i in range(300)]
+        outs.append((vals32, K.upload_table(vals32, torch.int32, dev)))
+    torch.cuda.synchronize()
+    for vals, t in outs:
+        assert t.tolist() == vals
+    assert sum(len(v) for v in K._STAGER.pool.values()) <= 80  # (bounded: one staging buffer per copy still in flight)
+    K.upload_table([1, 2, 3], torch.int64, dev)
+    torch.cuda.synchronize()
+    n_before = sum(len(v) for v in K._STAGER.pool.values())
+    for _ in range(10):
+        K.upload_table([4, 5, 6], torch.int64, dev)
+        torch.cuda.synchronize()
+    assert sum(len(v) for v in K._STAGER.pool.values()) == n_before  # an idle buffer is reused, not replaced
+
+
+@pytest.mark.gpu
 def test_single_tensor_adamw_entry_point_matches_torch_adamw_with_clip_scale():
     """wft_adamw_step (flat range, device-scalar gradient scale, bf16 shadow refreshed in the same pass)."""
     from whisper_finetune.engine import kernels as K

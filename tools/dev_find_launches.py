@@ -31,7 +31,7 @@ sites = collections.defaultdict(collections.Counter)
 class Spy(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         name = str(func)
-        if any(k in name for k in ("fill", "zero", "copy", "mul", "add", "empty", "clone", "contiguous", "sum", "div", "cat", "to_copy")):
+        if any(k in name for k in ("fill", "zero", "copy", "mul", "add", "empty", "clone", "contiguous", "sum", "div", "cat", "to_copy", "rand", "uniform", "bernoulli", "normal", "dropout", "lt", "gt", "ge", "le", "where")):
             fr = [f for f in traceback.extract_stack()[:-1] if ("whisper_finetune" in f.filename or "bench.py" in f.filename)]
             where = f"{Path(fr[-1].filename).name}:{fr[-1].lineno} {fr[-1].line[:90]}" if fr else "<autograd engine / torch internals>"
             sites[name][where] += 1
@@ -43,5 +43,5 @@ for name, c in sorted(sites.items(), key=lambda kv: -sum(kv[1].values())):
     if "empty" in name:
         continue
     print(f"== {name}: {sum(c.values())}")
-    for s, n in c.most_common(6):
+    for s, n in c.most_common(10):
         print(f"   {n:5d}  {s}")

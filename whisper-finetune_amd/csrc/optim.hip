@@ -35,6 +35,10 @@ __global__ __launch_bounds__(256) void mt_sumsq_kernel(const long* tab, const lo
                                                        float* partial) {
   __shared__ float red[4];
   const int t = mt_find(chunk_start, n, blockIdx.x);
+  if (tab[t] == 0) {  // no gradient this step (workgroup-uniform): contributes nothing
+    if (threadIdx.x == 0) partial[blockIdx.x] = 0.f;
+    return;
+  }
   const long off = (long)(blockIdx.x - chunk_start[t]) * MT_CHUNK;
   const long cnt = numel[t] - off < MT_CHUNK ? numel[t] - off : MT_CHUNK;
   const float* g = (const float*)tab[t] + off;
@@ -140,7 +144,10 @@ __global__ __launch_bounds__(256) void muon_momentum_kernel(const long* tab, int
   const int t = blockIdx.y;
   const long off = (long)blockIdx.x * MT_CHUNK;
   const long cnt = numel - off < MT_CHUNK ? numel - off : MT_CHUNK;
-  float* g = (float*)tab[n + t] + off;
+  // a NULL gradient row is a parameter that took no gradient this step (a layer stochastic depth skipped): the package gives it
+  // a zero gradient (muon.py "force synchronization"), i.e. the momentum decays and the update comes from the momentum alone —
+  // computed here without materialising the zeros
+  float* g = tab[n + t] ? (float*)tab[n + t] + off : nullptr;
   float* buf = (float*)tab[2 * n + t] + off;
   unsigned short* u = U + (long)t * numel + off;
   float gs = 1.f;
@@ -150,11 +157,11 @@ __global__ __launch_bounds__(256) void muon_momentum_kernel(const long* tab, int
   }
   float s = 0.f;
   for (long i = threadIdx.x; i < cnt; i += 256) {
-    const float gg = g[i] * gs;
+    const float gg = g ? g[i] * gs : 0.f;
     const float bb = buf[i] + (1.f - beta) * (gg - buf[i]);  // torch lerp: start + weight * (end - start)
     const float uu = nesterov ? gg + beta * (bb - gg) : bb;
     buf[i] = bb;
-    g[i] = uu;
+    if (g) g[i] = uu;
     const unsigned short ub = f2bf(uu);
     u[i] = ub;
     const float ur = bf2f(ub);

@@ -545,6 +545,46 @@ def sumsq(g, out):
 MT_CHUNK = 65536  # include/wft.h WFT_MT_CHUNK
 
 
+class _Stager:
+    """Small integer tables (tensor addresses, element counts) to the device WITHOUT a host synchronisation.
+    `torch.tensor(list, device=...)` goes through pageable memory: the copy waits for everything queued on the stream and the
+    host waits for the copy — thirteen such stalls per optimizer step emptied the queue in front of every Muon bucket
+    (profiles/r03_lora_gap_analysis.log: 16 of the 17.7 ms the GPU idled per LoRA + Muon step).  Here the values are written
+    into a pinned staging buffer (recycled once its copy event has fired) and copied stream-ordered."""
+
+    def __init__(self):
+        self.pool = {}  # (dtype, capacity) -> [(pinned tensor, numpy view, event)]
+
+    def upload(self, values, dtype, device) -> torch.Tensor:
+        n = len(values)
+        cap = max(256, 1 << max(n - 1, 0).bit_length())
+        pool = self.pool.setdefault((dtype, cap), [])
+        for i, ent in enumerate(pool):
+            if ent[2].query():
+                pool.pop(i)
+                break
+        else:
+            host = torch.empty(cap, dtype=dtype, pin_memory=True)
+            ent = (host, host.numpy(), torch.cuda.Event())
+        host, view, ev = ent
+        view[:n] = values
+        dev = torch.empty(n, dtype=dtype, device=device)
+        dev.copy_(host[:n], non_blocking=True)
+        ev.record()
+        pool.append(ent)
+        return dev
+
+
+_STAGER = _Stager()
+
+
+def upload_table(values, dtype, device) -> torch.Tensor:
+    """1-D integer table -> device tensor, stream-ordered, no host synchronisation (CPU tensors: plain construction)."""
+    if torch.device(device).type != "cuda":
+        return torch.tensor(values, dtype=dtype, device=device)
+    return _STAGER.upload(values, dtype, device)
+
+
 class TensorTable:
     """Device-side pointer table for the wft_mt_* / wft_muon_*_mt entry points: `rows` lists of equally long tensor
     lists (row r of tensor t at tab[r * n + t]).  numel / chunk_start depend only on the shapes and are cached by
@@ -560,23 +600,26 @@ class TensorTable:
             tot += (ne + MT_CHUNK - 1) // MT_CHUNK
         starts.append(tot)
         self.total_chunks = tot
-        self.numel = torch.tensor(numel, dtype=torch.int64, device=self.device)
-        self.chunk_start = torch.tensor(starts, dtype=torch.int32, device=self.device)
+        self.numel = upload_table(numel, torch.int64, self.device)
+        self.chunk_start = upload_table(starts, torch.int32, self.device)
 
-    def pointers(self, *rows):
+    def pointers(self, *rows, allow_none=False):
         flat = []
         for r in rows:
             assert len(r) == self.n
             for t in r:
+                if t is None and allow_none:
+                    flat.append(0)
+                    continue
                 if t.dtype != F32 or not t.is_contiguous() or not t.is_cuda:
                     raise L.WftError("multi-tensor optimizer kernels need contiguous f32 HIP tensors")
                 flat.append(t.data_ptr())
-        return torch.tensor(flat, dtype=torch.int64, device=self.device)
+        return upload_table(flat, torch.int64, self.device)
 
 
 def mt_sumsq(table: TensorTable, grads, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """sum over all tensors of g^2 -> f32 [1] on the device (fixed-order reduction)."""
-    tab = table.pointers(grads)
+    """sum over all tensors of g^2 -> f32 [1] on the device (fixed-order reduction); a None gradient adds nothing."""
+    tab = table.pointers(grads, allow_none=True)
     partial = torch.empty(table.total_chunks, dtype=F32, device=table.device)
     out = torch.empty(1, dtype=F32, device=table.device) if out is None else out
     L.check(L.load().wft_mt_sumsq_f32(_p(tab), _p(table.numel), _p(table.chunk_start), table.n, table.total_chunks,
@@ -604,7 +647,7 @@ NS_COEFFS = (3.4445, -4.7750, 2.0315)  # muon.py zeropower_via_newtonschulz5
 
 
 def muon_group_step(params, grads, bufs, lr, wd, momentum, nesterov=True, ns_steps=5, sumsq=None, max_norm=0.0,
-                    return_update=False, shard=None):
+                    return_update=False, shard=None, validated=False):
     """One Muon step for a list of same-shape 2-D f32 parameters (muon.py muon_update + the p update of
     SingleDeviceMuonWithAuxAdam.step): momentum/nesterov -> bf16 -> Frobenius normalisation -> 5 Newton-Schulz
     iterations as batched MFMA GEMMs -> p = p(1 - lr wd) - lr sqrt(max(1, rows/cols)) X.
@@ -633,15 +676,19 @@ def muon_group_step(params, grads, bufs, lr, wd, momentum, nesterov=True, ns_ste
     n = hi - lo
     if len(grads) != n or len(bufs) != n:
         raise L.WftError(f"muon_group_step: {n} owned matrices but {len(grads)} gradients / {len(bufs)} momentum buffers")
-    for row in (params, grads, bufs):
+    # (validated: the caller checked `params` and `bufs` when it built them — the optimizer's per-group plan; gradients are new
+    # tensors every step and are always checked)
+    for row in ((grads,) if validated else (params, grads, bufs)):
         for t in row:
+            if t is None and row is grads:
+                continue  # no gradient this step: an all-zero one to the momentum kernel (muon.py "force synchronization")
             if t.dtype != F32 or not t.is_contiguous() or t.shape != (rows, cols) or not t.is_cuda:
                 raise L.WftError("muon_group_step needs contiguous f32 HIP tensors of one shape (there is no CPU path)")
     O = None
     ldo, so = (Rp, Cp * Rp) if tall else (Cp, Rp * Cp)
     if n > 0:
-        flat = [t.data_ptr() for t in params[lo:hi]] + [t.data_ptr() for t in grads] + [t.data_ptr() for t in bufs]
-        tab = torch.tensor(flat, dtype=torch.int64, device=dev)
+        flat = [t.data_ptr() for t in params[lo:hi]] + [0 if t is None else t.data_ptr() for t in grads] + [t.data_ptr() for t in bufs]
+        tab = upload_table(flat, torch.int64, dev)
         U = torch.empty((n, rows, cols), dtype=BF16, device=dev)
         partial = torch.empty((n, chunks), dtype=F32, device=dev)
         L.check(lib.wft_muon_momentum_mt(_p(tab), n, numel, momentum, int(nesterov), _p(U), _p(partial), _p(sumsq),
@@ -673,7 +720,7 @@ def muon_group_step(params, grads, bufs, lr, wd, momentum, nesterov=True, ns_ste
         O = torch.empty((world * per,) + tuple(mine.shape[1:]), dtype=BF16, device=dev)
         all_gather(O, mine)
     scale = max(1.0, rows / cols) ** 0.5
-    ptab = torch.tensor([t.data_ptr() for t in params], dtype=torch.int64, device=dev)
+    ptab = upload_table([t.data_ptr() for t in params], torch.int64, dev)
     L.check(lib.wft_muon_apply_mt(_p(ptab), n_all, rows, cols, _p(O), ldo, so, lr, wd, scale, L.stream_ptr()), "wft_muon_apply_mt")
     if return_update:
         return O[:n_all, :rows, :cols].float() * scale

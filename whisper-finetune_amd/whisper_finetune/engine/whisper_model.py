@@ -332,6 +332,7 @@ class Whisper(nn.Module):
         if dtype not in ("bf16", "fp32"):
             raise ValueError(f"compute dtype must be 'bf16' or 'fp32', got {dtype!r}")
         self.compute_dtype = dtype
+        self.__dict__.pop("_wft_bias_params", None)
         for m in self.modules():
             if hasattr(m, "wft_fp32"):
                 m.wft_fp32 = dtype == "fp32"
@@ -345,6 +346,27 @@ class Whisper(nn.Module):
         all_heads = torch.zeros(dims.n_text_layer, dims.n_text_head, dtype=torch.bool)
         all_heads[dims.n_text_layer // 2:] = True
         self.register_buffer("alignment_heads", all_heads.to_sparse(), persistent=False)
+
+    def train(self, mode: bool = True):
+        """nn.Module.train for a tree whose modules all use the stock method (every module of this package does): one flat
+        walk that sets the flag, instead of a recursive call and an nn.Module.__setattr__ per module.  train_step calls
+        model.train() at the top of every step (model/model_utils.py:33 in the reference): 2 500 modules on large-v3,
+        3-4 ms of host time while the GPU has nothing queued.  Any overriding sub-module sends the call down the stock path."""
+        if not isinstance(mode, bool):
+            raise ValueError("training mode is expected to be boolean")
+        stack, seen, flat = [self], set(), []
+        while stack:
+            m = stack.pop()
+            if id(m) in seen:
+                continue
+            seen.add(id(m))
+            if m is not self and type(m).train is not nn.Module.train:
+                return super().train(mode)
+            flat.append(m)
+            stack.extend(c for c in m._modules.values() if c is not None)
+        for m in flat:
+            m.__dict__["training"] = mode
+        return self
 
     @property
     def device(self):
@@ -370,7 +392,13 @@ class Whisper(nn.Module):
         ops.reset_colsums()  # stale fused bias-gradient entries of an earlier backward pass (engine/ops.py)
         # a hint for the producer kernels (captured per autograd node at forward time): with every bias frozen (a LoRA run)
         # nobody will ask for the fused bias-gradient column sums
-        ops.BIAS_GRADS[0] = any(p.requires_grad for n, p in self.named_parameters() if n.endswith("bias"))
+        # (the walk over named_parameters() costs 7 ms on large-v3 — at the start of a step, with the GPU idle: the bias list is
+        # cached; set_compute_dtype(), which the entrypoint calls after every module swap, drops it.  A stale list can only
+        # cost speed: a consumer that finds no fused column sums forms its bias gradient with wft_colsum_bf16)
+        biases = self.__dict__.get("_wft_bias_params")
+        if biases is None:
+            biases = self.__dict__["_wft_bias_params"] = [p for n, p in self.named_parameters() if n.endswith("bias")]
+        ops.BIAS_GRADS[0] = any(p.requires_grad for p in biases)
         if targets is not None:
             return self.forward_loss(mel, tokens, targets, label_smoothing)
         return self.decoder(tokens, self.encoder(mel))

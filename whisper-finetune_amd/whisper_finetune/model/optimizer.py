@@ -19,12 +19,16 @@ def print_trainable_parameters(model) -> None:
     print(f"trainable params: {train:,} || all params: {total:,} || trainable%: {100 * train / max(total, 1):.4f}")
 
 
-def _global_sumsq(params_with_grad):
-    """device f32 [1] = sum of squares of every gradient (one fixed-order multi-tensor reduction)."""
+def _global_sumsq(optimizer, params):
+    """device f32 [1] = sum of squares of every gradient (one fixed-order multi-tensor reduction).  The element-count table is
+    built once for the optimizer's whole parameter list; a parameter without a gradient this step is a NULL row."""
     from whisper_finetune.engine import kernels as K
 
-    table = K.TensorTable(params_with_grad)
-    return K.mt_sumsq(table, [p.grad for p in params_with_grad])
+    key = tuple(id(p) for p in params)
+    ent = optimizer.__dict__.get("_clip_table")
+    if ent is None or ent[0] != key:
+        ent = optimizer.__dict__["_clip_table"] = (key, K.TensorTable(params))
+    return K.mt_sumsq(ent[1], [p.grad for p in params])
 
 
 class _FusedClipMixin:
@@ -40,11 +44,12 @@ class _FusedClipMixin:
             raise ValueError(f"max_norm must be > 0, got {max_norm}")
         self._pending_max_norm = float(max_norm)
 
-    def _take_clip(self, params_with_grad):
+    def _take_clip(self):
         max_norm, self._pending_max_norm = self._pending_max_norm, None
-        if max_norm is None or not params_with_grad:
+        params = [p for g in self.param_groups for p in g["params"]]
+        if max_norm is None or not any(p.grad is not None for p in params):
             return None, 0.0
-        sumsq = _global_sumsq(params_with_grad)
+        sumsq = _global_sumsq(self, params)
         self.last_grad_norm = sumsq.sqrt()
         return sumsq, max_norm
 
@@ -90,8 +95,7 @@ class WftAdamW(_FusedClipMixin, torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
-        with_grad = [p for g in self.param_groups for p in g["params"] if p.grad is not None]
-        sumsq, max_norm = self._take_clip(with_grad)
+        sumsq, max_norm = self._take_clip()
         _adamw_groups_step(self, self.param_groups, sumsq, max_norm)
         return loss  # the bf16 weight shadows are invalidated by the global optimizer post-hook (engine/ops.py)
 
@@ -127,42 +131,75 @@ class WftMuonWithAuxAdam(_FusedClipMixin, torch.optim.Optimizer):
                 assert set(group.keys()) == {"params", "lr", "betas", "eps", "weight_decay", "use_muon"}
         super().__init__(param_groups, dict())
 
+    def _muon_buckets(self, gi, group, shard):
+        """The group's bucket plan, rebuilt when the parameter list, the sharding, a parameter's storage or a momentum buffer
+        (optimizer.load_state_dict replaces those) is not what the plan was built from: 2 x 1 024 address compares per step
+        instead of 3 x 1 024 fresh views and their checks — the host side of a Muon step used to leave the GPU idle between
+        buckets (profiles/r03_lora_gap_analysis.log)."""
+        plans = self.__dict__.setdefault("_muon_plans", {})
+        key = (tuple(id(p) for p in group["params"]), None if shard is None else (shard[0], shard[1]))
+        ent = plans.get(gi)
+        if ent is not None and ent[0] == key:
+            ok = all(v.data_ptr() == p.data_ptr() for _, _, ps, _, pv, _ in ent[1] for p, v in zip(ps, pv)) and \
+                all(self.state[p].get("momentum_buffer") is not None and v.data_ptr() == self.state[p]["momentum_buffer"].data_ptr()
+                    for _, _, _, own, _, bv in ent[1] for p, v in zip(own, bv))
+            if ok:
+                return ent[1]
+        ent = plans[gi] = (key, _muon_buckets_build(self, group, shard))
+        return ent[1]
+
     @torch.no_grad()
     def step(self, closure=None):
         from whisper_finetune.engine import kernels as K
 
         loss = closure() if closure is not None else None
-        for group in self.param_groups:
-            if group["use_muon"]:
-                for p in group["params"]:
-                    if p.grad is None:
-                        p.grad = torch.zeros_like(p)  # muon.py: "force synchronization"
-        with_grad = [p for g in self.param_groups for p in g["params"] if p.grad is not None]
-        sumsq, max_norm = self._take_clip(with_grad)
+        # (muon.py gives a Muon parameter without a gradient a zero one, "force synchronization": its momentum decays and the
+        # update comes from the momentum alone.  Here such a parameter's table row is NULL and wft_muon_momentum_mt computes
+        # exactly that without the 120 allocations + fills per step a stochastic-depth run made of it; zeros add nothing to
+        # the clipping norm either)
+        sumsq, max_norm = self._take_clip()
         shard = _muon_shard()
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             if not group["use_muon"]:
                 continue
-            buckets = {}
-            for p in group["params"]:
-                if p.ndim < 2:
-                    raise ValueError("Muon parameters must have ndim >= 2")
-                buckets.setdefault((p.shape[0], p[0].numel()), []).append(p)
-            for (rows, cols), ps in buckets.items():
-                if shard is None:
-                    own = ps
-                else:
-                    per = (len(ps) + shard[1] - 1) // shard[1]
-                    own = ps[shard[0] * per:(shard[0] + 1) * per]
-                for p in own:  # momentum lives on the owning rank only
-                    if not self.state[p]:
-                        self.state[p]["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                grads = [(p.grad if p.grad.is_contiguous() else p.grad.contiguous()).view(rows, cols) for p in own]
-                K.muon_group_step([p.data.view(rows, cols) for p in ps], grads,
-                                  [self.state[p]["momentum_buffer"].view(rows, cols) for p in own], group["lr"],
-                                  group["weight_decay"], group["momentum"], sumsq=sumsq, max_norm=max_norm, shard=shard)
+            for rows, cols, ps, own, pviews, bviews in self._muon_buckets(gi, group, shard):
+                grads = []
+                for p in own:
+                    g = p.grad
+                    if g is not None and (g.ndim != 2 or not g.is_contiguous()):
+                        g = (g if g.is_contiguous() else g.contiguous()).view(rows, cols)
+                    grads.append(g)
+                K.muon_group_step(pviews, grads, bviews, group["lr"], group["weight_decay"], group["momentum"], sumsq=sumsq,
+                                  max_norm=max_norm, shard=shard, validated=True)
         _adamw_groups_step(self, [g for g in self.param_groups if not g["use_muon"]], sumsq, max_norm)
         return loss
+
+
+def _muon_buckets_build(optimizer, group, shard):
+    """Same-shape buckets of one Muon group with everything that does not change from step to step: the [rows, cols] views of
+    the parameters and of the owned momentum buffers (created here, on the owning rank only), checked once."""
+    buckets = {}
+    for p in group["params"]:
+        if p.ndim < 2:
+            raise ValueError("Muon parameters must have ndim >= 2")
+        buckets.setdefault((p.shape[0], p[0].numel()), []).append(p)
+    out = []
+    for (rows, cols), ps in buckets.items():
+        if shard is None:
+            own = ps
+        else:
+            per = (len(ps) + shard[1] - 1) // shard[1]
+            own = ps[shard[0] * per:(shard[0] + 1) * per]
+        for p in own:  # momentum lives on the owning rank only
+            if not optimizer.state[p]:
+                optimizer.state[p]["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        pviews = [p.data.view(rows, cols) for p in ps]
+        bviews = [optimizer.state[p]["momentum_buffer"].view(rows, cols) for p in own]
+        for t in pviews + bviews:
+            if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
+                raise ValueError("WftMuonWithAuxAdam needs contiguous f32 parameters on a HIP device (there is no CPU path)")
+        out.append((rows, cols, ps, own, pviews, bviews))
+    return out
 
 
 def _muon_shard():
