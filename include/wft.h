@@ -83,6 +83,10 @@ int wft_lora_pack(const float* A, const float* mask, const float* B, int rank, i
  * tile_start: device int32 [n + 1], prefix sums of (rows / 64) * (cols / 64); total_tiles = tile_start[n].  Values are
  * bit-identical to the per-adapter entry points. */
 int wft_lora_refresh_mt(const void* tab, const int32_t* tile_start, int n, int total_tiles, void* stream);
+/* n small f32 vector copies in one launch.  tab: DEVICE int64 [n][3] = source address, destination address, element count
+ * (disjoint ranges).  The host mirror uses it to restack the bias vectors of every fused q/k/v group after an optimizer step
+ * (whisper.model.Linear biases: the GEMM epilogue reads ONE bias vector per fused group). */
+int wft_mt_copy_f32(const void* tab, int n, void* stream);
 /* y[i] = a[i] + b[i] (bf16) — gradient accumulation on the residual stream. */
 int wft_add_bf16(const wft_bf16* a, const wft_bf16* b, wft_bf16* y, int64_t n, void* stream);
 /* out = a*x + b*y over n bf16 elements (y may be NULL).  StochasticDepthMixin's train-time rescale

@@ -708,8 +708,8 @@ def test_batched_weight_shadow_refresh_is_bit_identical_to_the_per_weight_kernel
         m = Whisper(MODEL_DIMS["tiny"]); m.load_state_dict(params)
         m.to(DEV).train()
         opt = WftAdamW([p for p in m.parameters() if p.requires_grad], lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.1)
-        counts = {"cast": 0, "mt": 0}
-        real = (K.weight_shadow, K.lora_refresh_mt)
+        counts = {"cast": 0, "mt": 0, "bias": 0}
+        real = (K.weight_shadow, K.lora_refresh_mt, K.mt_copy_f32)
 
         def wrap(name, f):
             def g(*a, **k):
@@ -717,7 +717,7 @@ def test_batched_weight_shadow_refresh_is_bit_identical_to_the_per_weight_kernel
                 return f(*a, **k)
             return g
 
-        K.weight_shadow, K.lora_refresh_mt = wrap("cast", real[0]), wrap("mt", real[1])
+        K.weight_shadow, K.lora_refresh_mt, K.mt_copy_f32 = wrap("cast", real[0]), wrap("mt", real[1]), wrap("bias", real[2])
         old = ops._SHADOW_BATCH
         ops._SHADOW_BATCH = batched
         try:
@@ -729,9 +729,20 @@ def test_batched_weight_shadow_refresh_is_bit_identical_to_the_per_weight_kernel
                 opt.step(); opt.zero_grad(set_to_none=True)
                 losses.append(loss.detach().clone())
                 per_step.append({k: counts[k] - before[k] for k in counts})
+            # the stacked bias vector of every fused group (q | k: none | v) is what its parameters say, after the last step too
+            m.eval()
+            with torch.no_grad():
+                m(mel, y_in)
+            for blk in list(m.encoder.blocks) + list(m.decoder.blocks):
+                g, d = blk.attn._qkv_group, blk.attn.query.weight.shape[0]
+                assert torch.equal(g.bias[:d], blk.attn.query.bias.detach()) and torch.equal(g.bias[2 * d:3 * d], blk.attn.value.bias.detach())
+                assert not g.bias[d:2 * d].any()
+            for blk in m.decoder.blocks:
+                g, d = blk.cross_attn._kv_group, blk.cross_attn.key.weight.shape[0]
+                assert torch.equal(g.bias[d:2 * d], blk.cross_attn.value.bias.detach()) and not g.bias[:d].any()
             return losses, [p.detach().clone() for p in m.parameters()], per_step
         finally:
-            K.weight_shadow, K.lora_refresh_mt = real
+            K.weight_shadow, K.lora_refresh_mt, K.mt_copy_f32 = real
             ops._SHADOW_BATCH = old
 
     l1, p1, c1 = run(True)
@@ -739,3 +750,5 @@ def test_batched_weight_shadow_refresh_is_bit_identical_to_the_per_weight_kernel
     assert all(torch.equal(a, b) for a, b in zip(l1, l0)) and all(torch.equal(a, b) for a, b in zip(p1, p0))
     assert c0[1]["mt"] == 0 and c0[1]["cast"] >= 4 * 6 + 4 * 10
     assert c1[1]["mt"] == 1 and c1[2]["mt"] == 1 and c1[1]["cast"] <= c0[1]["cast"] - (4 * 6 + 4 * 10) + 4, (c1, c0)
+    # ... and ONE wft_mt_copy_f32 launch restacks the q / v (and cross k / v) bias vectors of all fused groups
+    assert c0[1]["bias"] == 0 and c1[1]["bias"] == 1 and c1[2]["bias"] == 1, (c1, c0)

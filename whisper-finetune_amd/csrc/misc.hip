@@ -935,3 +935,20 @@ extern "C" int wft_sumsq_f32(const float* g, int64_t n, float* out, void* stream
   WFT_CHECK_LAUNCH();
   return WFT_OK;
 }
+
+// n small f32 copies in one launch (tab: int64 [n][3] = source address, destination address, element count): the stacked bias
+// vectors of the fused q/k/v groups after an optimizer step.  160 torch copy_ calls per step did this before, each a blit
+// launch of its own with ~40 us between two of them (profiles/r03_headline_gap_analysis.log).
+__global__ __launch_bounds__(256) void mt_copy_f32_kernel(const long* tab) {
+  const long* row = tab + 3 * (long)blockIdx.x;
+  const float* src = (const float*)row[0];
+  float* dst = (float*)row[1];
+  const long n = row[2];
+  for (long i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+}
+extern "C" int wft_mt_copy_f32(const void* tab, int n, void* stream) {
+  WFT_CHECK_ARG(tab && n >= 1, "bad args");
+  hipLaunchKernelGGL(mt_copy_f32_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, (const long*)tab);
+  WFT_CHECK_LAUNCH();
+  return WFT_OK;
+}

@@ -102,6 +102,11 @@ def lora_refresh_mt(table: torch.Tensor, tile_start: torch.Tensor, n: int, total
     L.check(L.load().wft_lora_refresh_mt(_p(table), _p(tile_start), int(n), int(total_tiles), L.stream_ptr()), "wft_lora_refresh_mt")
 
 
+def mt_copy_f32(table: torch.Tensor) -> None:
+    """wft_mt_copy_f32: every (source, destination, count) row of the device table int64 [n, 3] in one launch."""
+    L.check(L.load().wft_mt_copy_f32(_p(table), int(table.shape[0]), L.stream_ptr()), "wft_mt_copy_f32")
+
+
 def lora_pack(A, mask, B, scaling: float, Am, AmT, Bb, BbT, ro: int, no: int) -> None:
     """One adapter's blocks of the rank-r gradient-GEMM operands (see wft_lora_pack): A f32 [r, K], mask f32 [1, K] or None,
     B f32 [n, r] -> Am [Rpad, K] / AmT, Bb [Npad, Rpad] / BbT (bf16, zero-initialised by the caller)."""

@@ -86,6 +86,7 @@ SIGNATURES = {
     "wft_axpby_bf16": [C.c_float, c_vp, C.c_float, c_vp, c_vp, c_i64, c_vp],
     "wft_dgelu_mul_bf16": [c_vp, c_vp, c_vp, c_i64, c_vp],
     "wft_colsum_bf16": [c_vp, c_i64, c_i64, c_i64, c_vp, C.c_int, c_vp],
+    "wft_mt_copy_f32": [c_vp, C.c_int, c_vp],
     "wft_colsum_bf16_ws": [c_vp, c_i64, c_i64, c_i64, c_vp, C.c_int, c_vp, c_i64, c_vp],
     "wft_colsum_workspace_bytes": [c_i64, c_i64],
     "wft_layernorm_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_float,

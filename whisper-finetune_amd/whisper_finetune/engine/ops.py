@@ -128,7 +128,12 @@ class LinearGroup:
             live = True
         key = (tuple(_ver(w) for w in weights), want_t, _SHADOW_EPOCH[0] if live else -1, lkey)
         # biases have a key of their own: frozen ones (a LoRA run) are copied once, not with every new dropout mask
-        bkey = (tuple(_ver(b) for b in biases), _SHADOW_EPOCH[0] if any(b is not None and b.requires_grad for b in biases) else -1)
+        bkey = self._bias_key(biases)
+        if (key != self.key or bkey != self.bkey) and lkey is None and live and _SHADOW_BATCH and _PLAIN_PLAN.epoch != _SHADOW_EPOCH[0] \
+                and id(self) in _PLAIN_PLAN.groups and self.WT is not None:
+            # every trainable group's shadows AND stacked bias vectors in one launch each; sets self.key / self.bkey if this
+            # group took part
+            _PLAIN_PLAN.refresh()
         if bkey != self.bkey:
             n, k, npad = self.dims(weights)
             if not any(b is not None for b in biases):
@@ -145,9 +150,6 @@ class LinearGroup:
                     off += w.shape[0]
             self.bias_aliased = self.bias is not None and any(b is not None and b.data_ptr() == self.bias.data_ptr() for b in biases)
             self.bkey = bkey
-        if key != self.key and lkey is None and live and _SHADOW_BATCH and _PLAIN_PLAN.epoch != _SHADOW_EPOCH[0] \
-                and id(self) in _PLAIN_PLAN.groups and self.WT is not None:
-            _PLAIN_PLAN.refresh()  # every trainable group's shadows in one launch; sets self.key if this group took part
         if key != self.key:
             note_shadowed(list(weights) + list(biases) + ([x for sp in loras if sp is not None for x in (sp.A, sp.B)] if loras else []))
             n, k, npad = self.dims(weights)
@@ -172,8 +174,12 @@ class LinearGroup:
             if lkey is not None and None not in lkey:
                 _note_lora_group(self, weights, loras)
             elif lkey is None and _SHADOW_BATCH and want_t and all(w.requires_grad for w in weights):
-                _PLAIN_PLAN.note(self, weights)
+                _PLAIN_PLAN.note(self, weights, biases)
         return self.W, self.WT, self.bias
+
+    @staticmethod
+    def _bias_key(biases):
+        return (tuple(_ver(b) for b in biases), _SHADOW_EPOCH[0] if any(b is not None and b.requires_grad for b in biases) else -1)
 
     def lora_shadows(self, weights, loras: Sequence[Optional[LoraSpec]]):
         """scaling*(A*mask) stacked [Rpad, K] and block-diagonal scaling*B [Npad, Rpad], both (+T) in bf16: the operands of the
@@ -319,40 +325,59 @@ class PlainRefreshPlan:
         self.ptrs = None
         self.in_table = set()
 
-    def note(self, group: "LinearGroup", weights) -> None:
+    def note(self, group: "LinearGroup", weights, biases=()) -> None:
         ent = self.groups.get(id(group))
-        if ent is None or ent[0]() is not group or len(ent[1]) != len(weights) or any(r() is not w for r, w in zip(ent[1], weights)):
+        if ent is None or ent[0]() is not group or len(ent[1]) != len(weights) or any(r() is not w for r, w in zip(ent[1], weights)) \
+                or len(ent[2]) != len(biases) or any((r is None) != (b is None) or (r is not None and r() is not b) for r, b in zip(ent[2], biases)):
             n, k, npad = group.dims(weights)
             if k % 64 or any(w.shape[0] % 64 or w.data_ptr() % 16 or not w.is_contiguous() or w.dtype != F32 for w in weights):
                 return
-            self.groups[id(group)] = (weakref.ref(group), tuple(weakref.ref(w) for w in weights))
+            self.groups[id(group)] = (weakref.ref(group), tuple(weakref.ref(w) for w in weights),
+                                      tuple(None if b is None else weakref.ref(b) for b in biases))
             self.dirty = True
         elif id(group) not in self.in_table:
             self.dirty = True  # noted before its transposed shadow existed
 
     def _live(self):
         out = []
-        for key, (gref, wrefs) in list(self.groups.items()):
-            g, ws = gref(), [r() for r in wrefs]
+        for key, (gref, wrefs, brefs) in list(self.groups.items()):
+            g, ws, bs = gref(), [r() for r in wrefs], [None if r is None else r() for r in brefs]
             gone = g is None or any(w is None for w in ws) or not all(w.requires_grad for w in ws)  # dropped, or frozen since
+            gone = gone or any(r is not None and b is None for r, b in zip(brefs, bs))
             if gone or g.W is None or g.WT is None:
                 if gone:
                     del self.groups[key]
                 continue
-            out.append((g, ws))
+            out.append((g, ws, bs))
         return out
+
+    @staticmethod
+    def _stacks_biases(g, ws, bs) -> bool:
+        """The group owns a stacked bias vector that has to follow its parameters (not the single-Linear case, where the
+        parameter itself is the bias operand), and every bias is a contiguous f32 tensor."""
+        return (g.bias is not None and not g.bias_aliased and len(bs) == len(ws) and any(b is not None for b in bs)
+                and any(b is not None and b.requires_grad for b in bs)
+                and all(b is None or (b.dtype == F32 and b.is_contiguous() and b.numel() == w.shape[0]) for w, b in zip(ws, bs))
+                and g.bias.shape[0] >= sum(w.shape[0] for w in ws))
 
     def _build(self) -> None:
         by_dev = {}
-        for g, ws in self._live():
-            by_dev.setdefault(ws[0].device, []).append((g, ws))
+        for g, ws, bs in self._live():
+            by_dev.setdefault(ws[0].device, []).append((g, ws, bs))
         self.tables, self.ptrs = [], []
-        self.in_table = {id(g) for items in by_dev.values() for g, _ in items}
+        self.in_table = {id(g) for items in by_dev.values() for g, _, _ in items}
         for dev, items in by_dev.items():
-            rows, tiles = [], [0]
-            for g, ws in items:
+            rows, tiles, brows = [], [0], []
+            for g, ws, bs in items:
                 n, k, npad = g.dims(ws)
                 off = 0
+                if self._stacks_biases(g, ws, bs):
+                    for w, b in zip(ws, bs):
+                        if b is not None:
+                            brows.append([b.data_ptr(), g.bias.data_ptr() + 4 * off, w.shape[0]])
+                            self.ptrs.extend((b.data_ptr(), g.bias.data_ptr()))
+                        off += w.shape[0]
+                    off = 0
                 for w in ws:
                     o = w.shape[0]
                     rows.append([w.data_ptr(), o, k, 0, 0, 0, 0, 0, g.W.data_ptr() + 2 * off * g.W.stride(0), g.WT.data_ptr() + 2 * off,
@@ -361,7 +386,8 @@ class PlainRefreshPlan:
                     self.ptrs.append(w.data_ptr())
                     off += o
             self.tables.append((torch.tensor(rows, dtype=torch.int64).to(dev), torch.tensor(tiles, dtype=torch.int32).to(dev),
-                                tiles[-1], [(weakref.ref(g), ws) for g, ws in items], dev))
+                                tiles[-1], [(weakref.ref(g), ws, bs) for g, ws, bs in items], dev,
+                                torch.tensor(brows, dtype=torch.int64).to(dev) if brows else None))
         self.dirty = False
 
     def refresh(self) -> None:
@@ -371,23 +397,31 @@ class PlainRefreshPlan:
             if self.dirty:
                 self._build()
             cur, ok = [], True
-            for table, tile_start, total, items, dev in self.tables:
-                for gref, ws in items:
+            for table, tile_start, total, items, dev, btable in self.tables:
+                for gref, ws, bs in items:
                     g = gref()
                     ok = ok and g is not None and g.W is not None and g.WT is not None and all(w.requires_grad for w in ws)
+                    if ok and self._stacks_biases(g, ws, bs):  # (the same order _build appends in)
+                        for b in bs:
+                            if b is not None:
+                                cur.extend((b.data_ptr(), g.bias.data_ptr()))
                     cur.extend(w.data_ptr() for w in ws)
             if ok and cur == self.ptrs:
                 break
             self.dirty = True
         else:
             return
-        for table, tile_start, total, items, dev in self.tables:
+        for table, tile_start, total, items, dev, btable in self.tables:
             with torch.cuda.device(dev):
                 K.lora_refresh_mt(table, tile_start, table.shape[0], total)
-            for gref, ws in items:
+                if btable is not None:
+                    K.mt_copy_f32(btable)
+            for gref, ws, bs in items:
                 g = gref()
                 # only groups whose every weight is trainable were noted: `live` in shadows() is True for them
                 g.key = (tuple(_ver(w) for w in ws), True, epoch, None)
+                if btable is not None and self._stacks_biases(g, ws, bs):
+                    g.bkey = g._bias_key(bs)
 
 
 _PLAIN_PLAN = PlainRefreshPlan()
