@@ -24,7 +24,19 @@ def attn():
 def ln():
     x = torch.randn(M, 1280, device=dev).bfloat16(); g = torch.ones(1280, device=dev); b = torch.zeros(1280, device=dev)
     return lambda: K.layernorm_fwd(x, g, b)
-for name, mk in (("gemm_nt 5120x1280", lambda: gemm(5120, 1280)), ("gemm_nt 1280x5120", lambda: gemm(1280, 5120)), ("attn_bwd enc", attn), ("layernorm_fwd", ln)):
+def lib(N, Kd):  # the vendor library's kernel for the same product (yard-stick)
+    a = torch.randn(M, Kd, device=dev).bfloat16(); b = torch.randn(N, Kd, device=dev).bfloat16(); o = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    bt = b.t()
+    return lambda: torch.mm(a, bt, out=o)
+def zeros(N, Kd):  # all-zero operands: the same instruction stream at minimum switching power
+    a = torch.zeros(M, Kd, device=dev).bfloat16(); b = torch.zeros(N, Kd, device=dev).bfloat16(); o = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    return lambda: K.gemm_nt(a, b, out=o)
+CASES = (("gemm_nt 5120x1280", lambda: gemm(5120, 1280)), ("library 5120x1280", lambda: lib(5120, 1280)), ("gemm_nt 1280x1280", lambda: gemm(1280, 1280)),
+         ("library 1280x1280", lambda: lib(1280, 1280)), ("gemm_nt 5120x1280 zeros", lambda: zeros(5120, 1280)),
+         ("gemm_nt 1280x5120", lambda: gemm(1280, 5120)), ("attn_bwd enc", attn), ("layernorm_fwd", ln))
+if len(sys.argv) > 1:
+    CASES = tuple(c for c in CASES if any(k in c[0] for k in sys.argv[1:]))
+for name, mk in CASES:
     f = mk()
     for _ in range(5): f()
     torch.cuda.synchronize()
