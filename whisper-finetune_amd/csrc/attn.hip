@@ -445,53 +445,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
 }
 
 // ------------------------------------------------------------------------------ delta
-// delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d]
-// One wave = 64 consecutive queries of one (b, head): eight lanes share a row (16 bytes of O and dO each: whole 128-byte
-// lines), eight rows per pass, eight passes; the row sums are rotated so that lane L ends up owning query L and the two
-// outputs (delta, lse in log2 units) are written as 256 contiguous bytes.  HBM-bound: 2 * B * Tq * D * 2 bytes.
-__global__ __launch_bounds__(256) void attn_delta_kernel(AttnP p) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nqb = (p.Tq + 255) >> 8;
-  const int qb = blockIdx.x % nqb;
-  const int hd = (blockIdx.x / nqb) % p.H;
-  const int b = blockIdx.x / (nqb * p.H);
-  const int q0 = qb * 256 + wave * 64;
-  if (q0 >= p.Tq) return;
-  const int sub = lane >> 3, c = lane & 7;
-  const unsigned short* ob = p.o + (long)b * p.o_bs + hd * 64 + c * 8;
-  const unsigned short* db = p.d_o + (long)b * p.do_bs + hd * 64 + c * 8;
-  u32x4 av[8], dv[8];
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    int q = q0 + sub * 8 + it;
-    q = q < p.Tq ? q : p.Tq - 1;
-    av[it] = *(const u32x4*)(ob + (long)q * p.ldo);
-    dv[it] = *(const u32x4*)(db + (long)q * p.lddo);
-  }
-  float mine = 0.f;
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    float s = 0.f;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      s += bf2f((unsigned short)(av[it][e] & 0xffff)) * bf2f((unsigned short)(dv[it][e] & 0xffff));
-      s += bf2f((unsigned short)(av[it][e] >> 16)) * bf2f((unsigned short)(dv[it][e] >> 16));
-    }
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 4, 64);
-    if (c == it) mine = s;  // lane (sub, c) keeps row sub * 8 + c = its own lane number
-  }
-  const int q = q0 + lane;
-  if (q < p.Tq) {
-    const long sidx = ((long)b * p.H + hd) * p.Tq + q;
-    const long total = (long)p.B * p.Tq * p.H;
-    // NEGATED, so that both row constants enter the backward kernels' S and dP MFMA chains as their initial accumulators
-    // (S' = S - lse / scale, so exp2(c S') = exp(scale S - lse) needs no subtraction; dP' = dP - delta)
-    p.delta[sidx] = -mine;
-    p.delta[total + sidx] = -p.lse[sidx] / p.scale;
-  }
-}
+// delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d] and lse enter both backward kernels NEGATED, as the initial accumulators of the
+// dP and S MFMA chains (S' = S - lse / scale, so exp2(c S') = exp(scale S - lse) needs no subtraction; dP' = dP - delta).
+// Round 3: there is no delta kernel any more.  A lane of the dQ kernel already holds half of its query's dO row for the dP
+// product; it loads the same half of the O row, forms its 32 products, adds its partner lane's (the other half: lane ^ 32) and
+// has -delta; it writes both constants to the workspace for the dK/dV kernel, which runs behind it on the stream (96 launches and
+// a second pass over O and dO per step less: 3.6 ms at 68 clips).
 
 // ------------------------------------------------------------------------------ dQ
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
@@ -518,9 +477,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
   const AttOffs offs = att_offsets(lane);
   const AttStage stK = att_stage_init(p.ldk, wave, lane), stV = att_stage_init(p.ldv, wave, lane);
   const long sidx = ((long)b * p.H + hd) * p.Tq + qc;
-  // row constants of this lane's query (written negated by attn_delta_kernel): the initial accumulators of the S and dP chains
-  const float nlse = p.delta[(long)p.B * p.H * p.Tq + sidx];  // -lse / scale
-  const float ndlt = p.delta[sidx];                            // -rowsum(dO * O)
+  // row constants of this lane's query, negated: the initial accumulators of the S and dP chains
+  const float nlse = -p.lse[sidx] / p.scale;
+  float ndlt;
+  {
+    const unsigned short* orow = p.o + (long)b * p.o_bs + (long)qc * p.ldo + hd * 64;
+    float part = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bf16x8 of = att_load_reg_frag(orow, s, h);
+      const u32x4 ou = __builtin_bit_cast(u32x4, of), du = __builtin_bit_cast(u32x4, dof[s]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        part += bf2f((unsigned short)(ou[e] & 0xffff)) * bf2f((unsigned short)(du[e] & 0xffff));
+        part += bf2f((unsigned short)(ou[e] >> 16)) * bf2f((unsigned short)(du[e] >> 16));
+      }
+    }
+    ndlt = -(part + __shfl_xor(part, 32, 64));  // (a + b == b + a: both lanes of a query hold the same bits)
+  }
+  if (h == 0 && qi < p.Tq) {  // for the dK/dV kernel
+    p.delta[sidx] = ndlt;
+    p.delta[(long)p.B * p.H * p.Tq + sidx] = nlse;
+  }
 
   int nkt = (p.Tk + 63) >> 6;
   if (p.causal) {
@@ -651,7 +629,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
   const unsigned short* dob = p.d_o + (long)b * p.do_bs + hd * 64;
   const long sbase = ((long)b * p.H + hd) * p.Tq;
   const float* dlt_b = p.delta + sbase;
-  const float* lse_b = p.delta + (long)p.B * p.H * p.Tq + sbase;  // -lse / scale, written (like -delta) by attn_delta_kernel
+  const float* lse_b = p.delta + (long)p.B * p.H * p.Tq + sbase;  // -lse / scale, written (like -delta) by the dQ kernel, which runs first
   bf16x8 kf[4], vf[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
@@ -871,7 +849,12 @@ extern "C" int wft_attn_fwd_bf16(const wft_attn_args* a, void* stream) {
 // out[chunk][col] = sum over this chunk's partial rows (fixed order).  64 columns per workgroup (256-byte row segments),
 // 4 waves stride the rows; gridDim.y row chunks.  Run twice: [nrows] -> [ATT_CS_CHUNKS] -> [1].
 #define ATT_CS_CHUNKS 32
-__global__ __launch_bounds__(256) void attn_colsum_reduce_kernel(const float* partial, long nrows, int n, float* out) {
+__global__ __launch_bounds__(256) void attn_colsum_reduce_kernel(const float* partial0, long nrows0, float* out0,
+                                                                 const float* partial1, long nrows1, float* out1, int n) {
+  // blockIdx.z = 0: the q-projection's sums, 1: the v-projection's (one launch per level for both)
+  const float* partial = blockIdx.z ? partial1 : partial0;
+  const long nrows = blockIdx.z ? nrows1 : nrows0;
+  float* out = blockIdx.z ? out1 : out0;
   __shared__ float red[4][64];
   const int cx = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + cx;
@@ -910,7 +893,6 @@ extern "C" int wft_attn_bwd_bf16(const wft_attn_args* a, void* stream) {
     p.cs_v = a->colsum_ws + (long)a->B * ((a->Tq + 31) / 32) * a->H * 64;
   }
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)(((a->Tq + 255) / 256) * a->H * a->B)), dim3(256), 0, s, p);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(((a->Tq + 127) / 128) * a->H * a->B)), dim3(256), 0, s, p);
   {
     static bool lds_set[64] = {false};  // hipFuncSetAttribute is per device
@@ -927,11 +909,10 @@ extern "C" int wft_attn_bwd_bf16(const wft_attn_args* a, void* stream) {
     const long rq = (long)a->B * ((a->Tq + 31) / 32), rk = (long)a->B * ((a->Tk + 31) / 32);
     float* mid_q = p.cs_v + rk * n;
     float* mid_v = mid_q + (long)ATT_CS_CHUNKS * n;
-    const dim3 g1((n + 63) / 64, ATT_CS_CHUNKS), g2((n + 63) / 64, 1);
-    hipLaunchKernelGGL(attn_colsum_reduce_kernel, g1, dim3(256), 0, s, (const float*)p.cs_q, rq, n, mid_q);
-    hipLaunchKernelGGL(attn_colsum_reduce_kernel, g1, dim3(256), 0, s, (const float*)p.cs_v, rk, n, mid_v);
-    hipLaunchKernelGGL(attn_colsum_reduce_kernel, g2, dim3(256), 0, s, (const float*)mid_q, (long)ATT_CS_CHUNKS, n, a->dq_colsum);
-    hipLaunchKernelGGL(attn_colsum_reduce_kernel, g2, dim3(256), 0, s, (const float*)mid_v, (long)ATT_CS_CHUNKS, n, a->dv_colsum);
+    const dim3 g1((n + 63) / 64, ATT_CS_CHUNKS, 2), g2((n + 63) / 64, 1, 2);
+    hipLaunchKernelGGL(attn_colsum_reduce_kernel, g1, dim3(256), 0, s, (const float*)p.cs_q, rq, mid_q, (const float*)p.cs_v, rk, mid_v, n);
+    hipLaunchKernelGGL(attn_colsum_reduce_kernel, g2, dim3(256), 0, s, (const float*)mid_q, (long)ATT_CS_CHUNKS, a->dq_colsum,
+                       (const float*)mid_v, (long)ATT_CS_CHUNKS, a->dv_colsum, n);
   }
   WFT_CHECK_LAUNCH();
   return WFT_OK;
