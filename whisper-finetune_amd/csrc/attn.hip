@@ -339,7 +339,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
     const bool more = kt + 2 < nkt;
     if (more)
       att_stage2(stK, kb, p.ldk, smem + NXT2 * 16384, stV, vb, p.ldv, smem + NXT2 * 16384 + 8192, key0 + 128, p.Tk, wave, lane);
-    const bool active = !(p.causal && key0 > qw0 + 31);
+    // (a wave whose 32 queries all lie past the sequence end — T = 1500: the fourth wave of the last 128-query block — only
+    // stages and keeps the barriers)
+    const bool active = qw0 < p.Tq && !(p.causal && key0 > qw0 + 31);
     s16x4 vt[4][2][2];
     bf16x8 pf[4];
     if (active) {
@@ -526,7 +528,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
     }
     const char* kt_l = smem + CUR * 16384;
     const char* vt_l = kt_l + 8192;
-    if (!(p.causal && key0 > qw0 + 31)) {
+    if (qw0 < p.Tq && !(p.causal && key0 > qw0 + 31)) {
       f32x16 sacc[2], pacc[2];
 #pragma unroll
       for (int kb2 = 0; kb2 < 2; ++kb2) {
@@ -684,7 +686,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
     constexpr int CUR = decltype(cur_tag)::value;
     const int qq0 = qt * DKDV_Q;
     if (qt + 1 < nqt) stage_q(smem + (CUR ^ 1) * DKDV_BUF, qt + 1);
-    if (!(p.causal && kw0 > qq0 + DKDV_Q - 1)) {
+    if (kw0 < p.Tk && !(p.causal && kw0 > qq0 + DKDV_Q - 1)) {  // (a wave whose 32 keys lie past the end only stages)
       static_for<DKDV_Q / 32>([&](auto qb_tag) {
         constexpr int QB2 = decltype(qb_tag)::value;
         constexpr int qb2 = QB2;
