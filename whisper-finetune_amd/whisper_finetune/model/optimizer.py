@@ -78,8 +78,8 @@ def _adamw_groups_step(optimizer, groups, sumsq, max_norm):
             if table is None:
                 table = cache[key] = K.TensorTable(ps)
             grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
-            K.mt_adamw(table, [p.data for p in ps], grads, [optimizer.state[p]["exp_avg"] for p in ps],
-                       [optimizer.state[p]["exp_avg_sq"] for p in ps], group["lr"], b1, b2, group["eps"],
+            states = [optimizer.state[p] for p in ps]
+            K.mt_adamw(table, ps, grads, [st["exp_avg"] for st in states], [st["exp_avg_sq"] for st in states], group["lr"], b1, b2, group["eps"],
                        group["weight_decay"], 1 - b1 ** step, 1 - b2 ** step, sumsq, max_norm)
 
 
