@@ -210,6 +210,11 @@ typedef struct {
   int tn_block_n; int tn_block_r;
 } wft_gemm_args;
 int wft_gemm_nt_bf16(const wft_gemm_args* args, void* stream);
+/* Which 256x256 NT kernel serves the encoder-sized problems: 0 (default) = the one-wave-per-SIMD kernel (csrc/gemm_nt4w.hip)
+ * wherever it applies, 1 = always the 8-wave ping-pong kernel (csrc/gemm.hip).  Environment: WFT_NT_VARIANT=4w|pp, read once at
+ * load time.  Returns the previous setting; v < 0 only queries.  A/B tool and test hook: the two kernels accumulate in the same
+ * k order and give bit-identical C.                                                                        */
+int wft_gemm_set_nt_variant(int v);
 /* Which kernel wft_gemm_nt_bf16 dispatches these arguments to: 256 (gemm_nt256_kernel, 256x256
  * ping-pong tiles) or 128 (gemm_nt_kernel).  Pure host function (used by bench.py to attribute
  * HIP-event timings to the kernel names rocprofv3 reports).                              */

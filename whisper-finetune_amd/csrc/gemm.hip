@@ -18,42 +18,7 @@
 #endif
 #include <stdlib.h>
 
-struct GemmP {
-  const unsigned short* A; long lda; long sA;
-  const unsigned short* B; long ldb; long sB;
-  void* C; long ldc; long sC;
-  const float* bias;
-  const unsigned short* res; long ldr; long sR;
-  unsigned short* aux; long ldaux; long sAux;
-  float alpha, beta;
-  int M, N, K, batch;
-  int accumulate;
-  int period, valid;
-  int res_first;
-  float* ws;  // split-K partial tiles [nsplit][P][Q] fp32 (TN, optional)
-  float* cs_part;  // NT256: per-(row tile, wave row) column-sum partials [2*tiles_m][N] fp32, or NULL
-  int nsplit;  // gemm_tn_rank_kernel: split-K factor (its grid is 1-D)
-  int band;  // NT256: tile-order band width in column tiles (WFT_NT256_BAND, default 5)
-  int diag;  // WFT_GEMM_DIAG, NT256 A/B switches: 6 skips the staged epilogue (timing only), 7 = general epilogue body everywhere, 8 = no continuous staging
-};
-
-// sid -> (row tile, column tile) in column BANDS of 5 tiles, row-major inside a band: the 32 workgroups an XCD
-// runs at a time (consecutive sids) then cover a ~6 x 5 patch = 11 operand panels instead of 2 x 20 = 22 for a
-// wide N.  Measured before: FETCH_SIZE of the 48000x5120x1280 GEMM was 8x its algorithmic A+B bytes (every XCD
-// re-streamed all of B every round).
-__device__ __forceinline__ void band_coords(int sid, int tiles_r, int tiles_c, int& tr, int& tc, int W = 5) {
-  const int band = sid / (tiles_r * W);
-  const int c0 = band * W;
-  const int w = (tiles_c - c0) < W ? (tiles_c - c0) : W;
-  const int r = sid - band * tiles_r * W;
-  tr = r / w;
-  tc = c0 + r - tr * w;
-}
-
-__device__ __forceinline__ int xcd_remap(int bid, int ntile) {
-  const int q = ntile >> 3, r = ntile & 7, xcd = bid & 7;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-}
+#include "gemm_common.h"
 
 // ---------------------------------------------------------------------------------- NT
 template <int EPI, bool C_F32>
@@ -1458,8 +1423,14 @@ static int g_diag = 0;
 static int g_nt256_min_tiles = 128, g_tn256_min_steps = 64;
 static bool g_nt256_persistent = true;
 static int g_nt256_band = 5;
+// which 256x256 NT kernel: 0 = the one-wave-per-SIMD kernel where it applies (gemm_nt4w.hip), 1 = always the ping-pong kernel.
+// WFT_NT_VARIANT=pp|4w at load time; wft_gemm_set_nt_variant() for A/B runs inside one process.
+static int g_nt_variant = 0;
+bool wft_nt4w_eligible(const wft_gemm_args* a);
+int wft_nt4w_launch(const wft_gemm_args* a, const GemmP& p, bool persistent, void* stream);
+extern "C" int wft_gemm_set_nt_variant(int v) { const int o = g_nt_variant; if (v >= 0) g_nt_variant = v; return o; }
 static bool g_force_128 = false;  // debugging / A-B switch: WFT_GEMM_FORCE_128=1
-static struct EnvInit { EnvInit() { const char* e = getenv("WFT_GEMM_FORCE_128"); g_force_128 = e && e[0] == '1'; const char* d = getenv("WFT_GEMM_DIAG"); g_diag = d ? atoi(d) : 0; const char* t1 = getenv("WFT_NT256_MIN_TILES"); if (t1) g_nt256_min_tiles = atoi(t1); const char* t2 = getenv("WFT_TN256_MIN_STEPS"); if (t2) g_tn256_min_steps = atoi(t2); const char* pe = getenv("WFT_NT256_PERSISTENT"); if (pe) g_nt256_persistent = pe[0] != '0'; const char* bw = getenv("WFT_NT256_BAND"); if (bw && atoi(bw) > 0) g_nt256_band = atoi(bw); } } g_env_init;
+static struct EnvInit { EnvInit() { const char* e = getenv("WFT_GEMM_FORCE_128"); g_force_128 = e && e[0] == '1'; const char* d = getenv("WFT_GEMM_DIAG"); g_diag = d ? atoi(d) : 0; const char* t1 = getenv("WFT_NT256_MIN_TILES"); if (t1) g_nt256_min_tiles = atoi(t1); const char* t2 = getenv("WFT_TN256_MIN_STEPS"); if (t2) g_tn256_min_steps = atoi(t2); const char* pe = getenv("WFT_NT256_PERSISTENT"); if (pe) g_nt256_persistent = pe[0] != '0'; const char* bw = getenv("WFT_NT256_BAND"); if (bw && atoi(bw) > 0) g_nt256_band = atoi(bw); const char* nv = getenv("WFT_NT_VARIANT"); if (nv) g_nt_variant = (nv[0] == 'p') ? 1 : 0; } } g_env_init;
 
 static int fill_params(const wft_gemm_args* a, GemmP& p) {
   p.A = a->A; p.lda = a->lda; p.sA = a->strideA;
@@ -1481,36 +1452,6 @@ static int fill_params(const wft_gemm_args* a, GemmP& p) {
   return 0;
 }
 
-#define WFT_MAX_DEVICES 64
-static int wft_cur_device() {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= WFT_MAX_DEVICES) dev = 0;
-  return dev;
-}
-// CU count of the CURRENT device (cached per device id: a process may drive several GPUs)
-static int wft_num_cus() {
-  static int n[WFT_MAX_DEVICES] = {0};
-  const int dev = wft_cur_device();
-  if (n[dev] == 0) {
-    hipDeviceProp_t prop;
-    int v = 0;
-    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) v = prop.multiProcessorCount;
-    n[dev] = v > 0 ? v : 256;
-  }
-  return n[dev];
-}
-// hipFuncSetAttribute is per device: remember, per kernel call site, which devices have it
-struct DynLdsOnce {
-  bool done[WFT_MAX_DEVICES] = {false};
-  template <class K>
-  void set(K kfn, int bytes) {
-    const int dev = wft_cur_device();
-    if (!done[dev]) {
-      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-      done[dev] = true;
-    }
-  }
-};
 // out[col] = sum over `nrows` partial rows (fixed order): finishes the fused bias-gradient column sums of gemm_nt256_kernel
 __global__ __launch_bounds__(256) void nt_colsum_reduce_kernel(const float* partial, int nrows, int n, float* out) {
   __shared__ float red[8][33];
@@ -1567,6 +1508,16 @@ extern "C" int wft_gemm_nt_bf16(const wft_gemm_args* a, void* stream) {
   if (a->colsum) {
     WFT_CHECK_ARG(!a->c_is_f32 && a->batch == 1, "colsum needs a bf16 C and batch == 1");
     if (cs_fused) p.cs_part = (float*)a->workspace;
+  }
+  if (big && g_nt_variant != 1 && wft_nt4w_eligible(a)) {
+    const int rc = wft_nt4w_launch(a, p, g_nt256_persistent, stream);
+    if (rc != WFT_OK) return rc;
+    if (cs_fused)
+      hipLaunchKernelGGL(nt_colsum_reduce_kernel, dim3((unsigned)((a->N + 31) / 32)), dim3(256), 0, s, (const float*)a->workspace,
+                         (int)(2 * ((a->M + 255) / 256)), (int)a->N, a->colsum);
+    WFT_CHECK_LAUNCH();
+    if (a->colsum && !cs_fused) return wft_colsum_bf16((const wft_bf16*)a->C, a->M, a->N, a->ldc, a->colsum, 0, stream);
+    return WFT_OK;
   }
   if (big) {
     const long t256 = ((a->M + 255) / 256) * (a->N / 256) * a->batch;
