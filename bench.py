@@ -74,7 +74,7 @@ def lora_flops_per_clip(d, S: int, r: int) -> float:
     return enc + dec
 
 
-def pmc_traffic_per_launch(batch: int, lora: bool = False):
+def pmc_traffic_per_launch(batch: int, lora: bool = False, kname: str = "gemm_nt256_kernel"):
     """HBM bytes per gemm_nt256_kernel launch from the committed rocprofv3 PMC passes of THIS command
     (profiles/collect_r01.sh: --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, the only tracing next to them
     being --kernel-trace).  FETCH_SIZE is in KiB and counts 64 B per 128-B request on gfx950 for 16-B/lane streaming
@@ -91,7 +91,7 @@ def pmc_traffic_per_launch(batch: int, lora: bool = False):
         return None, f"PMC pass was collected at batch {d.get('batch', 68)}"
     tot = n = 0.0
     for k, v in d["FETCH_SIZE"].items():
-        if "gemm_nt256_kernel" in k:
+        if kname in k:
             w = d["WRITE_SIZE"][k]
             tot += (2.0 * v["sum"] + w["sum"]) * 1024.0
             n += v["launches"]
@@ -336,16 +336,20 @@ class Case:
             torch.cuda.synchronize()
             if rank == 0:
                 recs, K.PROFILE_NT = K.PROFILE_NT, None
-                big = [(s_.elapsed_time(e_), f, nb) for s_, e_, f, v, nb in recs if v == 256]  # gemm_nt256_kernel launches
-                kname = "gemm_nt256_kernel"
-                if not big:  # small models (whisper-base at 8 clips): every NT GEMM takes the 128x128 kernel
-                    big, kname = [(s_.elapsed_time(e_), f, nb) for s_, e_, f, v, nb in recs], "gemm_nt_kernel"
+                # the roofline kernel = the NT kernel family with the most time in the step (4: gemm_nt4w_kernel, 256: the ping-pong
+                # kernel, 128: the small-tile kernel — whisper-base at 8 clips)
+                names = {4: "gemm_nt4w_kernel", 256: "gemm_nt256_kernel", 128: "gemm_nt_kernel"}
+                by_v = {}
+                for s_, e_, f, v, nb in recs:
+                    by_v.setdefault(v, []).append((s_.elapsed_time(e_), f, nb))
+                vbig = max(by_v, key=lambda v: sum(t for t, _, _ in by_v[v]))
+                big, kname = by_v[vbig], names.get(vbig, str(vbig))
                 ms = sum(t for t, _, _ in big)
                 flops = sum(f for _, f, _ in big)
                 all_ms = sum(s_.elapsed_time(e_) for s_, e_, _, _, _ in recs)
                 all_fl = sum(f for _, _, f, _, _ in recs)
                 ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-                traffic, traffic_note = pmc_traffic_per_launch(B, self.lora) if (kname == "gemm_nt256_kernel" and self.model_name == "large-v3" and not self.prompt_ts) else (None, "no PMC pass committed for this configuration")
+                traffic, traffic_note = pmc_traffic_per_launch(B, self.lora, kname) if (kname in ("gemm_nt256_kernel", "gemm_nt4w_kernel") and self.model_name == "large-v3" and not self.prompt_ts) else (None, "no PMC pass committed for this configuration")
                 res["roofline"] = {
                     "kernel": kname, "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,

@@ -215,9 +215,9 @@ int wft_gemm_nt_bf16(const wft_gemm_args* args, void* stream);
  * load time.  Returns the previous setting; v < 0 only queries.  A/B tool and test hook: the two kernels accumulate in the same
  * k order and give bit-identical C.                                                                        */
 int wft_gemm_set_nt_variant(int v);
-/* Which kernel wft_gemm_nt_bf16 dispatches these arguments to: 256 (gemm_nt256_kernel, 256x256
- * ping-pong tiles) or 128 (gemm_nt_kernel).  Pure host function (used by bench.py to attribute
- * HIP-event timings to the kernel names rocprofv3 reports).                              */
+/* Which kernel wft_gemm_nt_bf16 dispatches these arguments to: 4 (gemm_nt4w_kernel: 256x256 tiles, four waves with 128x128
+ * accumulators each), 256 (gemm_nt256_kernel, the 8-wave ping-pong 256x256 kernel) or 128 (gemm_nt_kernel).  Pure host
+ * function (used by bench.py to attribute HIP-event timings to the kernel names rocprofv3 reports).        */
 int wft_gemm_nt_variant(const wft_gemm_args* args);
 int64_t wft_gemm_nt_colsum_workspace_bytes(const wft_gemm_args* args);
 /* C[p, q] (+)= alpha * sum_r A[r, p] * B[r, q]   (weight gradients dW = dY^T X:

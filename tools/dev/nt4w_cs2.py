@@ -6,7 +6,7 @@ from whisper_finetune.engine import kernels as K, lib as L
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 for rep in range(6):
-  for (M, N, Kd) in ((1024, 256, 256), (2048 + 112, 512, 384), (4000, 1280, 1280), (3072, 256, 5120), (1500 * 3, 3840, 1280)):
+  for (M, N, Kd) in ((1024, 256, 768), (2048 + 112, 512, 896), (4000, 1280, 1280), (3072, 256, 5120), (1500 * 3, 3840, 1280)):
     a = torch.randn(M, Kd, device=dev).to(torch.bfloat16); b = (torch.randn(N, Kd, device=dev) * 0.05).to(torch.bfloat16)
     bias = torch.randn(N, device=dev); res = torch.randn(M, N, device=dev).to(torch.bfloat16); auxin = torch.randn(M, N, device=dev).to(torch.bfloat16)
     ref0 = a.float() @ b.float().t()

@@ -1477,7 +1477,10 @@ static bool nt_uses_256(const wft_gemm_args* a) {
   return !g_force_128 && wide_ok && a->N % 256 == 0 && a->M >= 1024 &&
          ((a->M + 255) / 256) * (a->N / 256) * a->batch >= g_nt256_min_tiles;
 }
-extern "C" int wft_gemm_nt_variant(const wft_gemm_args* a) { return a && nt_uses_256(a) ? 256 : 128; }
+extern "C" int wft_gemm_nt_variant(const wft_gemm_args* a) {
+  if (!a || !nt_uses_256(a)) return 128;
+  return (g_nt_variant != 1 && wft_nt4w_eligible(a)) ? 4 : 256;
+}
 
 extern "C" int64_t wft_gemm_nt_colsum_workspace_bytes(const wft_gemm_args* a) {
   if (!a || !a->colsum || a->c_is_f32 || a->batch != 1 || !nt_uses_256(a)) return 0;
