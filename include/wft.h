@@ -215,6 +215,10 @@ int wft_gemm_nt_bf16(const wft_gemm_args* args, void* stream);
  * load time.  Returns the previous setting; v < 0 only queries.  A/B tool and test hook: the two kernels accumulate in the same
  * k order and give bit-identical C.                                                                        */
 int wft_gemm_set_nt_variant(int v);
+/* The same switch for the weight-gradient GEMM: 0 (default) = gemm_tn4w_kernel (csrc/gemm_tn4w.hip) where it applies, 1 = always
+ * gemm_tn256_kernel.  WFT_TN_VARIANT=4w|pp at load time.  Both sum the reduction in ascending 32-row MFMA steps inside a split;
+ * their split-K plans may differ (different partial sums, same fixed order from run to run).                          */
+int wft_gemm_set_tn_variant(int v);
 /* Which kernel wft_gemm_nt_bf16 dispatches these arguments to: 4 (gemm_nt4w_kernel: 256x256 tiles, four waves with 128x128
  * accumulators each), 256 (gemm_nt256_kernel, the 8-wave ping-pong 256x256 kernel) or 128 (gemm_nt_kernel).  Pure host
  * function (used by bench.py to attribute HIP-event timings to the kernel names rocprofv3 reports).        */

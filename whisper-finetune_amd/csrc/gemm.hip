@@ -1427,10 +1427,16 @@ static int g_nt256_band = 5;
 // WFT_NT_VARIANT=pp|4w at load time; wft_gemm_set_nt_variant() for A/B runs inside one process.
 static int g_nt_variant = 0;
 bool wft_nt4w_eligible(const wft_gemm_args* a);
+// the one-wave-per-SIMD weight-gradient kernel (gemm_tn4w.hip): WFT_TN_VARIANT=pp keeps gemm_tn256_kernel
+static int g_tn_variant = 0;
+bool wft_tn4w_eligible(const wft_gemm_args* a);
+void wft_tn4w_plan(const wft_gemm_args* a, int* nsplit_out, int* per_out);
+int wft_tn4w_launch(const wft_gemm_args* a, GemmP p, int nsplit, int per, void* stream);
+extern "C" int wft_gemm_set_tn_variant(int v) { const int o = g_tn_variant; if (v >= 0) g_tn_variant = v; return o; }
 int wft_nt4w_launch(const wft_gemm_args* a, const GemmP& p, bool persistent, void* stream);
 extern "C" int wft_gemm_set_nt_variant(int v) { const int o = g_nt_variant; if (v >= 0) g_nt_variant = v; return o; }
 static bool g_force_128 = false;  // debugging / A-B switch: WFT_GEMM_FORCE_128=1
-static struct EnvInit { EnvInit() { const char* e = getenv("WFT_GEMM_FORCE_128"); g_force_128 = e && e[0] == '1'; const char* d = getenv("WFT_GEMM_DIAG"); g_diag = d ? atoi(d) : 0; const char* t1 = getenv("WFT_NT256_MIN_TILES"); if (t1) g_nt256_min_tiles = atoi(t1); const char* t2 = getenv("WFT_TN256_MIN_STEPS"); if (t2) g_tn256_min_steps = atoi(t2); const char* pe = getenv("WFT_NT256_PERSISTENT"); if (pe) g_nt256_persistent = pe[0] != '0'; const char* bw = getenv("WFT_NT256_BAND"); if (bw && atoi(bw) > 0) g_nt256_band = atoi(bw); const char* nv = getenv("WFT_NT_VARIANT"); if (nv) g_nt_variant = (nv[0] == 'p') ? 1 : 0; } } g_env_init;
+static struct EnvInit { EnvInit() { const char* e = getenv("WFT_GEMM_FORCE_128"); g_force_128 = e && e[0] == '1'; const char* d = getenv("WFT_GEMM_DIAG"); g_diag = d ? atoi(d) : 0; const char* t1 = getenv("WFT_NT256_MIN_TILES"); if (t1) g_nt256_min_tiles = atoi(t1); const char* t2 = getenv("WFT_TN256_MIN_STEPS"); if (t2) g_tn256_min_steps = atoi(t2); const char* pe = getenv("WFT_NT256_PERSISTENT"); if (pe) g_nt256_persistent = pe[0] != '0'; const char* bw = getenv("WFT_NT256_BAND"); if (bw && atoi(bw) > 0) g_nt256_band = atoi(bw); const char* nv = getenv("WFT_NT_VARIANT"); if (nv) g_nt_variant = (nv[0] == 'p') ? 1 : 0; const char* tv = getenv("WFT_TN_VARIANT"); if (tv) g_tn_variant = (tv[0] == 'p') ? 1 : 0; } } g_env_init;
 
 static int fill_params(const wft_gemm_args* a, GemmP& p) {
   p.A = a->A; p.lda = a->lda; p.sA = a->strideA;
@@ -1650,7 +1656,12 @@ static int64_t tn_ws_rows(const wft_gemm_args* a) {
 static bool tn_needs_reduce(const wft_gemm_args* a) { return a->tn_col_scale != nullptr || a->tn_block_n > 0; }
 extern "C" int64_t wft_gemm_tn_workspace_bytes(const wft_gemm_args* a) {
   if (!a) return 0;
-  const int nsplit = tn_uses_256(a) ? tn256_nsplit(a) : tn128_nsplit(a);
+  int nsplit = tn_uses_256(a) ? tn256_nsplit(a) : tn128_nsplit(a);
+  if (tn_uses_256(a) && wft_tn4w_eligible(a)) {  // (the larger of the two plans: the variant switch may change between this call and the launch)
+    int ns4, per4;
+    wft_tn4w_plan(a, &ns4, &per4);
+    if (ns4 > nsplit) nsplit = ns4;
+  }
   return (nsplit > 1 || tn_needs_reduce(a)) ? (int64_t)nsplit * tn_ws_rows(a) * a->N * 4 : 0;
 }
 
@@ -1676,6 +1687,25 @@ extern "C" int wft_gemm_tn_bf16(const wft_gemm_args* a, void* stream) {
   fill_params(a, p);
   hipStream_t s = (hipStream_t)stream;
   const long nsteps = ((a->K + 63) / 64) * a->batch;
+  if (tn_uses_256(a) && g_tn_variant != 1 && wft_tn4w_eligible(a)) {
+    int nsplit, per;
+    wft_tn4w_plan(a, &nsplit, &per);
+    const bool use_ws = nsplit > 1 && a->workspace && a->workspace_bytes >= (int64_t)nsplit * a->M * a->N * 4 &&
+                        (((uintptr_t)a->workspace) & 15) == 0;
+    if (nsplit == 1 || use_ws) {  // (split without a workspace: the ping-pong kernel's atomic path below)
+      if (use_ws) p.ws = (float*)a->workspace;
+      wft_tn4w_launch(a, p, nsplit, per, stream);
+      if (use_ws) {
+        const long total = a->M * (a->N / 4);
+        long g = (total + 255) / 256;
+        if (g > 2048) g = 2048;
+        hipLaunchKernelGGL(tn_splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, (const float*)a->workspace, (float*)a->C,
+                           (long)a->ldc, (int)a->M, (int)a->N, nsplit, a->accumulate, (int)a->M, (const float*)nullptr, 0, 0, 0, (int)a->M);
+      }
+      WFT_CHECK_LAUNCH();
+      return WFT_OK;
+    }
+  }
   if (tn_uses_256(a)) {
     // 256x256 tiles, one workgroup per CU: pick the split-K factor that fills 256 slots in whole waves
     const long t256 = (a->M / 256) * (a->N / 256);

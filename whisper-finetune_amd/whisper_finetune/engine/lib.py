@@ -97,6 +97,7 @@ SIGNATURES = {
     "wft_gemm_nt_bf16": [C.POINTER(GemmArgs), c_vp],
     "wft_gemm_nt_variant": [C.POINTER(GemmArgs)],
     "wft_gemm_set_nt_variant": [C.c_int],
+    "wft_gemm_set_tn_variant": [C.c_int],
     "wft_gemm_nt_colsum_workspace_bytes": [C.POINTER(GemmArgs)],
     "wft_gemm_tn_bf16": [C.POINTER(GemmArgs), c_vp],
     "wft_gemm_nt_rank_pair_bf16": [C.POINTER(GemmArgs), C.POINTER(GemmArgs), c_vp],
