@@ -36,6 +36,11 @@
 #define NT4W_BIAS (2 * NT4W_BUF)      // two 1 KiB bias slices (this tile / next tile) behind the k-step buffers
 #define NT4W_LDS (NT4W_BIAS + 2048)   // 137 216 B
 
+// Cache policy of the output stores: sc0 nt (3).  A tile's 128 KiB of C are not read again by this kernel; written with the default
+// policy they displace operand panels from the XCD's 4 MiB L2 (measured at 102000 x 5120 x 1280: default 1 184-1 189 TF/s, nt
+// 1 219, sc0 nt 1 230, sc1 1 218; WFT_GEMM_DIAG=30 restores the default for A/B runs).
+#define NT4W_ST_AUX 3
+
 #define NT4W_STR2(x) #x
 #define NT4W_STR(x) NT4W_STR2(x)
 
@@ -448,92 +453,118 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmP p) {
       const unsigned long long b = nt4w_sgpr64((unsigned long long)base);
       return __builtin_amdgcn_make_buffer_rsrc((void*)b, (short)0, (int)nt4w_sgpr((unsigned)rows * (unsigned)ld * 2u), 0x00020000);
     };
-    // WFT_GEMM_DIAG (timing only): 22 = every C store dropped (a descriptor of zero records: the instructions still issue),
-    // 23 = whole-line store pattern.  Measured at 102000 x 5120 x 1280: 1 215 TF/s as shipped, 1 430 without the stores' traffic,
-    // 1 267 with whole lines; handing half of the stores to the next tile's K loop (2 per k-step) costs exactly what it saves —
-    // the per-CU memory path, shared with the K loop's 64 KiB per k-step, is the limit (profiles/README.md, round 4).
+    // WFT_GEMM_DIAG=22 (timing only): every C store dropped (a descriptor of zero records: the instructions still issue).  Measured
+    // at 102000 x 5120 x 1280 with half-line stores: 1 215 TF/s, 1 430 without the stores' traffic, 1 267 with whole lines; handing
+    // half of the stores to the next tile's K loop (2 per k-step) costs exactly what it saves — the per-CU memory path, shared with
+    // the K loop's 64 KiB per k-step, is the limit (profiles/README.md, round 4).
     const auto srdC = srd_of((const unsigned short*)p.C + (long)bz * p.sC + (long)m0 * p.ldc, p.diag == 22 ? 0 : p.ldc);
     const unsigned offC = (row_l * (unsigned)p.ldc + (unsigned)ncol) * 2u, stepC = nt4w_sgpr(32u * (unsigned)p.ldc);
-    const unsigned offC23 = ((unsigned)(wm * 128 + (mr & 7) + after_loop) * (unsigned)p.ldc + (unsigned)(n0 + wn * 128 + 32 * (mr >> 3) + 8 * q)) * 2u;
-    // The 32 groups (fx, u) of a lane are walked u-major: g = 8 u + fx (a column chunk top to bottom, then the next chunk).
+    // The 32 groups (fx, u) of a lane are walked in column-chunk PAIRS: order o = 16 up + 2 fx + (u & 1), u = 2 up + (u & 1): both
+    // chunks of a row band are converted, then stored together as whole 128-byte lines (store_pair below).
     // Residual / aux rows of this lane: a ring of 16 groups (64 registers; all 32 would leave the lane constants no room beside
-    // them): groups 0-15 are fetched up front, group g + 16 as soon as g has been consumed.
+    // them): the first 16 in walking order are fetched up front, group o + 16 as soon as o has been consumed.
     u32x4 opq[16];
     const unsigned short* const ob = RD_AUX ? p.aux + (long)bz * p.sAux + (long)m0 * p.ldaux : p.res + (long)bz * p.sR + (long)m0 * p.ldr;
     const long ldo = RD_AUX ? p.ldaux : p.ldr;
     const auto srdO = srd_of((RD_AUX || has_res) ? (const void*)ob : (const void*)p.C, (RD_AUX || has_res) ? ldo : 0);
     const unsigned offO = (row_l * (unsigned)ldo + (unsigned)ncol) * 2u, stepO = nt4w_sgpr(32u * (unsigned)ldo);
-    if constexpr (RD_AUX || has_res) {
-      nt4w_for<0, 16>([&](auto g) {
-        opq[g] = __builtin_amdgcn_raw_buffer_load_b128(srdO, offO + (decltype(g)::value & 7) * stepO + 64u * (decltype(g)::value >> 3), 0, 0);
-      });
-    }
+    auto load_o = [&](auto oc) {  // group number oc in walking order
+      constexpr int o = decltype(oc)::value, fx = (o >> 1) & 7, u = 2 * (o >> 4) + (o & 1);
+      opq[o & 15] = __builtin_amdgcn_raw_buffer_load_b128(srdO, offO + fx * stepO + 64u * u, 0, 0);
+    };
+    if constexpr (RD_AUX || has_res) nt4w_for<0, 16>(load_o);
     const auto srdA = srd_of(WR_AUX ? p.aux + (long)bz * p.sAux + (long)m0 * p.ldaux : (const unsigned short*)p.C, WR_AUX ? p.ldaux : 0);
-    const unsigned offA = (row_l * (unsigned)p.ldaux + (unsigned)ncol) * 2u, stepA = nt4w_sgpr(32u * (unsigned)p.ldaux);
-    nt4w_for<0, 4>([&](auto uc) {
-      constexpr int u = decltype(uc)::value;
-      const f32x4 b0 = *(const f32x4*)(bias_l + 32 * u), b1 = *(const f32x4*)(bias_l + 32 * u + 4);
-      float cs[8];
+    const unsigned stepA = nt4w_sgpr(32u * (unsigned)p.ldaux);
+    // Whole-line stores.  As they leave the MFMA a lane (q, mr) holds 16 bytes of row mr in each column chunk, so one store
+    // instruction would write 16 rows x 64 B: half lines, and the CU's store path is paid per request (measured: whole lines cost
+    // 27 % less, profiles/README.md round 4).  Two DPP moves per dword (row_ror:8 = lanes mr <-> mr + 8 of a 16-lane row, bank
+    // masks) regroup a chunk pair: store 1 = rows 0-7 of the band, store 2 = rows 8-15, every row a full 128-byte line
+    //   lanes mr < 8 : [own chunk u]              | [chunk u of lane mr + 8]
+    //   lanes mr >= 8: [chunk u+1 of lane mr - 8] | [own chunk u+1]
+    const unsigned lrow = (unsigned)(wm * 128 + (mr & 7)) + after_loop, lcol = (unsigned)(n0 + wn * 128 + 32 * (mr >> 3) + 8 * q);
+    const unsigned offCL = (lrow * (unsigned)p.ldc + lcol) * 2u, offAL = (lrow * (unsigned)p.ldaux + lcol) * 2u;
+    auto store_pair = [&](auto srd, unsigned off, unsigned half_step, const u32x4& pu, const u32x4& pv) {
+      u32x4 s1, s2;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) cs[e] = 0.f;
+      for (int e = 0; e < 4; ++e) {
+        s1[e] = (unsigned)__builtin_amdgcn_update_dpp((int)pu[e], (int)pv[e], 0x128, 0xf, 0xc, false);
+        s2[e] = (unsigned)__builtin_amdgcn_update_dpp((int)pv[e], (int)pu[e], 0x128, 0xf, 0x3, false);
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(s1, srd, off, 0, NT4W_ST_AUX);
+      __builtin_amdgcn_raw_buffer_store_b128(s2, srd, off + half_step, 0, NT4W_ST_AUX);
+    };
+    nt4w_for<0, 2>([&](auto upc) {
+      constexpr int up = decltype(upc)::value;
+      float cs[2][8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { cs[0][e] = 0.f; cs[1][e] = 0.f; }
       nt4w_for<0, 8>([&](auto fxc) {
-        constexpr int fx = decltype(fxc)::value, g = 8 * u + fx;
-        constexpr int i0 = (fx * 8 + 2 * u) * 4, i1 = i0 + 4;
-        float v[8];
-        v[0] = nt4w_acc<i0>(); v[1] = nt4w_acc<i0 + 1>(); v[2] = nt4w_acc<i0 + 2>(); v[3] = nt4w_acc<i0 + 3>();
-        v[4] = nt4w_acc<i1>(); v[5] = nt4w_acc<i1 + 1>(); v[6] = nt4w_acc<i1 + 2>(); v[7] = nt4w_acc<i1 + 3>();
+        constexpr int fx = decltype(fxc)::value;
+        u32x4 pk[2], dpk[2];
+        nt4w_for<0, 2>([&](auto hc) {
+          constexpr int hh = decltype(hc)::value, u = 2 * up + hh, o = 16 * up + 2 * fx + hh;
+          constexpr int i0 = (fx * 8 + 2 * u) * 4, i1 = i0 + 4;
+          const f32x4 b0 = *(const f32x4*)(bias_l + 32 * u), b1 = *(const f32x4*)(bias_l + 32 * u + 4);
+          float v[8];
+          v[0] = nt4w_acc<i0>(); v[1] = nt4w_acc<i0 + 1>(); v[2] = nt4w_acc<i0 + 2>(); v[3] = nt4w_acc<i0 + 3>();
+          v[4] = nt4w_acc<i1>(); v[5] = nt4w_acc<i1 + 1>(); v[6] = nt4w_acc<i1 + 2>(); v[7] = nt4w_acc<i1 + 3>();
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = v[e] * p.alpha + b0[e]; v[4 + e] = v[4 + e] * p.alpha + b1[e]; }
-        if constexpr (EPI == WFT_EPI_GELU_GRAD) {
-          float dv[8];
+          for (int e = 0; e < 4; ++e) { v[e] = v[e] * p.alpha + b0[e]; v[4 + e] = v[4 + e] * p.alpha + b1[e]; }
+          if constexpr (EPI == WFT_EPI_GELU_GRAD) {
+            float dv[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) gelu_both_f(v[e], v[e], dv[e]);
-          const u32x4 pk = {pack2bf(dv[0], dv[1]), pack2bf(dv[2], dv[3]), pack2bf(dv[4], dv[5]), pack2bf(dv[6], dv[7])};
-          __builtin_amdgcn_raw_buffer_store_b128(pk, srdA, offA + fx * stepA + 64u * u, 0, 0);
-        } else if constexpr (EPI == WFT_EPI_MUL_AUX) {
-          const u32x4 a4 = opq[g & 15];
+            for (int e = 0; e < 8; ++e) gelu_both_f(v[e], v[e], dv[e]);
+            dpk[hh] = u32x4{pack2bf(dv[0], dv[1]), pack2bf(dv[2], dv[3]), pack2bf(dv[4], dv[5]), pack2bf(dv[6], dv[7])};
+          } else if constexpr (EPI == WFT_EPI_MUL_AUX) {
+            const u32x4 a4 = opq[o & 15];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[2 * e] *= __builtin_bit_cast(float, a4[e] << 16);
-            v[2 * e + 1] *= __builtin_bit_cast(float, a4[e] & 0xffff0000u);
+            for (int e = 0; e < 4; ++e) {
+              v[2 * e] *= __builtin_bit_cast(float, a4[e] << 16);
+              v[2 * e + 1] *= __builtin_bit_cast(float, a4[e] & 0xffff0000u);
+            }
           }
-        }
-        if constexpr (!RD_AUX && has_res) {
-          const u32x4 r4 = opq[g & 15];
+          if constexpr (!RD_AUX && has_res) {
+            const u32x4 r4 = opq[o & 15];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[2 * e] += p.beta * __builtin_bit_cast(float, r4[e] << 16);
-            v[2 * e + 1] += p.beta * __builtin_bit_cast(float, r4[e] & 0xffff0000u);
+            for (int e = 0; e < 4; ++e) {
+              v[2 * e] += p.beta * __builtin_bit_cast(float, r4[e] << 16);
+              v[2 * e + 1] += p.beta * __builtin_bit_cast(float, r4[e] & 0xffff0000u);
+            }
           }
-        }
-        if constexpr ((RD_AUX || has_res) && g < 16)
-          opq[g & 15] = __builtin_amdgcn_raw_buffer_load_b128(srdO, offO + ((g + 16) & 7) * stepO + 64u * ((g + 16) >> 3), 0, 0);
-        const u32x4 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
-        if (p.diag == 23)  // timing only (values land in the wrong place): every store instruction writes 8 rows x 128 B, whole lines
-          __builtin_amdgcn_raw_buffer_store_b128(pk, srdC, offC23 + fx * stepC + (u & 1) * (stepC >> 1) + 128u * (u >> 1), 0, 0);
-        else
-          __builtin_amdgcn_raw_buffer_store_b128(pk, srdC, offC + fx * stepC + 64u * u, 0, 0);
-        if constexpr (CS) {  // (rows >= M hold exact zeros only without a bias; the engine asks for column sums of bias-free products)
-          const bool row_ok = (int)(row_l + 16 * fx) < rows;
+          if constexpr ((RD_AUX || has_res) && o < 16) load_o(std::integral_constant<int, o + 16>{});
+          pk[hh] = u32x4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+          if constexpr (CS) {  // (rows >= M hold exact zeros only without a bias; the engine asks for column sums of bias-free products)
+            const bool row_ok = (int)(row_l + 16 * fx) < rows;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) cs[e] += row_ok ? v[e] : 0.f;
+            for (int e = 0; e < 8; ++e) cs[hh][e] += row_ok ? v[e] : 0.f;
+          }
+        });
+        if constexpr (WR_AUX) store_pair(srdA, offAL + fx * stepA + 128u * up, stepA >> 1, dpk[0], dpk[1]);
+        if (p.diag == 30) {  // (A/B: half-line stores, default cache policy — the first form of this epilogue)
+          __builtin_amdgcn_raw_buffer_store_b128(pk[0], srdC, offC + fx * stepC + 128u * up, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(pk[1], srdC, offC + fx * stepC + 128u * up + 64u, 0, 0);
+        } else {
+          store_pair(srdC, offCL + fx * stepC + 128u * up, stepC >> 1, pk[0], pk[1]);
         }
       });
-      if constexpr (CS) {  // column sums of this wave's 128 rows in chunk u: reduce over the 16 row lanes; lane mr == 0 of each group stores
+      if constexpr (CS) {  // column sums of this wave's 128 rows in chunks 2 up, 2 up + 1: reduce over the 16 row lanes; lane mr == 0 stores
+        nt4w_for<0, 2>([&](auto hc) {
+          constexpr int hh = decltype(hc)::value, u = 2 * up + hh;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float sacc = cs[e];
-          sacc += __shfl_xor(sacc, 1, 64);
-          sacc += __shfl_xor(sacc, 2, 64);
-          sacc += __shfl_xor(sacc, 4, 64);
-          sacc += __shfl_xor(sacc, 8, 64);
-          cs[e] = sacc;
-        }
-        if (mr == 0) {
-          float* dst = p.cs_part + (long)(tm * 2 + wm) * p.N + ncol + 32 * u;
-          *(f32x4*)dst = f32x4{cs[0], cs[1], cs[2], cs[3]};
-          *(f32x4*)(dst + 4) = f32x4{cs[4], cs[5], cs[6], cs[7]};
-        }
+          for (int e = 0; e < 8; ++e) {
+            float sacc = cs[hh][e];
+            sacc += __shfl_xor(sacc, 1, 64);
+            sacc += __shfl_xor(sacc, 2, 64);
+            sacc += __shfl_xor(sacc, 4, 64);
+            sacc += __shfl_xor(sacc, 8, 64);
+            cs[hh][e] = sacc;
+          }
+          if (mr == 0) {
+            float* dst = p.cs_part + (long)(tm * 2 + wm) * p.N + ncol + 32 * u;
+            *(f32x4*)dst = f32x4{cs[hh][0], cs[hh][1], cs[hh][2], cs[hh][3]};
+            *(f32x4*)(dst + 4) = f32x4{cs[hh][4], cs[hh][5], cs[hh][6], cs[hh][7]};
+          }
+        });
       }
     });
   }
