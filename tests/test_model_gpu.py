@@ -42,7 +42,7 @@ def assert_lora_grad_errors(errs):
 
 def assert_grad_errors(errs, tag=""):
     """Per-tensor relative-L2 gradient errors of a bf16 engine step against the oracle (fp32 or bf16-emulating).
-    Calibrated on the GPU (tools/dev_emu_tol.py, tiny and base): every tensor but the q / k projections of the decoder's causal
+    Calibrated on the GPU (tools/dev/emu_tol.py, tiny and base): every tensor but the q / k projections of the decoder's causal
     self-attention sits at 0.9-1.6 % (bound 3e-2 — a mis-scaled term moves a tensor by tens of per cent); those q / k tensors
     are small differences of large terms under near-uniform attention and reach 3.5-6.8 % for ANY two bf16 evaluations
     (bound 8e-2); median 0.5-0.9 % (bound 1.5e-2)."""
