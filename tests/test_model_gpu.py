@@ -486,6 +486,20 @@ def test_lora_masks_survive_a_second_forward_before_the_backward():
         s1 = pool.serial
         m.encoder(mel)
     assert s1 > s0 and pool.serial > s1
+    # forward_loss called directly is ONE forward of the model — one draw, and the same loss / gradients as
+    # the same call through the module
+    m3, m4 = build(), build()
+    pool3 = m3.__dict__["_wft_lora_pool"]
+    draws = []
+    on_forward = pool3._on_forward
+    pool3._on_forward = lambda *a: (draws.append(1), on_forward(*a))[1]
+    torch.manual_seed(303); l3 = m3.forward_loss(mel, y_in, y_out)
+    l3.backward()
+    assert len(draws) == 1
+    torch.manual_seed(303); l4 = m4(mel, y_in, targets=y_out); l4.backward()
+    assert torch.equal(l3, l4)
+    g3, g4 = grads(m3), grads(m4)
+    assert max(rel(g3[n], g4[n]) for n in g4) < 1e-6
 
 
 def test_train_step_on_the_engine_follows_the_references_loss_sequence():

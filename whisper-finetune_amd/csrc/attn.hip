@@ -886,6 +886,7 @@ extern "C" int wft_attn_bwd_bf16(const wft_attn_args* a, void* stream) {
                     ATT_ALIGNED(a->dk, a->lddk, a->dk_bs) && ATT_ALIGNED(a->dv, a->lddv, a->dv_bs),
                 "tensors need 16-byte aligned bases and strides that are multiples of 8");
   WFT_CHECK_ARG(!a->causal || a->Tq == a->Tk, "causal attention needs Tq == Tk");
+  WFT_CHECK_ARG(a->scale > 0.f, "scale must be positive (the row constants are -lse / scale)");
   WFT_CHECK_ARG((!a->dq_colsum && !a->dv_colsum && !a->colsum_ws) || (a->dq_colsum && a->dv_colsum && a->colsum_ws),
                 "dq_colsum, dv_colsum and colsum_ws go together");
   AttnP p;
@@ -901,7 +902,12 @@ extern "C" int wft_attn_bwd_bf16(const wft_attn_args* a, void* stream) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!lds_set[dev]) {
-      (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DKDV_BUF);
+      const hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dkdv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DKDV_BUF);
+      if (e != hipSuccess) {  // (not remembered: the next call tries again)
+        wft_set_error("wft_attn_bwd_bf16: the dK/dV kernel needs %d bytes of dynamic LDS (160 KiB per CU: gfx950), hipFuncSetAttribute: %s",
+                      2 * DKDV_BUF, hipGetErrorString(e));
+        return WFT_ERR_LAUNCH;
+      }
       lds_set[dev] = true;
     }
   }

@@ -621,12 +621,16 @@ class TensorTable:
                 if t is None and allow_none:
                     flat.append(0)
                     continue
-                if not (trust and id(t) in seen):
+                ptr = t.data_ptr()
+                # validated once per (object, storage address, dtype): an id recycled by another tensor after
+                # optimizer.load_state_dict, or a parameter re-typed in place (.data = ..., model.half()), is checked again
+                key = (id(t), ptr, t.dtype)
+                if not (trust and key in seen):
                     if t.dtype != F32 or not t.is_contiguous() or not t.is_cuda:
                         raise L.WftError("multi-tensor optimizer kernels need contiguous f32 HIP tensors")
                     if trust:
-                        seen.add(id(t))
-                flat.append(t.data_ptr())
+                        seen.add(key)
+                flat.append(ptr)
         return upload_table(flat, torch.int64, self.device)
 
 

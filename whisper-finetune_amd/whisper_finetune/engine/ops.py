@@ -57,11 +57,13 @@ def note_shadowed(tensors) -> None:
 
 
 def _optimizer_post_hook(optimizer, args, kwargs):
-    gen = _SHADOWED_GEN[0]
+    # (re-)classify when the set of shadowed parameters OR the optimizer's own parameter list has changed (add_param_group with
+    # parameters that were already shadowed leaves the generation alone: the signature below catches it)
+    sig = (_SHADOWED_GEN[0], len(optimizer.param_groups), sum(len(g["params"]) for g in optimizer.param_groups))
     owns = optimizer.__dict__.get("_wft_owns_shadowed")
-    if owns is None or owns[0] != gen:  # (re-)classify when the set of shadowed parameters has changed
+    if owns is None or owns[0] != sig:
         hit = any((r := _SHADOWED.get(id(p))) is not None and r() is p for g in optimizer.param_groups for p in g["params"])
-        owns = optimizer.__dict__["_wft_owns_shadowed"] = (gen, hit)
+        owns = optimizer.__dict__["_wft_owns_shadowed"] = (sig, hit)
     if owns[1]:
         bump_shadow_epoch()
 

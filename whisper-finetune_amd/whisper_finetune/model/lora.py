@@ -97,8 +97,9 @@ class LoraMaskPool:
     yet: `loss = model(a) + model(b)`, R-Drop, a train-mode probe — and moves their masks to a snapshot of the old values; their
     backward then rebuilds its operands from exactly the masks its forward used (the per-Linear path: the serial differs).  In the
     ordinary loop (forward, backward, step) no spec survives to the next draw and nothing is copied.
-    Train-mode calls that enter below the root (`model.encoder(x)`, `model.forward_loss(...)`) reach the same draw through hooks
-    on the root's direct children: they draw when no forward of the root is in progress."""
+    Train-mode calls that enter below the root (`model.encoder(x)`) reach the same draw through hooks on the root's direct
+    children: they draw when no forward of the root is in progress; `model.forward_loss(...)` is wrapped to count as one forward
+    of the root."""
 
     def __init__(self, root: nn.Module):
         self.adapters = []
@@ -114,6 +115,18 @@ class LoraMaskPool:
         for child in root.children():  # (encoder, decoder): entry points of calls that bypass root.__call__
             self.handles.append(child.register_forward_pre_hook(self._on_child_forward))
         self.root = root
+        # `model.forward_loss(...)` is a plain method, not a child module: wrapped so that it counts as ONE forward of the root (one
+        # draw; without this its encoder and decoder calls each looked like an entry below the root — a second draw while the
+        # first one's specs were alive, and with checkpointed blocks a recompute against the wrong masks)
+        inner = getattr(root, "forward_loss", None)
+        if callable(inner) and "forward_loss" not in root.__dict__:
+            def forward_loss(*args, **kwargs):
+                self._on_root_forward(root, args)
+                try:
+                    return inner(*args, **kwargs)
+                finally:
+                    self._after_root_forward(root, args, None)
+            root.__dict__["forward_loss"] = forward_loss
         # all merged shadows / gradient-GEMM operands of the model in one launch per training forward (WFT_LORA_BATCH=0: the
         # per-Linear kernels, A/B runs)
         self.plan = ops.LoraRefreshPlan() if os.environ.get("WFT_LORA_BATCH", "1") != "0" else None
@@ -251,6 +264,7 @@ def _drop_pool(model: nn.Module) -> None:
         pool.handle.remove()
         for h in pool.handles:
             h.remove()
+        model.__dict__.pop("forward_loss", None)
 
 
 def remove_lora(model: nn.Module) -> None:

@@ -72,11 +72,18 @@ def _adamw_groups_step(optimizer, groups, sumsq, max_norm):
             st["step"] += 1
             by_step.setdefault(int(st["step"]), []).append(p)
         for step, ps in by_step.items():
+            # A parameter without a gradient this step is SKIPPED (torch.optim.AdamW's rule, which is what the reference runs;
+            # the aux-Adam branch of the external muon package would zero-fill it: no moment decay here).  With stochastic depth
+            # the set of parameters that have a gradient changes from step to step, so the tables are kept in a small LRU
+            # (the common sets recur; an unbounded dict grew by one table — device index arrays included — per new set).
             key = tuple(id(p) for p in ps)
             cache = optimizer.__dict__.setdefault("_tables", {})
-            table = cache.get(key)
+            table = cache.pop(key, None)
             if table is None:
-                table = cache[key] = K.TensorTable(ps)
+                table = K.TensorTable(ps)
+                while len(cache) >= 8:
+                    cache.pop(next(iter(cache)))
+            cache[key] = table  # (re-inserted last: dicts keep insertion order)
             grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
             states = [optimizer.state[p] for p in ps]
             K.mt_adamw(table, ps, grads, [st["exp_avg"] for st in states], [st["exp_avg_sq"] for st in states], group["lr"], b1, b2, group["eps"],
