@@ -571,13 +571,95 @@ def gen_ref_dataset():
     print("ref_dataset.json written", len(out), bad)
 
 
+
+# ------------------------------------------------------------------ §8(f3): checkpoint / merge wire format
+# (the reference's converter hard-codes Whisper's special-token ids: the vocabulary must be the real one)
+CKPT_DIMS = O.ModelDimensions(n_mels=80, n_audio_ctx=100, n_audio_state=128, n_audio_head=2, n_audio_layer=2,
+                              n_vocab=51865, n_text_ctx=64, n_text_state=128, n_text_head=2, n_text_layer=2)
+
+
+def gen_ref_checkpoint_make(outdir=None):
+    """Step 1 (THIS package): full.pt and lora.pt of the tiny test model, written by our save_model."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import _ckpt_case
+
+    out = Path(outdir or sys.argv[2])
+    _ckpt_case.build(out, CKPT_DIMS, arch_params(CKPT_DIMS, 3))
+    print("wrote", sorted(p.name for p in out.iterdir()))
+
+
+def gen_ref_checkpoint_consume(outdir=None):
+    """Step 2 (the REFERENCE's package, import stubs for the third-party modules): full.pt through
+    scripts/convert_openai_to_hf.py:172-224 (convert_openai_whisper_to_tfms) -> HF logits; lora.pt through the flow of
+    scripts/merge_lora_weights.py:26-60 (apply_lora -> load_state_dict -> merge_lora) -> merged weights."""
+    out = Path(outdir or sys.argv[2])
+    tmp = _ref_imports()
+    sys.path.insert(0, str(ROOT / "oracle" / "stubs"))  # minlora (restated, pinned by the reference's tests/test_lora.py)
+    import whisper_finetune.scripts.convert_openai_to_hf as conv
+    from transformers import GenerationConfig
+
+    # the converter's LAST step downloads openai/whisper-*'s generation_config.json from the hub (no network here): replaced by a
+    # default GenerationConfig — it does not touch the weights or the forward this fixture records
+    conv._get_generation_config = lambda *a, **k: GenerationConfig()
+    hf, _, _ = conv.convert_openai_whisper_to_tfms(str(out / "full.pt"), str(out / "hf"))
+    hf = hf.float().eval()
+    mel, y_in, y_out = arch_inputs(CKPT_DIMS, 11)
+    with torch.no_grad():
+        logits = hf(input_features=mel, decoder_input_ids=y_in).logits
+    loss = torch.nn.functional.cross_entropy(logits.transpose(1, 2), y_out, label_smoothing=0.1)
+    res = {"hf_logits_s17": logits[:, :, ::17].numpy(), "hf_loss": np.float64(loss.item()),  # (every 17th vocabulary column: 0.3 MB)
+           "hf_argmax": logits.argmax(-1).numpy()}
+
+    # merge flow on a skeleton of the checkpoint's Linear layers (whisper.load_model is not available; only Linear layers carry
+    # adapters, so the skeleton holds exactly those, under the checkpoint's module names)
+    from whisper.model import Linear as WLinear
+    from whisper_finetune.model.lora import apply_lora, is_lora_enabled, merge_lora
+
+    ckpt = torch.load(out / "lora.pt", map_location="cpu", weights_only=True)
+    sd = {k: v.float() for k, v in ckpt["model_state_dict"].items()}
+    lin = sorted(k[: -len(".parametrizations.weight.original")] for k in sd if k.endswith(".parametrizations.weight.original"))
+    root = torch.nn.Module()
+    for name in lin:
+        w = sd[name + ".parametrizations.weight.original"]
+        mod = root
+        parts = name.split(".")
+        for part in parts[:-1]:
+            if part not in mod._modules:
+                mod.add_module(part, torch.nn.Module())
+            mod = mod._modules[part]
+        mod.add_module(parts[-1], WLinear(w.shape[1], w.shape[0], bias=(name + ".bias") in sd))
+    apply_lora(root, lora_config={"rank": 8, "lora_alpha": 16, "lora_dropout": 0.1})
+    sub = {k: v for k, v in sd.items() if any(k.startswith(n + ".") for n in lin)}
+    missing, unexpected = root.load_state_dict(sub, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)  # the reference raises on either (merge_lora_weights.py:45-50)
+    assert is_lora_enabled(root)
+    root.eval()
+    merge_lora(root)
+    assert not is_lora_enabled(root)
+    merged = dict(root.state_dict())
+    for name in lin:
+        res["merged::" + name] = merged[name + ".weight"].numpy()
+    res["linear_names"] = np.array(lin)
+    res["lora_keys"] = np.array(sorted(k for k in sd if "lora" in k))
+    np.savez_compressed(HERE / "ref_checkpoint.npz", **res)
+    print("ref_checkpoint.npz: hf loss", loss.item(), "merged Linears", len(lin))
+
+
+def gen_ref_checkpoint():
+    import subprocess
+
+    d = tempfile.mkdtemp()
+    subprocess.run([sys.executable, __file__, "gen_ref_checkpoint_make", d], check=True)
+    subprocess.run([sys.executable, __file__, "gen_ref_checkpoint_consume", d], check=True)
+
+
 if __name__ == "__main__":
     import subprocess
 
     if len(sys.argv) > 1:  # one generator per process: several of them import the reference under different stubs
         globals()[sys.argv[1]]()
         sys.exit(0)
-    for fn in ("gen_ref_sched", "gen_ref_train_step", "gen_ref_dataset"):
+    for fn in ("gen_ref_sched", "gen_ref_train_step", "gen_ref_dataset", "gen_ref_checkpoint"):
         subprocess.run([sys.executable, __file__, fn], check=True)
     gen_ref_optim()
     gen_ref_eval()
