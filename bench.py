@@ -320,6 +320,24 @@ class Case:
         tf = self.step_flops(B, S) / (dt / steps) / 1e12
         res["step_tflops_per_gpu"] = round(tf, 1)
         res["step_frac_of_bf16_peak"] = round(tf / PEAK_BF16_TFLOPS, 4)
+        if self.ddp:
+            # The multi-GPU line describes itself: ranks, bucket size, and what the gradient exchange costs in
+            # the step — the same step under no_sync() (no all-reduce, gradients stay local) timed right behind the timed region;
+            # the difference is the exposed communication + reducer work (the part NOT hidden under the backward).
+            nosync_steps = min(3, steps)
+            self.fence()
+            t0 = time.perf_counter()
+            for _ in range(nosync_steps):
+                with net.no_sync():
+                    step()
+            self.fence()
+            t = torch.tensor([(time.perf_counter() - t0) / nosync_steps], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            import os as _os
+            res["ddp"] = {"rccl_ranks": self.world, "bucket_cap_mb": 64, "gradient_as_bucket_view": True,
+                          "nt_persistent_launches": _os.environ.get("WFT_NT256_PERSISTENT", "1") != "0",
+                          "ms_per_step_no_sync": round(t.item() * 1e3, 2),
+                          "exposed_exchange_ms": round(dt / steps * 1e3 - t.item() * 1e3, 2)}
         if hand_rolled_steps > 0:
             self.fence()
             t0 = time.perf_counter()

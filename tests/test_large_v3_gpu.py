@@ -34,6 +34,7 @@ from whisper_finetune.model.optimizer import get_optimizer  # noqa: E402
 DEV = torch.device("cuda:0")
 EMU_FLOOR, EMU_MED = 2e-2, 1.5e-2   # vs the bf16-emulating oracle (+ 2 cond per tensor)
 F32_FLOOR, F32_MED = 3e-2, 2.5e-2   # vs the fp32 oracle
+ALLOW_CAP = 0.35                    # no tensor may be further than this from either oracle, whatever its conditioning
 
 
 def rel(a, b):
@@ -93,8 +94,10 @@ def _check(got, emu, f32, tag, emu_med=EMU_MED, f32_med=F32_MED):
     _report(raw, tag + " cond (emulated vs fp32 oracle)")
     _report(e_emu, tag + " gpu vs emulated")
     _report(e_f32, tag + " gpu vs fp32")
+    # (the allowance is capped: a sign / scale slip moves a tensor by 50-100 % and must not hide behind 3 cond on the worst-
+    # conditioned q / k tensors — VERDICT r3 item 7)
     bad = [(n, e_emu[n], e_f32[n], cond[n]) for n in got
-           if e_emu[n] > EMU_FLOOR + 3 * cond[n] or e_f32[n] > F32_FLOOR + 3 * cond[n]]
+           if e_emu[n] > min(EMU_FLOOR + 3 * cond[n], ALLOW_CAP) or e_f32[n] > min(F32_FLOOR + 3 * cond[n], ALLOW_CAP)]
     assert not bad, sorted(bad, key=lambda t: -t[1])[:8]
     # per ROLE (one parameter name over all blocks): the median over the blocks is insensitive to the few badly conditioned
     # layers that set the per-tensor allowance above, so it gets the tight bound — a factor-2 slip in one role (a mis-scaled
@@ -145,6 +148,43 @@ def test_large_v3_full_finetune_step_matches_oracle():
         assert abs(loss.item() - loss_ref) < ltol * loss_ref, (emulate, loss.item(), loss_ref)
     assert len(got) == len([k for k in params if k != "encoder.positional_embedding"])
     _check(got, refs[True], refs[False], "full-FT")
+
+
+def test_large_v3_full_finetune_batch_of_two_ragged_targets_matches_fp32_oracle():
+    """The same step at B = 2 with different -100 tails per row (a batch-stride slip that only shows at
+    d = 1280, B > 1 was visible to the property tests only).  One fp32 oracle pass (no emulated twin: the oracle takes twice as
+    long at B = 2), so the bounds are the unconditioned ones: every tensor within ALLOW_CAP, every role's median over the blocks
+    within 6e-2 (3e-2 + 1.5 x the ~2 % a bf16 evaluation moves a typical tensor), the median over all tensors within F32_MED."""
+    import re
+    from collections import defaultdict
+
+    dims, params = _large_v3_params(seed=29)
+    audio, y_in, y_out = O.synthetic_batch(dims, 2, 128, seed=5)
+    y_out[0, :3] = -100
+    y_out[0, 100:] = -100   # ragged tails: row 0 keeps 97 targets, row 1 keeps 120
+    y_out[1, 120:] = -100
+    mel_ref = O.log_mel_spectrogram(audio, dims.n_mels)
+    m = Whisper(ModelDimensions(**vars(dims)))
+    m.load_state_dict(params)
+    m.to(DEV).train()
+    mel = K.logmel(audio.to(DEV), O.mel_filters(dims.n_mels).to(DEV))
+    loss = m(mel, y_in.to(DEV), targets=y_out.to(DEV), label_smoothing=0.1)
+    loss.backward()
+    got = {n: p.grad.detach().cpu() for n, p in m.named_parameters()}
+    del m
+    torch.cuda.empty_cache()
+    p_req = {k: v.clone().requires_grad_(k != "encoder.positional_embedding") for k, v in params.items()}
+    loss_ref = _oracle_grads(dims, p_req, mel_ref, y_in, y_out, False)
+    assert abs(loss.item() - loss_ref) < 2e-3 * loss_ref, (loss.item(), loss_ref)
+    errs = {n: rel(got[n], p_req[n].grad) for n in got}
+    _report(errs, "full-FT B=2 gpu vs fp32")
+    assert max(errs.values()) < ALLOW_CAP, sorted(errs.items(), key=lambda kv: -kv[1])[:6]
+    roles = defaultdict(list)
+    for n, e in errs.items():
+        roles[re.sub(r"blocks\.\d+\.", "blocks.*.", n)].append(e)
+    bad_roles = {r: float(np.median(v)) for r, v in roles.items() if float(np.median(v)) > 6e-2}
+    assert not bad_roles, bad_roles
+    assert float(np.median(list(errs.values()))) < F32_MED
 
 
 def test_large_v3_lora_muon_config_step_matches_oracle():
