@@ -499,6 +499,8 @@ def main():
             "hbm_peak_gib": hbm_peak,
             "roofline": head.get("roofline"),
         }
+        if "ddp" in head:
+            out["ddp"] = head["ddp"]  # multi-GPU (or WFT_BENCH_FORCE_DDP=1): ranks, bucket size, the no_sync twin, exposed exchange
         if "hand_rolled_ms_per_step" in head:
             out["hand_rolled_ms_per_step"] = head["hand_rolled_ms_per_step"]  # round 1's loop, 3 steps: cross-check of the product loop
         if other:

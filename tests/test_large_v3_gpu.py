@@ -154,7 +154,8 @@ def test_large_v3_full_finetune_batch_of_two_ragged_targets_matches_fp32_oracle(
     """The same step at B = 2 with different -100 tails per row (a batch-stride slip that only shows at
     d = 1280, B > 1 was visible to the property tests only).  One fp32 oracle pass (no emulated twin: the oracle takes twice as
     long at B = 2), so the bounds are the unconditioned ones: every tensor within ALLOW_CAP, every role's median over the blocks
-    within 6e-2 (3e-2 + 1.5 x the ~2 % a bf16 evaluation moves a typical tensor), the median over all tensors within F32_MED."""
+    within 6e-2 (3e-2 + 1.5 x the ~2 % a bf16 evaluation moves a typical tensor; 0.2 for the decoder's self-attention q / k), the
+    median over all tensors within F32_MED."""
     import re
     from collections import defaultdict
 
@@ -182,7 +183,10 @@ def test_large_v3_full_finetune_batch_of_two_ragged_targets_matches_fp32_oracle(
     roles = defaultdict(list)
     for n, e in errs.items():
         roles[re.sub(r"blocks\.\d+\.", "blocks.*.", n)].append(e)
-    bad_roles = {r: float(np.median(v)) for r, v in roles.items() if float(np.median(v)) > 6e-2}
+    # (the q / k projections of the decoder's causal self-attention are the ill-conditioned roles of this model: two bf16
+    # evaluations of their gradients differ by 13-19 % in the deep blocks — measured by the B = 1 test's emulated pass)
+    loose = ("decoder.blocks.*.attn.query", "decoder.blocks.*.attn.key")
+    bad_roles = {r: float(np.median(v)) for r, v in roles.items() if float(np.median(v)) > (0.2 if r.startswith(loose) else 6e-2)}
     assert not bad_roles, bad_roles
     assert float(np.median(list(errs.values()))) < F32_MED
 

@@ -121,6 +121,8 @@ class LoraMaskPool:
         inner = getattr(root, "forward_loss", None)
         if callable(inner) and "forward_loss" not in root.__dict__:
             def forward_loss(*args, **kwargs):
+                if self.depth > 0:  # reached through root.forward(..., targets=...): that call already is the forward of the model
+                    return inner(*args, **kwargs)
                 self._on_root_forward(root, args)
                 try:
                     return inner(*args, **kwargs)
