@@ -60,7 +60,13 @@
 //   after slot 127   : lgkmcnt(0)
 // vmcnt retires in issue order and every k-step issues 8 W pieces then 8 X pieces, so "k-step t+1's W complete" = at most 8 (its
 // X) + 16 (k-step t+2) younger operations outstanding.
-#define NT4W_ASM_MACROS R"ASM(
+#ifndef NT4W_T1
+#define NT4W_T1 17
+#define NT4W_T2 37
+#define NT4W_T3 66
+#define NT4W_T4 84
+#endif
+#define NT4W_ASM_MACROS ".set NT4W_T1, " NT4W_STR(NT4W_T1) "\n.set NT4W_T2, " NT4W_STR(NT4W_T2) "\n.set NT4W_T3, " NT4W_STR(NT4W_T3) "\n.set NT4W_T4, " NT4W_STR(NT4W_T4) "\n" R"ASM(
 .macro NT4W_MFMA s, z
   .if \z
     v_mfma_f32_16x16x32_bf16 a[4*((\s)%%64):4*((\s)%%64)+3], v[128+64*((\s)/64)+4*((\s)%%8):128+64*((\s)/64)+4*((\s)%%8)+3], v[160+64*((\s)/64)+4*(((\s)%%64)/8):160+64*((\s)/64)+4*(((\s)%%64)/8)+3], 0
@@ -104,33 +110,33 @@
     .if (nt4w_s < 16) && ((nt4w_s %% 2) == 0)
       ds_read_b128 v[192+4*(nt4w_s/2):192+4*(nt4w_s/2)+3], \rdWc offset:128*(nt4w_s/2)+64
     .endif
-    .if nt4w_s == 17
+    .if nt4w_s == NT4W_T1
       s_waitcnt lgkmcnt(0)
     .endif
-    .if nt4w_s == 18
+    .if nt4w_s == NT4W_T1+1
       s_barrier
     .endif
-    .if (nt4w_s >= 20) && (nt4w_s < 36)
-      .if (nt4w_s %% 2) == 0
+    .if (nt4w_s >= NT4W_T1+2) && (nt4w_s < NT4W_T1+18)
+      .if ((nt4w_s-NT4W_T1) %% 2) == 0
         .if \ld
-          NT4W_DMA (nt4w_s-20)/2, 120, 44, \mW
+          NT4W_DMA (nt4w_s-NT4W_T1-2)/2, 120, 44, \mW
         .endif
       .else
-        ds_read_b128 v[224+4*((nt4w_s-21)/2):224+4*((nt4w_s-21)/2)+3], \rdXc offset:128*((nt4w_s-21)/2)+64
+        ds_read_b128 v[224+4*((nt4w_s-NT4W_T1-3)/2):224+4*((nt4w_s-NT4W_T1-3)/2)+3], \rdXc offset:128*((nt4w_s-NT4W_T1-3)/2)+64
       .endif
     .endif
-    .if nt4w_s == 37
+    .if nt4w_s == NT4W_T2
       s_waitcnt lgkmcnt(0)
     .endif
-    .if nt4w_s == 38
+    .if nt4w_s == NT4W_T2+1
       s_barrier
     .endif
-    .if (nt4w_s >= 40) && (nt4w_s < 56) && ((nt4w_s %% 2) == 0)
+    .if (nt4w_s >= NT4W_T2+2) && (nt4w_s < NT4W_T2+18) && (((nt4w_s-NT4W_T2) %% 2) == 0)
       .if \ld
-        NT4W_DMA (nt4w_s-40)/2, 112, 40, \mX
+        NT4W_DMA (nt4w_s-NT4W_T2-2)/2, 112, 40, \mX
       .endif
     .endif
-    .if nt4w_s == 56
+    .if nt4w_s == NT4W_T2+18
       .if \ld
         s_add_u32 s40, s40, 128
         s_addc_u32 s41, s41, 0
@@ -139,23 +145,23 @@
       .endif
     .endif
     .if \nx
-      .if nt4w_s == 66
+      .if nt4w_s == NT4W_T3
         s_waitcnt vmcnt(\vmA)
       .endif
-      .if nt4w_s == 67
+      .if nt4w_s == NT4W_T3+1
         s_barrier
       .endif
-      .if (nt4w_s >= 68) && (nt4w_s < 84) && ((nt4w_s %% 2) == 0)
-        ds_read_b128 v[128+4*((nt4w_s-68)/2):128+4*((nt4w_s-68)/2)+3], \rdWn offset:128*((nt4w_s-68)/2)
+      .if (nt4w_s >= NT4W_T3+2) && (nt4w_s < NT4W_T3+18) && (((nt4w_s-NT4W_T3) %% 2) == 0)
+        ds_read_b128 v[128+4*((nt4w_s-NT4W_T3-2)/2):128+4*((nt4w_s-NT4W_T3-2)/2)+3], \rdWn offset:128*((nt4w_s-NT4W_T3-2)/2)
       .endif
-      .if nt4w_s == 84
+      .if nt4w_s == NT4W_T4
         s_waitcnt vmcnt(\vmB)
       .endif
-      .if nt4w_s == 85
+      .if nt4w_s == NT4W_T4+1
         s_barrier
       .endif
-      .if (nt4w_s >= 86) && (nt4w_s < 102) && ((nt4w_s %% 2) == 0)
-        ds_read_b128 v[160+4*((nt4w_s-86)/2):160+4*((nt4w_s-86)/2)+3], \rdXn offset:128*((nt4w_s-86)/2)
+      .if (nt4w_s >= NT4W_T4+2) && (nt4w_s < NT4W_T4+18) && (((nt4w_s-NT4W_T4) %% 2) == 0)
+        ds_read_b128 v[160+4*((nt4w_s-NT4W_T4-2)/2):160+4*((nt4w_s-NT4W_T4-2)/2)+3], \rdXn offset:128*((nt4w_s-NT4W_T4-2)/2)
       .endif
     .endif
     .set nt4w_s, nt4w_s+1
