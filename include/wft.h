@@ -269,6 +269,11 @@ typedef struct {
 int wft_attn_fwd_bf16(const wft_attn_args* args, void* stream);
 int wft_attn_bwd_bf16(const wft_attn_args* args, void* stream);
 int64_t wft_attn_bwd_colsum_workspace_bytes(const wft_attn_args* args);
+/* Which dK/dV kernel wft_attn_bwd_bf16 launches: 0 (default) the one-wave-per-SIMD kernel (csrc/attn.hip, attn_bwd_dkdv4w_kernel)
+ * for non-causal calls with Tq >= 128, the 8-wave kernel otherwise; 1 always the 8-wave kernel.  Same results up to the
+ * rounding of a different summation order over queries.  Returns the previous value; a negative argument only reads.
+ * Start value from WFT_DKDV_VARIANT=4w|8w.  (A/B measurements and tests; not part of the reference's interface.)          */
+int wft_attn_set_dkdv_variant(int variant);
 
 /* -------------------------------------------------------------- Embedding */
 /* TextDecoder: x = token_embedding(tokens) + positional_embedding[:S]

@@ -1,0 +1,29 @@
+"""Developer script (GPU box): where a workgroup of attn_bwd_dkdv4w_kernel spends its clock ticks (build with -DD4_STAMPS, see
+csrc/attn.hip; WFT_LIB points at that build).   WFT_LIB=.../libwft_stamps.so python tools/dev/dkdv4w_stamps.py"""
+import ctypes, os, sys, torch
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[2] / "whisper-finetune_amd"))
+from whisper_finetune.engine import kernels as K, lib as L
+dev = torch.device("cuda:0")
+lib = L.load()
+so = ctypes.CDLL(os.environ["WFT_LIB"])
+B, H, T = 32, 20, 1500
+d = H * 64
+qkv = torch.randn(B, T, 3 * d, device=dev).bfloat16()
+q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+do = torch.randn(B, T, d, device=dev).bfloat16()
+o, lse = K.attn_fwd(q, k, v, H, False, 0.125)
+cs = (torch.empty(d, device=dev), torch.empty(d, device=dev))
+for _ in range(3): K.attn_bwd(q, k, v, o, lse, do, H, False, 0.125, colsums=cs)
+torch.cuda.synchronize()
+buf = (ctypes.c_ulonglong * 8)()
+so.wft_dbg_read(buf, 1)
+# atomicMin slot starts from zero after the reset: seed it high
+K.attn_bwd(q, k, v, o, lse, do, H, False, 0.125, colsums=cs)
+so.wft_dbg_read(buf, 0)
+n = buf[0]
+print(f"{n} workgroups; clock ticks per workgroup (s_memtime, 100 MHz-class constant clock or shader clock, see ratio below):")
+for i, name in ((1, "prologue"), (2, "block 0 + loop"), (3, "last dV / dK"), (4, "read-back + colsum + stores")):
+    print(f"  {name:28s} {buf[i] / n:10.0f}")
+tot = sum(buf[1:5]) / n
+print(f"  sum {tot:.0f}; x {n / 256:.1f} workgroups per CU = {tot * n / 256:.0f}; first start -> last end {buf[6]:d} (min start slot not seeded)")

@@ -16,6 +16,7 @@
 // ds_read_b128 operand reads and the 4-row transposed reads.
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 
 #ifndef ATT_PK
 #define ATT_PK 1
@@ -812,6 +813,519 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
 }
 
 // ------------------------------------------------------------------------------ host
+// ------------------------------------------------------------------------------ dK/dV, one wave per SIMD (round 4)
+// The non-causal dK/dV sweep (the encoder's 1500 x 1500 attention and the decoder's cross attention: 85 of a step's 657 ms in
+// the kernel above, matrix pipe 29 % busy) as ONE hand-scheduled stream per SIMD, like gemm_nt4w.hip.  In the kernel above a
+// wave's chain  S / dP MFMAs -> exp, multiplies, packing -> dV / dK MFMAs  is serial and only the SIMD's other wave fills the
+// holes; here a wave owns 64 keys (two 32-key blocks, K / V fragments in a[128:191]) and runs THREE query blocks at once:
+//   iteration j:  MFMA  slots  0-15  dV / dK of block j-1   (operands: P, dS packed in v[32:63]; Q^T, dO^T fragments v[96:127])
+//                       slots 16-31  S / dP of block j+1    (into the other accumulator generation, which STARTS from the row
+//                                                            constants -lse/scale and -delta read from LDS as the C operand)
+//                 VALU  4 per slot   block j: slots 0-15  p = exp2(c S')  (2 multiplies + 2 exponentials per slot),
+//                                             slots 16-23 dS = p dP',  slots 24-31 the 32 bf16 packs
+//                 LDS   slots  0-11  row fragments of Q, dO and the constants of block j+1;  slots 16-31 transposed fragments of j
+// so the matrix pipe never waits for the vector stream of the same block (budget per 32-cycle MFMA: 24 issue cycles; 2 exp + 2
+// mul = 24).  Q / dO fragments and constants are shared by the wave's two key blocks (half the LDS traffic per MFMA).
+// Queries beyond Tq need no masks: their Q / dO rows and constants arrive as ZEROS (buffer descriptors that end at row Tq), so
+// they add exp2(0) * 0 = 0 to dV and 0 * finite = 0 to dK; keys beyond Tk are lanes whose results are not stored.
+// LDS: four buffers of one 64-query tile {Q, dO: 8 pieces of 8 rows, 1 280 B apart, piece pid at pid * 1280 + 64 (pid & 1) +
+// 16 (pid >> 1); -lse/scale, -delta: 256 B each}.  Piece pid holds queries q0 + {0, 2} + 16 m, q0 = (pid & 1) + 4 (pid >> 1): row q sits
+// at 64 (q & 3) + 16 ((q >> 2) & 3) modulo 256 B, which makes BOTH the 32-row ds_read_b128 operand reads and the 4-row
+// ds_read_b64_tr_b16 reads bank-conflict-free with every fragment address = one base register + an immediate.
+#define D4_PIECE 1280
+#define D4_DO 10240
+#define D4_LSE 20480
+#define D4_DLT 20736
+#define D4_BUF 20992
+#define D4_LDS (4 * D4_BUF)
+#define D4_STR2(x) #x
+#define D4_STR(x) D4_STR2(x)
+
+#ifndef D4_EXP
+#define D4_EXP 0  // developer timing experiments (results wrong): 1 no LDS-DMA in the loop, 2 no vector arithmetic, 3 no LDS reads, 4 no barrier
+#endif
+#define D4_ASM_MACROS ".set d4_exp, " D4_STR(D4_EXP) "\n" R"ASM(
+.macro D4_VALU ops:vararg
+  .if d4_exp == 10
+    v_mov_b32 v29, v30
+  .elseif d4_exp == 11
+    s_nop 0
+  .elseif d4_exp == 12
+    v_mov_b32 v29, s66
+  .elseif d4_exp != 2 && !(d4_exp == 8 && d4_s < 16) && !(d4_exp == 9 && d4_s >= 16)
+    \ops
+  .endif
+.endm
+.macro D4_EXPF d, x
+  .if d4_exp == 10
+    v_mov_b32 v29, v30
+  .elseif d4_exp == 11
+    s_nop 0
+  .elseif d4_exp == 12
+    v_mov_b32 v29, s66
+  .elseif d4_exp == 5
+    v_mov_b32 \d, \x
+  .elseif d4_exp == 6
+  .elseif d4_exp != 2 && d4_exp != 8 && d4_exp < 13
+    v_exp_f32 \d, \x
+  .endif
+.endm
+; registers: S(g,kb) v[g+32kb..+15], dP(g,kb) v[g+16+32kb..+15], g = 128 / 192;  PF(kb) v[32+16kb..+7], DSF(kb) v[40+16kb..+7];
+; row constants v[64:79] (-lse/scale), v[80:95] (-delta); Q rows AQ(s) a[192+4s..], dO rows AD(s) a[208+4s..]; TQ(ks,db) v[96+8ks+4db..], TD(ks,db) v[112+8ks+4db..];
+; dK(kb,db) a[64kb+16db..+15], dV(kb,db) a[64kb+32+16db..+15]; KF(kb,s) a[128+32kb+4s..+3], VF(kb,s) a[144+32kb+4s..+3]
+.macro D4_M2 n
+  .if ((\n) %% 2) == 0
+    v_mfma_f32_32x32x16_bf16 a[64*((\n)/8)+32+16*(((\n)/2)%%2):64*((\n)/8)+32+16*(((\n)/2)%%2)+15], v[112+8*(((\n)/4)%%2)+4*(((\n)/2)%%2):112+8*(((\n)/4)%%2)+4*(((\n)/2)%%2)+3], v[32+16*((\n)/8)+4*(((\n)/4)%%2):32+16*((\n)/8)+4*(((\n)/4)%%2)+3], a[64*((\n)/8)+32+16*(((\n)/2)%%2):64*((\n)/8)+32+16*(((\n)/2)%%2)+15]
+  .else
+    v_mfma_f32_32x32x16_bf16 a[64*((\n)/8)+16*(((\n)/2)%%2):64*((\n)/8)+16*(((\n)/2)%%2)+15], v[96+8*(((\n)/4)%%2)+4*(((\n)/2)%%2):96+8*(((\n)/4)%%2)+4*(((\n)/2)%%2)+3], v[40+16*((\n)/8)+4*(((\n)/4)%%2):40+16*((\n)/8)+4*(((\n)/4)%%2)+3], a[64*((\n)/8)+16*(((\n)/2)%%2):64*((\n)/8)+16*(((\n)/2)%%2)+15]
+  .endif
+.endm
+.macro D4_M1 n, g
+  ; chain (\n)/4: 0 S kb0, 1 dP kb0, 2 S kb1, 3 dP kb1; k-step (\n)%%4.  The first MFMA of a chain starts from the block's row
+  ; constants (v[64:79] -lse/scale for S, v[80:95] -delta for dP), shared by the two key blocks
+  .if ((\n) %% 4) == 0
+    v_mfma_f32_32x32x16_bf16 v[\g+16*(((\n)/4)%%2)+32*((\n)/8):\g+16*(((\n)/4)%%2)+32*((\n)/8)+15], a[192+16*(((\n)/4)%%2):192+16*(((\n)/4)%%2)+3], a[128+16*(((\n)/4)%%2)+32*((\n)/8):128+16*(((\n)/4)%%2)+32*((\n)/8)+3], v[64+16*(((\n)/4)%%2):64+16*(((\n)/4)%%2)+15]
+  .else
+    v_mfma_f32_32x32x16_bf16 v[\g+16*(((\n)/4)%%2)+32*((\n)/8):\g+16*(((\n)/4)%%2)+32*((\n)/8)+15], a[192+16*(((\n)/4)%%2)+4*((\n)%%4):192+16*(((\n)/4)%%2)+4*((\n)%%4)+3], a[128+16*(((\n)/4)%%2)+32*((\n)/8)+4*((\n)%%4):128+16*(((\n)/4)%%2)+32*((\n)/8)+4*((\n)%%4)+3], v[\g+16*(((\n)/4)%%2)+32*((\n)/8):\g+16*(((\n)/4)%%2)+32*((\n)/8)+15]
+  .endif
+.endm
+; row read i (0..15) of a block, in the order the S / dP chains need them: 0-3 -lse/scale -> v[64:79], 4-7 Q rows -> a[192:207],
+; 8-11 -delta -> v[80:95], 12-15 dO rows -> a[208:223]
+.macro D4_RD1 i, rb, cb, qb
+  .if d4_exp == 3
+  .elseif (\i) < 4
+    ds_read_b128 v[64+4*(\i):64+4*(\i)+3], \cb offset:20480+128*\qb+32*(\i)
+  .elseif (\i) < 8
+    ds_read_b128 a[192+4*((\i)-4):192+4*((\i)-4)+3], \rb offset:512*\qb+32*((\i)-4)
+  .elseif (\i) < 12
+    ds_read_b128 v[80+4*((\i)-8):80+4*((\i)-8)+3], \cb offset:20736+128*\qb+32*((\i)-8)
+  .else
+    ds_read_b128 a[208+4*((\i)-12):208+4*((\i)-12)+3], \rb offset:10240+512*\qb+32*((\i)-12)
+  .endif
+.endm
+; transposed read m (0..15) in the order the dV / dK MFMAs consume them: (ks, db) = (m/8, (m/4)%2); (m/2)%2 = 0 dO^T, 1 Q^T; t = m%2
+.macro D4_RD2 m, tb, qb
+  .if d4_exp != 3
+  ds_read_b64_tr_b16 v[112-16*(((\m)/2)%%2)+8*((\m)/8)+4*(((\m)/4)%%2)+2*((\m)%%2):112-16*(((\m)/2)%%2)+8*((\m)/8)+4*(((\m)/4)%%2)+2*((\m)%%2)+1], \tb offset:10240*(1-((\m)/2)%%2)+5152*((\m)%%2)+128*(4*\qb+2*((\m)/8))+64*(((\m)/4)%%2)
+  .endif
+.endm
+; next 64-query tile: source bases += 64 rows (Q, dO) / 256 B (constants), bounds shrink with them (not below zero)
+.macro D4_ADVANCE
+  s_add_u32 s40, s40, s56
+  s_addc_u32 s41, s41, 0
+  s_sub_u32 s42, s42, s56
+  s_cselect_b32 s42, 0, s42
+  s_add_u32 s44, s44, s57
+  s_addc_u32 s45, s45, 0
+  s_sub_u32 s46, s46, s57
+  s_cselect_b32 s46, 0, s46
+  s_add_u32 s48, s48, 256
+  s_addc_u32 s49, s49, 0
+  s_sub_u32 s50, s50, 256
+  s_cselect_b32 s50, 0, s50
+.endm
+; step i (0..4) of this wave's share of one tile -> the buffer at LDS offset \boff (an SGPR): pieces 2 wave, 2 wave + 1 of Q (0, 1)
+; and dO (2, 3); 4: the constants (even waves -lse/scale, odd waves -delta; waves 2, 3 repeat 0, 1 so that every wave has
+; five pieces per tile in flight and the counted waits are uniform)
+.macro D4_DMA i, boff
+  .if (\i) == 0
+    s_add_u32 m0, s58, \boff
+    s_nop 0
+    buffer_load_dwordx4 %[voQ0], s[40:43], 0 offen lds
+  .elseif (\i) == 1
+    s_add_u32 m0, s59, \boff
+    s_nop 0
+    buffer_load_dwordx4 %[voQ1], s[40:43], 0 offen lds
+  .elseif (\i) == 2
+    s_add_u32 m0, s58, \boff
+    s_add_u32 m0, m0, 10240
+    s_nop 0
+    buffer_load_dwordx4 %[voD0], s[44:47], 0 offen lds
+  .elseif (\i) == 3
+    s_add_u32 m0, s59, \boff
+    s_add_u32 m0, m0, 10240
+    s_nop 0
+    buffer_load_dwordx4 %[voD1], s[44:47], 0 offen lds
+  .else
+    s_add_u32 m0, s60, \boff
+    s_nop 0
+    buffer_load_dword %[voC], s[48:51], 0 offen lds
+  .endif
+.endm
+.macro D4_STAGE boff
+  D4_DMA 0, \boff
+  D4_DMA 1, \boff
+  D4_DMA 2, \boff
+  D4_DMA 3, \boff
+  D4_DMA 4, \boff
+.endm
+; one iteration.  gV: generation (128 / 192) whose block is exponentiated here, gM: the other (target of the S / dP MFMAs);
+; rb1, cb1, qb1: bases / half of the block whose row fragments are read; tb2, qb2: of the block whose transposed fragments are read;
+; dma = 1: this wave's LDS-DMA share of the tile three ahead goes out in slots 16-20 (buffer offset s65), sources advance in slot 21.
+; A wave alone on its SIMD issues in order and an MFMA gap hides about 24 issue cycles (measured here: two junk v_mov per gap cost
+; 1.4 cycles each, the third and fourth 3.4): every slot carries 20 cycles of vector work and ONE LDS read —
+;   slots  0-15  c-multiply of key block 1, both exponentials; row read number slot
+;   slots 16-23  four dS multiplies, one pack; transposed read         24-31  three packs, the c-multiplies of the NEXT block's
+;                key block 0 (its S chain finished in slot 19); transposed read
+; LDS reads are counted, never drained: transposed fragment f (two reads, slots 16 + 2 f, 17 + 2 f) is consumed by slot f of the
+; next iteration behind lgkmcnt(14 - f) (the later transposed reads + the f row reads issued since); the row reads behind
+; lgkmcnt(8) (slot 16: constants and Q rows) and lgkmcnt(4) (slot 20: -delta, dO rows; four transposed reads are younger).
+.macro D4_ITER gV, gM, rb1, cb1, qb1, tb2, qb2, dma
+  .set d4_s, 0
+  .rept 32
+    .if d4_s < 8 && d4_exp != 7
+      s_waitcnt lgkmcnt(14-d4_s)
+    .elseif d4_s == 16
+      s_waitcnt lgkmcnt(8)
+    .elseif d4_s == 20
+      s_waitcnt lgkmcnt(4)
+    .endif
+    .if d4_s < 16
+      D4_M2 d4_s
+      D4_VALU v_mul_f32 v[\gV+32+d4_s], %[c], v[\gV+32+d4_s]
+      D4_EXPF v[\gV+d4_s], v[\gV+d4_s]
+      D4_RD1 d4_s, \rb1, \cb1, \qb1
+      D4_EXPF v[\gV+32+d4_s], v[\gV+32+d4_s]
+    .else
+      D4_M1 d4_s-16, \gM
+      .if d4_s < 24
+        D4_VALU v_mul_f32 v[\gV+16+2*(d4_s-16)], v[\gV+2*(d4_s-16)], v[\gV+16+2*(d4_s-16)]
+        D4_VALU v_mul_f32 v[\gV+16+2*(d4_s-16)+1], v[\gV+2*(d4_s-16)+1], v[\gV+16+2*(d4_s-16)+1]
+        D4_RD2 d4_s-16, \tb2, \qb2
+        D4_VALU v_mul_f32 v[\gV+48+2*(d4_s-16)], v[\gV+32+2*(d4_s-16)], v[\gV+48+2*(d4_s-16)]
+        D4_VALU v_mul_f32 v[\gV+48+2*(d4_s-16)+1], v[\gV+32+2*(d4_s-16)+1], v[\gV+48+2*(d4_s-16)+1]
+        D4_VALU v_cvt_pk_bf16_f32 v[32+(d4_s-16)], v[\gV+2*(d4_s-16)], v[\gV+2*(d4_s-16)+1]
+        .if \dma && d4_s < 21 && d4_exp != 1
+          D4_DMA d4_s-16, s65
+        .endif
+        .if \dma && d4_s == 21
+          D4_ADVANCE
+        .endif
+      .else
+        D4_VALU v_cvt_pk_bf16_f32 v[48+(d4_s-24)], v[\gV+32+2*(d4_s-24)], v[\gV+32+2*(d4_s-24)+1]
+        D4_VALU v_cvt_pk_bf16_f32 v[40+(d4_s-24)], v[\gV+16+2*(d4_s-24)], v[\gV+16+2*(d4_s-24)+1]
+        D4_RD2 d4_s-16, \tb2, \qb2
+        D4_VALU v_cvt_pk_bf16_f32 v[56+(d4_s-24)], v[\gV+48+2*(d4_s-24)], v[\gV+48+2*(d4_s-24)+1]
+        D4_VALU v_mul_f32 v[\gM+2*(d4_s-24)], %[c], v[\gM+2*(d4_s-24)]
+        D4_VALU v_mul_f32 v[\gM+2*(d4_s-24)+1], %[c], v[\gM+2*(d4_s-24)+1]
+      .endif
+    .endif
+    .set d4_s, d4_s+1
+  .endr
+.endm
+)ASM"
+
+#define D4_ASM_PURGE R"ASM(
+.purgem D4_VALU
+.purgem D4_EXPF
+.purgem D4_M2
+.purgem D4_M1
+.purgem D4_RD1
+.purgem D4_RD2
+.purgem D4_ADVANCE
+.purgem D4_DMA
+.purgem D4_STAGE
+.purgem D4_ITER
+)ASM"
+
+#define D4_A8(x) "a" D4_STR(x##0), "a" D4_STR(x##1), "a" D4_STR(x##2), "a" D4_STR(x##3), "a" D4_STR(x##4), "a" D4_STR(x##5), "a" D4_STR(x##6), "a" D4_STR(x##7), "a" D4_STR(x##8), "a" D4_STR(x##9)
+#define D4_V8(x) "v" D4_STR(x##0), "v" D4_STR(x##1), "v" D4_STR(x##2), "v" D4_STR(x##3), "v" D4_STR(x##4), "v" D4_STR(x##5), "v" D4_STR(x##6), "v" D4_STR(x##7), "v" D4_STR(x##8), "v" D4_STR(x##9)
+#define D4_S8(x) "s" D4_STR(x##0), "s" D4_STR(x##1), "s" D4_STR(x##2), "s" D4_STR(x##3), "s" D4_STR(x##4), "s" D4_STR(x##5), "s" D4_STR(x##6), "s" D4_STR(x##7), "s" D4_STR(x##8), "s" D4_STR(x##9)
+// a0..a223, v24..v255, s40..s79
+#define D4_CLOBBER_A "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", D4_A8(1), D4_A8(2), D4_A8(3), D4_A8(4), D4_A8(5), D4_A8(6), D4_A8(7), D4_A8(8), D4_A8(9), D4_A8(10), D4_A8(11), D4_A8(12), D4_A8(13), D4_A8(14), D4_A8(15), D4_A8(16), D4_A8(17), D4_A8(18), D4_A8(19), D4_A8(20), D4_A8(21), "a220", "a221", "a222", "a223"
+#define D4_CLOBBER_V "v24", "v25", "v26", "v27", "v28", "v29", D4_V8(3), D4_V8(4), D4_V8(5), D4_V8(6), D4_V8(7), D4_V8(8), D4_V8(9), D4_V8(10), D4_V8(11), D4_V8(12), D4_V8(13), D4_V8(14), D4_V8(15), D4_V8(16), D4_V8(17), D4_V8(18), D4_V8(19), D4_V8(20), D4_V8(21), D4_V8(22), D4_V8(23), D4_V8(24), "v250", "v251", "v252", "v253", "v254", "v255"
+#define D4_CLOBBER_S D4_S8(4), D4_S8(5), D4_S8(6), D4_S8(7)
+
+template <int N>
+__device__ __forceinline__ float d4_acc() {
+  float x;
+  asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(x) : "i"(N));
+  return x;
+}
+template <int BASE>
+__device__ __forceinline__ f32x16 d4_get16() {
+  f32x16 v;
+  v[0] = d4_acc<BASE>(); v[1] = d4_acc<BASE + 1>(); v[2] = d4_acc<BASE + 2>(); v[3] = d4_acc<BASE + 3>();
+  v[4] = d4_acc<BASE + 4>(); v[5] = d4_acc<BASE + 5>(); v[6] = d4_acc<BASE + 6>(); v[7] = d4_acc<BASE + 7>();
+  v[8] = d4_acc<BASE + 8>(); v[9] = d4_acc<BASE + 9>(); v[10] = d4_acc<BASE + 10>(); v[11] = d4_acc<BASE + 11>();
+  v[12] = d4_acc<BASE + 12>(); v[13] = d4_acc<BASE + 13>(); v[14] = d4_acc<BASE + 14>(); v[15] = d4_acc<BASE + 15>();
+  return v;
+}
+
+#ifdef D4_STAMPS  // developer build (tools/dev/dkdv4w_stamps.py): clock-tick sums over workgroups, wave 0
+__device__ unsigned long long d4_dbg[8];
+extern "C" void wft_dbg_read(unsigned long long* host, int reset) {
+  if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(d4_dbg), z, sizeof z); return; }
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(d4_dbg), 8 * sizeof(unsigned long long));
+}
+#endif
+__global__ __launch_bounds__(256) void attn_bwd_dkdv4w_kernel(AttnP p) {
+#ifdef D4_STAMPS
+  const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+#endif
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  int bx, hd, b;
+  att_block_coords((p.Tk + 255) >> 8, p.H, p.B, p.xcd, bx, hd, b);
+  const int kw0 = bx * 256 + wave * 64;
+  // K / V row fragments of this wave's two 32-key blocks -> a[128:191], loaded inside the asm block (rows clamped: lanes past
+  // Tk compute garbage nobody stores): byte offsets of this lane's row in block 0 / 1, relative to the (batch, head) bases
+  auto krow = [&](int kb) { const int ki = kw0 + 32 * kb + r; return ki < p.Tk ? ki : p.Tk - 1; };
+  const unsigned voK0 = (unsigned)(krow(0) * (int)p.ldk + 8 * h) * 2u, voK1 = (unsigned)(krow(1) * (int)p.ldk + 8 * h) * 2u;
+  const unsigned voV0 = (unsigned)(krow(0) * (int)p.ldv + 8 * h) * 2u, voV1 = (unsigned)(krow(1) * (int)p.ldv + 8 * h) * 2u;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+  // fragment read bases (see the layout note above)
+  const int c = r & 15, pidr = (c & 1) | ((c >> 2) << 1);
+  const unsigned rb = lds0 + pidr * D4_PIECE + 64 * (pidr & 1) + 16 * (pidr >> 1) + (2 * (r >> 4) + ((c >> 1) & 1)) * 128 + h * 16;
+  const int g4 = lane >> 4, i16 = lane & 15, pidt = ((i16 >> 2) & 1) | ((g4 >> 1) << 1);
+  const unsigned tb = lds0 + pidt * D4_PIECE + 64 * (pidt & 1) + 16 * (pidt >> 1) + ((i16 >> 3) & 1) * 128 + 32 * (g4 & 1) + 8 * (i16 & 3);
+  const unsigned cb = lds0 + 16 * h;
+  // LDS-DMA share of this wave: pieces 2 wave and 2 wave + 1 of Q and of dO; lane: slot lane >> 3 (query q0 + 2 (slot & 1) + 16 (slot >> 1)), chunk lane & 7
+  const int slot = lane >> 3, ch = lane & 7;
+  auto qrow = [&](int pid) { return (pid & 1) + 4 * (pid >> 1) + 2 * (slot & 1) + 16 * (slot >> 1); };
+  const unsigned voQ0 = (unsigned)(qrow(2 * wave) * (int)p.ldq + ch * 8) * 2u, voQ1 = (unsigned)(qrow(2 * wave + 1) * (int)p.ldq + ch * 8) * 2u;
+  const unsigned voD0 = (unsigned)(qrow(2 * wave) * (int)p.lddo + ch * 8) * 2u, voD1 = (unsigned)(qrow(2 * wave + 1) * (int)p.lddo + ch * 8) * 2u;
+  const unsigned voC = (unsigned)lane * 4u;
+  const long sbase = ((long)b * p.H + hd) * p.Tq;
+  auto sg64 = [](unsigned long long x) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)x), hi = __builtin_amdgcn_readfirstlane((unsigned)(x >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+  };
+  const unsigned long long bQ = sg64((unsigned long long)(p.q + (long)b * p.q_bs + hd * 64));
+  const unsigned long long bD = sg64((unsigned long long)(p.d_o + (long)b * p.do_bs + hd * 64));
+  const unsigned long long bL = sg64((unsigned long long)(p.delta + (long)p.B * p.H * p.Tq + sbase));  // -lse / scale (written by the dQ kernel)
+  const unsigned long long bT = sg64((unsigned long long)(p.delta + sbase));                            // -delta
+  const unsigned long long bK = sg64((unsigned long long)(p.k + (long)b * p.k_bs + hd * 64));
+  const unsigned long long bV = sg64((unsigned long long)(p.v + (long)b * p.v_bs + hd * 64));
+  const unsigned nrQ = __builtin_amdgcn_readfirstlane((unsigned)((p.Tq - 1) * (int)p.ldq * 2 + 128));
+  const unsigned nrD = __builtin_amdgcn_readfirstlane((unsigned)((p.Tq - 1) * (int)p.lddo * 2 + 128));
+  const unsigned nrC = __builtin_amdgcn_readfirstlane((unsigned)p.Tq * 4u);
+  const unsigned stQ = __builtin_amdgcn_readfirstlane((unsigned)p.ldq * 128u), stD = __builtin_amdgcn_readfirstlane((unsigned)p.lddo * 128u);
+  const unsigned npair = __builtin_amdgcn_readfirstlane((unsigned)((p.Tq + 63) >> 6));  // 64-query tiles = iteration pairs
+  const float cscale = p.scale * LOG2E;
+  const unsigned cbits = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, cscale));
+  const unsigned wv = (unsigned)wave;
+
+  asm volatile(D4_ASM_MACROS R"ASM(
+    ; ---- descriptors: Q s[40:43], dO s[44:47], this wave's constants (-lse/scale or -delta) s[48:51]; tile strides s56, s57
+    s_mov_b64 s[40:41], %[bQ]
+    s_mov_b32 s42, %[nrQ]
+    s_mov_b32 s43, 0x20000
+    s_mov_b64 s[44:45], %[bD]
+    s_mov_b32 s46, %[nrD]
+    s_mov_b32 s47, 0x20000
+    s_and_b32 s61, %[wave], 1
+    s_cmp_eq_u32 s61, 0
+    s_cselect_b64 s[48:49], %[bL], %[bT]
+    s_mov_b32 s50, %[nrC]
+    s_mov_b32 s51, 0x20000
+    s_mov_b32 s56, %[stQ]
+    s_mov_b32 s57, %[stD]
+    ; K / V fragments of the two key blocks -> v[128:191] (copied to a[128:191] below)
+    s_mov_b64 s[68:69], %[bK]
+    s_mov_b32 s70, 0x7fffffff
+    s_mov_b32 s71, 0x20000
+    s_mov_b64 s[72:73], %[bV]
+    s_mov_b32 s74, 0x7fffffff
+    s_mov_b32 s75, 0x20000
+    .set d4_i, 0
+    .rept 4
+      buffer_load_dwordx4 v[128+4*d4_i:128+4*d4_i+3], %[voK0], s[68:71], 0 offen offset:32*d4_i
+      buffer_load_dwordx4 v[144+4*d4_i:144+4*d4_i+3], %[voV0], s[72:75], 0 offen offset:32*d4_i
+      buffer_load_dwordx4 v[160+4*d4_i:160+4*d4_i+3], %[voK1], s[68:71], 0 offen offset:32*d4_i
+      buffer_load_dwordx4 v[176+4*d4_i:176+4*d4_i+3], %[voV1], s[72:75], 0 offen offset:32*d4_i
+      .set d4_i, d4_i+1
+    .endr
+    ; LDS-DMA destinations inside a buffer: piece 2 wave (s58), 2 wave + 1 (s59), this wave's constant row (s60: wave 0 lse, 1 delta)
+    s_lshl_b32 s61, %[wave], 1
+    s_mul_i32 s58, s61, 1280
+    s_lshr_b32 s62, s61, 1
+    s_lshl_b32 s62, s62, 4
+    s_add_u32 s58, s58, s62
+    s_add_u32 s58, s58, %[lds0]
+    s_add_u32 s59, s58, 1344
+    s_and_b32 s60, %[wave], 1
+    s_mul_i32 s60, s60, 256
+    s_add_u32 s60, s60, 20480
+    s_add_u32 s60, s60, %[lds0]
+    ; buffer offsets: cur (tile T) s63, nxt (T+1) s64, after next (T+2) s52, ld (T+3) s65; loop counter s66
+    s_mov_b32 s63, 0
+    s_mov_b32 s64, )ASM" D4_STR(D4_BUF) R"ASM(
+    s_mov_b32 s52, 2*)ASM" D4_STR(D4_BUF) R"ASM(
+    s_mov_b32 s65, 3*)ASM" D4_STR(D4_BUF) R"ASM(
+    s_mov_b32 s66, %[npair]
+    ; ---- tiles 0, 1 and 2
+    D4_STAGE s63
+    D4_ADVANCE
+    s_nop 4
+    D4_STAGE s64
+    D4_ADVANCE
+    s_nop 4
+    D4_STAGE s52
+    D4_ADVANCE
+    ; ---- (under the loads) accumulators, packed operands and transposed fragments start from zero: iteration 0 multiplies them
+    .set d4_i, 0
+    .rept 128
+      v_accvgpr_write_b32 a[d4_i], 0
+      .set d4_i, d4_i+1
+    .endr
+    .set d4_i, 32
+    .rept 32
+      v_mov_b32 v[d4_i], 0
+      v_mov_b32 v[d4_i+64], 0
+      .set d4_i, d4_i+1
+    .endr
+    v_mov_b32 v24, %[rb]
+    v_mov_b32 v25, %[tb]
+    v_mov_b32 v26, %[cb]
+    v_add_u32 v27, s64, v24
+    v_add_u32 v28, s64, v26
+    s_waitcnt vmcnt(10)        ; K / V fragments and tile 0 (tiles 1, 2: five pieces each still in flight)
+    s_barrier
+    .set d4_i, 128
+    .rept 64
+      v_accvgpr_write_b32 a[d4_i], v[d4_i]
+      .set d4_i, d4_i+1
+    .endr
+    s_memtime s[76:77]
+    ; ---- block 0: row fragments + constants, S / dP -> generation 128
+    .set d4_i, 0
+    .rept 16
+      D4_RD1 d4_i, v24, v26, 0
+      .set d4_i, d4_i+1
+    .endr
+    s_waitcnt lgkmcnt(0)
+    .set d4_i, 0
+    .rept 16
+      D4_M1 d4_i, 128
+      .set d4_i, d4_i+1
+    .endr
+    s_nop 15
+    s_nop 15
+    .set d4_i, 0
+    .rept 16
+      v_mul_f32 v[128+d4_i], %[c], v[128+d4_i]
+      .set d4_i, d4_i+1
+    .endr
+1:
+    ; ==== tile boundary: tile T+1 has landed for every wave (tile T+2's five pieces may still fly), tile T-1's buffer is free ->
+    ; tile T+3 goes into it during this iteration (three tiles = four to six iterations of memory latency covered)
+    .if d4_exp != 4
+    s_waitcnt vmcnt(5)
+    s_barrier
+    .endif
+    ; even iteration (block 2T): row fragments of block 2T+1 (this tile, half 1), transposed fragments of block 2T (half 0)
+    D4_ITER 128, 192, v24, v26, 1, v25, 0, 1
+    ; odd iteration (block 2T+1): row fragments of block 2T+2 (next tile, half 0), transposed fragments of block 2T+1
+    D4_ITER 192, 128, v27, v28, 0, v25, 1, 0
+    ; rotate the buffers: cur <- nxt <- after next <- ld <- cur
+    s_mov_b32 s67, s63
+    s_mov_b32 s63, s64
+    s_mov_b32 s64, s52
+    s_mov_b32 s52, s65
+    s_mov_b32 s65, s67
+    v_add_u32 v24, s63, %[rb]
+    v_add_u32 v25, s63, %[tb]
+    v_add_u32 v26, s63, %[cb]
+    v_add_u32 v27, s64, %[rb]
+    v_add_u32 v28, s64, %[cb]
+    s_sub_u32 s66, s66, 1
+    s_cmp_eq_u32 s66, 0
+    s_cbranch_scc0 1b
+    ; ---- dV / dK of the last block
+    s_waitcnt lgkmcnt(0)
+    s_memtime s[78:79]
+    s_waitcnt lgkmcnt(0)
+    s_nop 1
+    .set d4_i, 0
+    .rept 16
+      D4_M2 d4_i
+      .set d4_i, d4_i+1
+    .endr
+    s_waitcnt vmcnt(0)
+    s_nop 15
+  )ASM" D4_ASM_PURGE
+               :
+               : [rb] "v"(rb), [tb] "v"(tb), [cb] "v"(cb), [voQ0] "v"(voQ0), [voQ1] "v"(voQ1), [voD0] "v"(voD0), [voD1] "v"(voD1),
+                 [voC] "v"(voC), [voK0] "v"(voK0), [voK1] "v"(voK1), [voV0] "v"(voV0), [voV1] "v"(voV1), [bK] "s"(bK), [bV] "s"(bV), [bQ] "s"(bQ), [bD] "s"(bD), [bL] "s"(bL), [bT] "s"(bT), [nrQ] "s"(nrQ), [nrD] "s"(nrD), [nrC] "s"(nrC),
+                 [stQ] "s"(stQ), [stD] "s"(stD), [npair] "s"(npair), [c] "s"(cbits), [lds0] "s"(lds0), [wave] "s"(wv)
+               : "memory", "vcc", "scc", D4_CLOBBER_A, D4_CLOBBER_V, D4_CLOBBER_S);
+
+  // ---- epilogue: lane (r, h) holds dK / dV [key kw0 + 32 kb + r][d = 32 db + 8 a + 4 h + e] in register 4 a + e of (kb, db).
+  // Lanes r and r + 32 hold the two halves of each 8-column group a: one v_permlane32_swap per dword hands lane (r, 0) all of
+  // group 2 m and lane (r, 1) all of group 2 m + 1 -> 16-byte stores (4 per tensor and key block instead of 16 8-byte ones)
+  auto row16 = [&](const f32x16& acc, int m, float mul) {
+    const unsigned x0 = pack2bf(acc[8 * m] * mul, acc[8 * m + 1] * mul), x1 = pack2bf(acc[8 * m + 2] * mul, acc[8 * m + 3] * mul);
+    const unsigned y0 = pack2bf(acc[8 * m + 4] * mul, acc[8 * m + 5] * mul), y1 = pack2bf(acc[8 * m + 6] * mul, acc[8 * m + 7] * mul);
+    const auto s0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false), s1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+    u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+    return o;
+  };
+  auto store = [&](auto kbc) {
+    constexpr int kb = decltype(kbc)::value;
+    const int kb0 = kw0 + 32 * kb, ki = kb0 + r;
+    f32x16 dk[2], dv[2];
+    dk[0] = d4_get16<64 * kb>(); dk[1] = d4_get16<64 * kb + 16>();
+    dv[0] = d4_get16<64 * kb + 32>(); dv[1] = d4_get16<64 * kb + 48>();
+    unsigned short* dkrow = p.dk + (long)b * p.dk_bs + (long)ki * p.lddk + hd * 64;
+    unsigned short* dvrow = p.dv + (long)b * p.dv_bs + (long)ki * p.lddv + hd * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int d = 32 * db + 8 * (2 * m + h);
+        const u32x4 pk = row16(dk[db], m, p.scale), pv = row16(dv[db], m, 1.0f);  // (every lane takes part in the swaps)
+        if (ki < p.Tk) {
+          *(u32x4*)(dkrow + d) = pk;
+          *(u32x4*)(dvrow + d) = pv;
+        }
+      }
+    if (p.cs_v && kb0 < p.Tk) {  // v-projection bias gradient: column sums over the block's 32 keys of the bf16 values written.
+      // Halving butterfly over the 32 lanes of a half-wave: a lane keeps the half of its values its lane bit selects and adds
+      // the partner's copy of that half — 31 exchanges for 32 sums (att_colsum_store: 160), same pairing, same bits.
+      float cv[32];
+      const bool ok = ki < p.Tk;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) cv[i] = ok ? bf2f(f2bf(dv[i >> 4][i & 15])) : 0.f;
+#pragma unroll
+      for (int m = 16; m >= 1; m >>= 1) {
+        const bool up = (r & m) != 0;
+#pragma unroll
+        for (int i = 0; i < m; ++i) {
+          const float keep = up ? cv[i + m] : cv[i], send = up ? cv[i] : cv[i + m];
+          cv[i] = keep + __shfl_xor(send, m, 64);
+        }
+      }
+      // lane r now holds value index r = 16 db + 4 a + e, i.e. column 32 db + 8 a + 4 h + e
+      float* dst = p.cs_v + ((long)b * ((p.Tk + 31) >> 5) + (kb0 >> 5)) * (p.H * 64) + hd * 64;
+      dst[32 * (r >> 4) + 8 * ((r >> 2) & 3) + 4 * h + (r & 3)] = cv[0];
+    }
+  };
+#ifdef D4_STAMPS
+  unsigned long long st1, st2;
+  asm volatile("s_mov_b64 %0, s[76:77]\n s_mov_b64 %1, s[78:79]" : "=s"(st1), "=s"(st2));
+  const unsigned long long st3 = __builtin_amdgcn_s_memtime();
+#endif
+  store(IntC<0>{});
+  store(IntC<1>{});
+#ifdef D4_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned long long st4 = __builtin_amdgcn_s_memtime();
+  if (tid == 0) {
+    atomicAdd(&d4_dbg[0], 1ull);
+    atomicAdd(&d4_dbg[1], st1 - st0);  // prologue: K / V fragments, two tiles, zeroing
+    atomicAdd(&d4_dbg[2], st2 - st1);  // block 0 + the iteration loop
+    atomicAdd(&d4_dbg[3], st3 - st2);  // last dV / dK
+    atomicAdd(&d4_dbg[4], st4 - st3);  // accumulator read-back, column sums, stores (drained)
+    atomicMin(&d4_dbg[5], st0);
+    atomicMax(&d4_dbg[6], st4);
+  }
+#endif
+}
+
 static int attn_fill(const wft_attn_args* a, AttnP& p) {
   p.q = a->q; p.ldq = a->ldq; p.q_bs = a->q_bs;
   p.k = a->k; p.ldk = a->ldk; p.k_bs = a->k_bs;
@@ -876,6 +1390,21 @@ extern "C" int64_t wft_attn_bwd_colsum_workspace_bytes(const wft_attn_args* a) {
   return ((int64_t)a->B * ((a->Tq + 31) / 32) + (int64_t)a->B * ((a->Tk + 31) / 32) + 2 * ATT_CS_CHUNKS) * a->H * 64 * (int64_t)sizeof(float);
 }
 
+// Which dK/dV kernel: 0 (default) the one-wave-per-SIMD kernel where it applies, 1 always the 8-wave kernel.  WFT_DKDV_VARIANT=8w|4w
+// sets the start value; returns the previous one (a negative argument only reads).
+static int g_dkdv_variant = [] { const char* e = getenv("WFT_DKDV_VARIANT"); return (e && !strcmp(e, "8w")) ? 1 : 0; }();
+extern "C" int wft_attn_set_dkdv_variant(int v) {
+  const int old = g_dkdv_variant;
+  if (v >= 0) g_dkdv_variant = v ? 1 : 0;
+  return old;
+}
+// non-causal sweeps over at least two 64-query tiles whose byte offsets fit the 32-bit buffer addressing of the asm block
+static bool wft_dkdv4w_eligible(const wft_attn_args* a) {
+  if (g_dkdv_variant != 0 || a->causal || a->Tq < 128) return false;
+  const long lim = 0x7fffffffL;
+  return (long)a->Tq * a->ldq * 2 < lim && (long)a->Tq * a->lddo * 2 < lim && (long)a->Tk * a->ldk * 2 < lim && (long)a->Tk * a->ldv * 2 < lim;
+}
+
 extern "C" int wft_attn_bwd_bf16(const wft_attn_args* a, void* stream) {
   WFT_CHECK_ARG(a && a->q && a->k && a->v && a->o && a->lse && a->d_o && a->delta && a->dq && a->dk && a->dv,
                 "null pointer");
@@ -897,10 +1426,10 @@ extern "C" int wft_attn_bwd_bf16(const wft_attn_args* a, void* stream) {
   }
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(((a->Tq + 127) / 128) * a->H * a->B)), dim3(256), 0, s, p);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   {
     static bool lds_set[64] = {false};  // hipFuncSetAttribute is per device
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!lds_set[dev]) {
       const hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dkdv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DKDV_BUF);
       if (e != hipSuccess) {  // (not remembered: the next call tries again)
@@ -911,7 +1440,20 @@ extern "C" int wft_attn_bwd_bf16(const wft_attn_args* a, void* stream) {
       lds_set[dev] = true;
     }
   }
-  hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3((unsigned)(((a->Tk + 127) / 128) * a->H * a->B)), dim3(256), 2 * DKDV_BUF, s, p);
+  if (wft_dkdv4w_eligible(a)) {
+    static bool lds4_set[64] = {false};
+    if (!lds4_set[dev]) {
+      const hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dkdv4w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, D4_LDS);
+      if (e != hipSuccess) {
+        wft_set_error("wft_attn_bwd_bf16: the dK/dV kernel needs %d bytes of dynamic LDS, hipFuncSetAttribute: %s", D4_LDS, hipGetErrorString(e));
+        return WFT_ERR_LAUNCH;
+      }
+      lds4_set[dev] = true;
+    }
+    hipLaunchKernelGGL(attn_bwd_dkdv4w_kernel, dim3((unsigned)(((a->Tk + 255) / 256) * a->H * a->B)), dim3(256), D4_LDS, s, p);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3((unsigned)(((a->Tk + 127) / 128) * a->H * a->B)), dim3(256), 2 * DKDV_BUF, s, p);
+  }
   if (p.cs_q) {
     const int n = a->H * 64;
     const long rq = (long)a->B * ((a->Tq + 31) / 32), rk = (long)a->B * ((a->Tk + 31) / 32);
@@ -925,3 +1467,4 @@ extern "C" int wft_attn_bwd_bf16(const wft_attn_args* a, void* stream) {
   WFT_CHECK_LAUNCH();
   return WFT_OK;
 }
+
