@@ -16,14 +16,17 @@ o, lse = K.attn_fwd(q, k, v, H, False, 0.125)
 cs = (torch.empty(d, device=dev), torch.empty(d, device=dev))
 for _ in range(3): K.attn_bwd(q, k, v, o, lse, do, H, False, 0.125, colsums=cs)
 torch.cuda.synchronize()
-buf = (ctypes.c_ulonglong * 8)()
+buf = (ctypes.c_ulonglong * 16)()
 so.wft_dbg_read(buf, 1)
-# atomicMin slot starts from zero after the reset: seed it high
 K.attn_bwd(q, k, v, o, lse, do, H, False, 0.125, colsums=cs)
 so.wft_dbg_read(buf, 0)
-n = buf[0]
-print(f"{n} workgroups; clock ticks per workgroup (s_memtime, 100 MHz-class constant clock or shader clock, see ratio below):")
-for i, name in ((1, "prologue"), (2, "block 0 + loop"), (3, "last dV / dK"), (4, "read-back + colsum + stores")):
-    print(f"  {name:28s} {buf[i] / n:10.0f}")
-tot = sum(buf[1:5]) / n
-print(f"  sum {tot:.0f}; x {n / 256:.1f} workgroups per CU = {tot * n / 256:.0f}; first start -> last end {buf[6]:d} (min start slot not seeded)")
+names = ("prologue (descriptors, requests or wait, zeroing, barrier)", "block 0 + loop", "last dV / dK + drain", "prefetch block",
+         "read-back + colsum + stores")
+for o, what in ((0, "first item of a workgroup"), (8, "later items")):
+    n = buf[o]
+    if not n:
+        continue
+    print(f"{what}: {n} items; clock ticks per item")
+    for i, name in enumerate(names):
+        print(f"  {name:60s} {buf[o + 1 + i] / n:10.0f}")
+    print(f"  sum {sum(buf[o + 1:o + 6]) / n:.0f}")

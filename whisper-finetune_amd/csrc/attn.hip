@@ -15,6 +15,7 @@
 // ONE source-side swizzle (chunk ^= F(row)) that is conflict-free for both the 32-row
 // ds_read_b128 operand reads and the 4-row transposed reads.
 #include "common.h"
+#include "gemm_common.h"  // wft_num_cus
 #include <stdlib.h>
 #include <string.h>
 
@@ -1052,30 +1053,117 @@ __device__ __forceinline__ f32x16 d4_get16() {
   return v;
 }
 
+#ifdef D4_STAMPS
+#define D4_STAMP_ASM(r) "s_memtime s[" #r ":" #r "+1]\n s_waitcnt lgkmcnt(0)\n"
+#else
+#define D4_STAMP_ASM(r) ""
+#endif
 #ifdef D4_STAMPS  // developer build (tools/dev/dkdv4w_stamps.py): clock-tick sums over workgroups, wave 0
-__device__ unsigned long long d4_dbg[8];
+__device__ unsigned long long d4_dbg[16];
 extern "C" void wft_dbg_read(unsigned long long* host, int reset) {
-  if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(d4_dbg), z, sizeof z); return; }
+  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(d4_dbg), z, sizeof z); return; }
   (void)hipDeviceSynchronize();
-  (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(d4_dbg), 8 * sizeof(unsigned long long));
+  (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(d4_dbg), 16 * sizeof(unsigned long long));
 }
 #endif
+// descriptors and requests shared by the main block and the prefetch block of attn_bwd_dkdv4w_kernel
+#define D4_ASM_MACROS2 R"ASM(
+; descriptors: Q s[40:43], dO s[44:47], this wave's constants (-lse/scale or -delta) s[48:51], K s[68:71], V s[72:75];
+; tile strides s56, s57; LDS-DMA destinations inside a buffer: piece 2 wave (s58), 2 wave + 1 (s59), this wave's constant row (s60:
+; even waves lse, odd delta); buffer offsets: cur (tile T) s63, nxt (T+1) s64, after next (T+2) s52, ld (T+3) s65
+.macro D4_SRD_INIT
+  s_mov_b64 s[40:41], %[bQ]
+  s_lshr_b32 s61, %[stQ], 6
+  s_sub_u32 s62, %[tq], 1
+  s_mul_i32 s42, s62, s61
+  s_add_u32 s42, s42, 128
+  s_mov_b32 s43, 0x20000
+  s_mov_b64 s[44:45], %[bD]
+  s_lshr_b32 s61, %[stD], 6
+  s_mul_i32 s46, s62, s61
+  s_add_u32 s46, s46, 128
+  s_mov_b32 s47, 0x20000
+  s_and_b32 s61, %[wave], 1
+  s_cmp_eq_u32 s61, 0
+  s_cselect_b64 s[48:49], %[bL], %[bT]
+  s_lshl_b32 s50, %[tq], 2
+  s_mov_b32 s51, 0x20000
+  s_mov_b32 s56, %[stQ]
+  s_mov_b32 s57, %[stD]
+  s_mov_b64 s[68:69], %[bK]
+  s_sub_u32 s62, %[tk], 1
+  s_mul_i32 s70, s62, %[ldk2]
+  s_add_u32 s70, s70, 128
+  s_mov_b32 s71, 0x20000
+  s_mov_b64 s[72:73], %[bV]
+  s_mul_i32 s74, s62, %[ldv2]
+  s_add_u32 s74, s74, 128
+  s_mov_b32 s75, 0x20000
+  s_lshl_b32 s61, %[wave], 1
+  s_mul_i32 s58, s61, 1280
+  s_lshr_b32 s62, s61, 1
+  s_lshl_b32 s62, s62, 4
+  s_add_u32 s58, s58, s62
+  s_add_u32 s58, s58, %[lds0]
+  s_add_u32 s59, s58, 1344
+  s_and_b32 s60, %[wave], 1
+  s_mul_i32 s60, s60, 256
+  s_add_u32 s60, s60, 20480
+  s_add_u32 s60, s60, %[lds0]
+  s_mov_b32 s63, 0
+  s_mov_b32 s64, )ASM" D4_STR(D4_BUF) R"ASM(
+  s_mov_b32 s52, 2*)ASM" D4_STR(D4_BUF) R"ASM(
+  s_mov_b32 s65, 3*)ASM" D4_STR(D4_BUF) R"ASM(
+.endm
+; K / V row fragments of this wave's two 32-key blocks -> a[128:191] (rows past Tk lie beyond the descriptors: zeros)
+.macro D4_KV
+  .set d4_i, 0
+  .rept 4
+    buffer_load_dwordx4 a[128+4*d4_i:128+4*d4_i+3], %[voK0], s[68:71], 0 offen offset:32*d4_i
+    buffer_load_dwordx4 a[144+4*d4_i:144+4*d4_i+3], %[voV0], s[72:75], 0 offen offset:32*d4_i
+    buffer_load_dwordx4 a[160+4*d4_i:160+4*d4_i+3], %[voK1], s[68:71], 0 offen offset:32*d4_i
+    buffer_load_dwordx4 a[176+4*d4_i:176+4*d4_i+3], %[voV1], s[72:75], 0 offen offset:32*d4_i
+    .set d4_i, d4_i+1
+  .endr
+.endm
+; first three tiles of a key block -> buffers 0, 1, 2 (sources end up three tiles on)
+.macro D4_STAGE3
+  D4_STAGE s63
+  D4_ADVANCE
+  s_nop 4
+  D4_STAGE s64
+  D4_ADVANCE
+  s_nop 4
+  D4_STAGE s52
+  D4_ADVANCE
+.endm
+)ASM"
+#define D4_ASM_PURGE2 R"ASM(
+.purgem D4_SRD_INIT
+.purgem D4_KV
+.purgem D4_STAGE3
+)ASM"
+
 __global__ __launch_bounds__(256) void attn_bwd_dkdv4w_kernel(AttnP p) {
 #ifdef D4_STAMPS
-  const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+  unsigned long long st0 = __builtin_amdgcn_s_memtime();
 #endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
-  int bx, hd, b;
-  att_block_coords((p.Tk + 255) >> 8, p.H, p.B, p.xcd, bx, hd, b);
-  const int kw0 = bx * 256 + wave * 64;
-  // K / V row fragments of this wave's two 32-key blocks -> a[128:191], loaded inside the asm block (rows clamped: lanes past
-  // Tk compute garbage nobody stores): byte offsets of this lane's row in block 0 / 1, relative to the (batch, head) bases
-  auto krow = [&](int kb) { const int ki = kw0 + 32 * kb + r; return ki < p.Tk ? ki : p.Tk - 1; };
-  const unsigned voK0 = (unsigned)(krow(0) * (int)p.ldk + 8 * h) * 2u, voK1 = (unsigned)(krow(1) * (int)p.ldk + 8 * h) * 2u;
-  const unsigned voV0 = (unsigned)(krow(0) * (int)p.ldv + 8 * h) * 2u, voV1 = (unsigned)(krow(1) * (int)p.ldv + 8 * h) * 2u;
+  // PERSISTENT: one workgroup per CU (it owns the CU: one wave per SIMD, 512 registers) walks work items (batch, head, 256-key
+  // block).  The workgroups of one XCD take that XCD's items round-robin, in the order (head group, key block): the ~32 items
+  // in flight on an XCD are the key blocks of 5-6 heads, whose Q / dO tiles (384 KB per head) stay in that XCD's L2, exactly
+  // as with one workgroup per item (att_block_coords).  The next item's K / V fragments and first three tiles are requested
+  // before this item's epilogue, so only a workgroup's first item waits for memory.
+  const int nkb = (p.Tk + 255) >> 8;
+  const int ngrp = p.H * p.B;
+  const bool xcd_mode = ((ngrp & 7) == 0) && p.xcd && ((gridDim.x & 7) == 0);
+  const int xcd = xcd_mode ? (int)(blockIdx.x & 7) : 0;
+  const int w0 = xcd_mode ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int wstep = xcd_mode ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+  const int nitems = (xcd_mode ? ngrp >> 3 : ngrp) * nkb;
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
   // fragment read bases (see the layout note above)
   const int c = r & 15, pidr = (c & 1) | ((c >> 2) << 1);
@@ -1089,83 +1177,63 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv4w_kernel(AttnP p) {
   const unsigned voQ0 = (unsigned)(qrow(2 * wave) * (int)p.ldq + ch * 8) * 2u, voQ1 = (unsigned)(qrow(2 * wave + 1) * (int)p.ldq + ch * 8) * 2u;
   const unsigned voD0 = (unsigned)(qrow(2 * wave) * (int)p.lddo + ch * 8) * 2u, voD1 = (unsigned)(qrow(2 * wave + 1) * (int)p.lddo + ch * 8) * 2u;
   const unsigned voC = (unsigned)lane * 4u;
-  const long sbase = ((long)b * p.H + hd) * p.Tq;
   auto sg64 = [](unsigned long long x) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)x), hi = __builtin_amdgcn_readfirstlane((unsigned)(x >> 32));
     return ((unsigned long long)hi << 32) | lo;
   };
-  const unsigned long long bQ = sg64((unsigned long long)(p.q + (long)b * p.q_bs + hd * 64));
-  const unsigned long long bD = sg64((unsigned long long)(p.d_o + (long)b * p.do_bs + hd * 64));
-  const unsigned long long bL = sg64((unsigned long long)(p.delta + (long)p.B * p.H * p.Tq + sbase));  // -lse / scale (written by the dQ kernel)
-  const unsigned long long bT = sg64((unsigned long long)(p.delta + sbase));                            // -delta
-  const unsigned long long bK = sg64((unsigned long long)(p.k + (long)b * p.k_bs + hd * 64));
-  const unsigned long long bV = sg64((unsigned long long)(p.v + (long)b * p.v_bs + hd * 64));
-  const unsigned nrQ = __builtin_amdgcn_readfirstlane((unsigned)((p.Tq - 1) * (int)p.ldq * 2 + 128));
-  const unsigned nrD = __builtin_amdgcn_readfirstlane((unsigned)((p.Tq - 1) * (int)p.lddo * 2 + 128));
-  const unsigned nrC = __builtin_amdgcn_readfirstlane((unsigned)p.Tq * 4u);
+  const unsigned tq = __builtin_amdgcn_readfirstlane((unsigned)p.Tq), tk = __builtin_amdgcn_readfirstlane((unsigned)p.Tk);
+  const unsigned ldk2 = __builtin_amdgcn_readfirstlane((unsigned)p.ldk * 2u), ldv2 = __builtin_amdgcn_readfirstlane((unsigned)p.ldv * 2u);
   const unsigned stQ = __builtin_amdgcn_readfirstlane((unsigned)p.ldq * 128u), stD = __builtin_amdgcn_readfirstlane((unsigned)p.lddo * 128u);
   const unsigned npair = __builtin_amdgcn_readfirstlane((unsigned)((p.Tq + 63) >> 6));  // 64-query tiles = iteration pairs
   const float cscale = p.scale * LOG2E;
   const unsigned cbits = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, cscale));
   const unsigned wv = (unsigned)wave;
+  // everything that depends on the work item
+  struct Item {
+    int b, hd, kw0;
+    unsigned long long bQ, bD, bL, bT, bK, bV;
+    unsigned voK0, voK1, voV0, voV1;
+  };
+  auto item = [&](int t) {
+    Item x;
+    const int g = xcd_mode ? (t / nkb) * 8 + xcd : t / nkb;
+    x.hd = g % p.H;
+    x.b = g / p.H;
+    x.kw0 = (t % nkb) * 256 + wave * 64;
+    const long sbase = ((long)x.b * p.H + x.hd) * p.Tq;
+    x.bQ = sg64((unsigned long long)(p.q + (long)x.b * p.q_bs + x.hd * 64));
+    x.bD = sg64((unsigned long long)(p.d_o + (long)x.b * p.do_bs + x.hd * 64));
+    x.bL = sg64((unsigned long long)(p.delta + (long)p.B * p.H * p.Tq + sbase));  // -lse / scale (written by the dQ kernel)
+    x.bT = sg64((unsigned long long)(p.delta + sbase));                            // -delta
+    x.bK = sg64((unsigned long long)(p.k + (long)x.b * p.k_bs + x.hd * 64));
+    x.bV = sg64((unsigned long long)(p.v + (long)x.b * p.v_bs + x.hd * 64));
+    // byte offsets of this lane's K / V rows (key blocks 0 / 1 of the wave) relative to the (batch, head) bases
+    x.voK0 = (unsigned)((x.kw0 + r) * (int)p.ldk + 8 * h) * 2u; x.voK1 = x.voK0 + 32u * ldk2;
+    x.voV0 = (unsigned)((x.kw0 + r) * (int)p.ldv + 8 * h) * 2u; x.voV1 = x.voV0 + 32u * ldv2;
+    return x;
+  };
 
-  asm volatile(D4_ASM_MACROS R"ASM(
-    ; ---- descriptors: Q s[40:43], dO s[44:47], this wave's constants (-lse/scale or -delta) s[48:51]; tile strides s56, s57
-    s_mov_b64 s[40:41], %[bQ]
-    s_mov_b32 s42, %[nrQ]
-    s_mov_b32 s43, 0x20000
-    s_mov_b64 s[44:45], %[bD]
-    s_mov_b32 s46, %[nrD]
-    s_mov_b32 s47, 0x20000
-    s_and_b32 s61, %[wave], 1
-    s_cmp_eq_u32 s61, 0
-    s_cselect_b64 s[48:49], %[bL], %[bT]
-    s_mov_b32 s50, %[nrC]
-    s_mov_b32 s51, 0x20000
-    s_mov_b32 s56, %[stQ]
-    s_mov_b32 s57, %[stD]
-    ; K / V fragments of the two key blocks -> v[128:191] (copied to a[128:191] below)
-    s_mov_b64 s[68:69], %[bK]
-    s_mov_b32 s70, 0x7fffffff
-    s_mov_b32 s71, 0x20000
-    s_mov_b64 s[72:73], %[bV]
-    s_mov_b32 s74, 0x7fffffff
-    s_mov_b32 s75, 0x20000
-    .set d4_i, 0
-    .rept 4
-      buffer_load_dwordx4 v[128+4*d4_i:128+4*d4_i+3], %[voK0], s[68:71], 0 offen offset:32*d4_i
-      buffer_load_dwordx4 v[144+4*d4_i:144+4*d4_i+3], %[voV0], s[72:75], 0 offen offset:32*d4_i
-      buffer_load_dwordx4 v[160+4*d4_i:160+4*d4_i+3], %[voK1], s[68:71], 0 offen offset:32*d4_i
-      buffer_load_dwordx4 v[176+4*d4_i:176+4*d4_i+3], %[voV1], s[72:75], 0 offen offset:32*d4_i
-      .set d4_i, d4_i+1
-    .endr
-    ; LDS-DMA destinations inside a buffer: piece 2 wave (s58), 2 wave + 1 (s59), this wave's constant row (s60: wave 0 lse, 1 delta)
-    s_lshl_b32 s61, %[wave], 1
-    s_mul_i32 s58, s61, 1280
-    s_lshr_b32 s62, s61, 1
-    s_lshl_b32 s62, s62, 4
-    s_add_u32 s58, s58, s62
-    s_add_u32 s58, s58, %[lds0]
-    s_add_u32 s59, s58, 1344
-    s_and_b32 s60, %[wave], 1
-    s_mul_i32 s60, s60, 256
-    s_add_u32 s60, s60, 20480
-    s_add_u32 s60, s60, %[lds0]
-    ; buffer offsets: cur (tile T) s63, nxt (T+1) s64, after next (T+2) s52, ld (T+3) s65; loop counter s66
-    s_mov_b32 s63, 0
-    s_mov_b32 s64, )ASM" D4_STR(D4_BUF) R"ASM(
-    s_mov_b32 s52, 2*)ASM" D4_STR(D4_BUF) R"ASM(
-    s_mov_b32 s65, 3*)ASM" D4_STR(D4_BUF) R"ASM(
-    s_mov_b32 s66, %[npair]
-    ; ---- tiles 0, 1 and 2
-    D4_STAGE s63
+  for (int t = w0; t < nitems; t += wstep) {
+  const Item cur = item(t);
+  const int b = cur.b, hd = cur.hd, kw0 = cur.kw0;
+  const unsigned first = __builtin_amdgcn_readfirstlane((unsigned)(t == w0));
+
+  asm volatile(D4_ASM_MACROS D4_ASM_MACROS2 R"ASM(
+    D4_SRD_INIT
+    s_mov_b32 s66, %[npair]      ; loop counter
+    s_cmp_eq_u32 %[first], 0
+    s_cbranch_scc1 2f
+    ; ---- first item of this workgroup: its K / V fragments and tiles 0, 1, 2 are requested here ...
+    D4_KV
+    D4_STAGE3
+    s_branch 3f
+2:
+    ; ---- ... later ones found them requested by the prefetch block behind the previous item (below): only the descriptors move on
     D4_ADVANCE
-    s_nop 4
-    D4_STAGE s64
     D4_ADVANCE
-    s_nop 4
-    D4_STAGE s52
     D4_ADVANCE
+    s_waitcnt vmcnt(0)
+3:
     ; ---- (under the loads) accumulators, packed operands and transposed fragments start from zero: iteration 0 multiplies them
     .set d4_i, 0
     .rept 128
@@ -1183,14 +1251,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv4w_kernel(AttnP p) {
     v_mov_b32 v26, %[cb]
     v_add_u32 v27, s64, v24
     v_add_u32 v28, s64, v26
-    s_waitcnt vmcnt(10)        ; K / V fragments and tile 0 (tiles 1, 2: five pieces each still in flight)
+    s_waitcnt vmcnt(10)        ; K / V fragments and tile 0 (tiles 1, 2: five pieces each may still be in flight)
     s_barrier
-    .set d4_i, 128
-    .rept 64
-      v_accvgpr_write_b32 a[d4_i], v[d4_i]
-      .set d4_i, d4_i+1
-    .endr
-    s_memtime s[76:77]
+    )ASM" D4_STAMP_ASM(76) R"ASM(
     ; ---- block 0: row fragments + constants, S / dP -> generation 128
     .set d4_i, 0
     .rept 16
@@ -1237,22 +1300,47 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv4w_kernel(AttnP p) {
     s_cbranch_scc0 1b
     ; ---- dV / dK of the last block
     s_waitcnt lgkmcnt(0)
-    s_memtime s[78:79]
-    s_waitcnt lgkmcnt(0)
+    )ASM" D4_STAMP_ASM(78) R"ASM(
     s_nop 1
     .set d4_i, 0
     .rept 16
       D4_M2 d4_i
       .set d4_i, d4_i+1
     .endr
-    s_waitcnt vmcnt(0)
+    s_waitcnt vmcnt(0)         ; (the tiles requested past the last query block: zeros, but they must not land later)
     s_nop 15
-  )ASM" D4_ASM_PURGE
+  )ASM" D4_ASM_PURGE D4_ASM_PURGE2
                :
                : [rb] "v"(rb), [tb] "v"(tb), [cb] "v"(cb), [voQ0] "v"(voQ0), [voQ1] "v"(voQ1), [voD0] "v"(voD0), [voD1] "v"(voD1),
-                 [voC] "v"(voC), [voK0] "v"(voK0), [voK1] "v"(voK1), [voV0] "v"(voV0), [voV1] "v"(voV1), [bK] "s"(bK), [bV] "s"(bV), [bQ] "s"(bQ), [bD] "s"(bD), [bL] "s"(bL), [bT] "s"(bT), [nrQ] "s"(nrQ), [nrD] "s"(nrD), [nrC] "s"(nrC),
-                 [stQ] "s"(stQ), [stD] "s"(stD), [npair] "s"(npair), [c] "s"(cbits), [lds0] "s"(lds0), [wave] "s"(wv)
+                 [voC] "v"(voC), [voK0] "v"(cur.voK0), [voK1] "v"(cur.voK1), [voV0] "v"(cur.voV0), [voV1] "v"(cur.voV1), [bK] "s"(cur.bK),
+                 [bV] "s"(cur.bV), [bQ] "s"(cur.bQ), [bD] "s"(cur.bD), [bL] "s"(cur.bL), [bT] "s"(cur.bT), [tq] "s"(tq), [tk] "s"(tk),
+                 [ldk2] "s"(ldk2), [ldv2] "s"(ldv2), [first] "s"(first), [stQ] "s"(stQ), [stD] "s"(stD), [npair] "s"(npair), [c] "s"(cbits),
+                 [lds0] "s"(lds0), [wave] "s"(wv)
                : "memory", "vcc", "scc", D4_CLOBBER_A, D4_CLOBBER_V, D4_CLOBBER_S);
+
+#ifdef D4_STAMPS
+  const unsigned long long st3 = __builtin_amdgcn_s_memtime();
+#endif
+  if (t + wstep < nitems) {
+    // ---- prefetch block: once every wave has left the LDS buffers, request the NEXT item's K / V fragments (a[128:191]) and
+    // first three tiles; they fly while the accumulators of this item are scaled, summed and stored below
+    const Item nx = item(t + wstep);
+    asm volatile(D4_ASM_MACROS D4_ASM_MACROS2 R"ASM(
+      s_barrier
+      D4_SRD_INIT
+      D4_KV
+      D4_STAGE3
+    )ASM" D4_ASM_PURGE D4_ASM_PURGE2
+                 :
+                 : [voQ0] "v"(voQ0), [voQ1] "v"(voQ1), [voD0] "v"(voD0), [voD1] "v"(voD1), [voC] "v"(voC), [voK0] "v"(nx.voK0),
+                   [voK1] "v"(nx.voK1), [voV0] "v"(nx.voV0), [voV1] "v"(nx.voV1), [bK] "s"(nx.bK), [bV] "s"(nx.bV), [bQ] "s"(nx.bQ),
+                   [bD] "s"(nx.bD), [bL] "s"(nx.bL), [bT] "s"(nx.bT), [tq] "s"(tq), [tk] "s"(tk), [ldk2] "s"(ldk2), [ldv2] "s"(ldv2),
+                   [stQ] "s"(stQ), [stD] "s"(stD), [lds0] "s"(lds0), [wave] "s"(wv), [c] "s"(cbits)
+                 : "memory", "scc", D4_CLOBBER_S, D4_A8(13), D4_A8(14), D4_A8(15), D4_A8(16), D4_A8(17), D4_A8(18), "a128", "a129", "a190", "a191");
+  }
+#ifdef D4_STAMPS
+  const unsigned long long st3b = __builtin_amdgcn_s_memtime();
+#endif
 
   // ---- epilogue: lane (r, h) holds dK / dV [key kw0 + 32 kb + r][d = 32 db + 8 a + 4 h + e] in register 4 a + e of (kb, db).
   // Lanes r and r + 32 hold the two halves of each 8-column group a: one v_permlane32_swap per dword hands lane (r, 0) all of
@@ -1307,23 +1395,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv4w_kernel(AttnP p) {
 #ifdef D4_STAMPS
   unsigned long long st1, st2;
   asm volatile("s_mov_b64 %0, s[76:77]\n s_mov_b64 %1, s[78:79]" : "=s"(st1), "=s"(st2));
-  const unsigned long long st3 = __builtin_amdgcn_s_memtime();
 #endif
   store(IntC<0>{});
   store(IntC<1>{});
 #ifdef D4_STAMPS
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const unsigned long long st4 = __builtin_amdgcn_s_memtime();
   if (tid == 0) {
-    atomicAdd(&d4_dbg[0], 1ull);
-    atomicAdd(&d4_dbg[1], st1 - st0);  // prologue: K / V fragments, two tiles, zeroing
-    atomicAdd(&d4_dbg[2], st2 - st1);  // block 0 + the iteration loop
-    atomicAdd(&d4_dbg[3], st3 - st2);  // last dV / dK
-    atomicAdd(&d4_dbg[4], st4 - st3);  // accumulator read-back, column sums, stores (drained)
-    atomicMin(&d4_dbg[5], st0);
-    atomicMax(&d4_dbg[6], st4);
+    const int o = (t == w0) ? 0 : 8;  // first item of a workgroup | later items
+    atomicAdd(&d4_dbg[o + 0], 1ull);
+    atomicAdd(&d4_dbg[o + 1], st1 - st0);  // prologue: descriptors, (first item: requests), zeroing, wait, barrier
+    atomicAdd(&d4_dbg[o + 2], st2 - st1);  // block 0 + the iteration loop
+    atomicAdd(&d4_dbg[o + 3], st3 - st2);  // last dV / dK, drain
+    atomicAdd(&d4_dbg[o + 4], st3b - st3);  // prefetch block
+    atomicAdd(&d4_dbg[o + 5], st4 - st3b);  // accumulator read-back, column sums, stores (not drained)
   }
+  st0 = st4;
 #endif
+  }  // work items of this workgroup
 }
 
 static int attn_fill(const wft_attn_args* a, AttnP& p) {
@@ -1450,7 +1538,13 @@ extern "C" int wft_attn_bwd_bf16(const wft_attn_args* a, void* stream) {
       }
       lds4_set[dev] = true;
     }
-    hipLaunchKernelGGL(attn_bwd_dkdv4w_kernel, dim3((unsigned)(((a->Tk + 255) / 256) * a->H * a->B)), dim3(256), D4_LDS, s, p);
+    // persistent: one workgroup per CU (WFT_DKDV_WGS overrides: A/B runs; >= the number of items = one item per workgroup)
+    static const int wgs_env = [] { const char* e = getenv("WFT_DKDV_WGS"); return e ? atoi(e) : 0; }();
+    const long items = (long)((a->Tk + 255) / 256) * a->H * a->B;
+    long wgs = wgs_env > 0 ? wgs_env : wft_num_cus();
+    if (wgs > items) wgs = items;
+    if (((long)a->H * a->B) % 8 == 0 && wgs >= 8) wgs -= wgs % 8;  // XCD mode needs the same number of workgroups on every XCD
+    hipLaunchKernelGGL(attn_bwd_dkdv4w_kernel, dim3((unsigned)wgs), dim3(256), D4_LDS, s, p);
   } else {
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3((unsigned)(((a->Tk + 127) / 128) * a->H * a->B)), dim3(256), 2 * DKDV_BUF, s, p);
   }
