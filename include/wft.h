@@ -274,6 +274,9 @@ int64_t wft_attn_bwd_colsum_workspace_bytes(const wft_attn_args* args);
  * rounding of a different summation order over queries.  Returns the previous value; a negative argument only reads.
  * Start value from WFT_DKDV_VARIANT=4w|8w.  (A/B measurements and tests; not part of the reference's interface.)          */
 int wft_attn_set_dkdv_variant(int variant);
+/* The same switch for the dQ kernel (attn_bwd_dq4w_kernel: non-causal calls with Tq >= 512).  Start value from
+ * WFT_DQ_VARIANT=4w|8w.                                                                                                    */
+int wft_attn_set_dq_variant(int variant);
 
 /* -------------------------------------------------------------- Embedding */
 /* TextDecoder: x = token_embedding(tokens) + positional_embedding[:S]

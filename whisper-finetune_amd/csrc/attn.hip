@@ -1433,6 +1433,423 @@ static int attn_fill(const wft_attn_args* a, AttnP& p) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------ dQ, one wave per SIMD (round 4)
+// The mirror image of attn_bwd_dkdv4w_kernel with the roles of queries and keys exchanged: a wave owns 64 QUERIES (two 32-query
+// blocks; Q / dO row fragments in a[64:127] as B operands, dQ^T accumulators a[0:63]) and streams 32-key blocks from LDS tiles
+// {K, V} of 64 keys (same piece layout as the Q / dO tiles above).  Scores are formed transposed, S^T[key, query], so a lane holds
+// ONE query's column: the row constants -lse/scale and -delta are per-lane values, spread over 16 registers each and used as the C
+// operand of the first MFMA of every chain (exactly the 8-wave kernel's arithmetic: results are bit-identical).  Per iteration:
+//   MFMA  slots  0-7   dQ^T += K^T(tr) . dS of block j-1      slots 8-23  S^T / dP^T of block j+1 (four chains of four)
+//   VALU  slots  0-15  c-multiply of query block 1, both exponentials, dS multiply of query block 0 (24 cycles per slot)
+//         slots 16-23  the other dS multiplies, the 16 packs, the c-multiplies of the NEXT block's query block 0
+//   LDS   slots  0-7   K / V row fragments of block j+1;  slots 12-19 transposed K fragments of block j;  counted waits only
+// Keys past Tk exist only in the last tile: its two iterations are emitted a second time with a per-element select (x -> -1e30
+// before the exponential, so p = dS = 0 exactly like the 8-wave kernel's mask); K / V rows past Tk arrive as zeros.
+// The kernel also writes the row constants -delta = -rowsum(dO * O) and -lse / scale for the dK/dV kernel (same expression, same
+// order as attn_bwd_dq_kernel).
+#define Q4_BUF 20480
+#define Q4_LDS (4 * Q4_BUF)
+#define Q4_ASM_MACROS R"ASM(
+; registers: S(g,qb) v[g+32qb..+15], dP(g,qb) v[g+16+32qb..+15], g = 128 / 192; DSF(qb) v[32+8qb..+7]; TK(ks,db) v[48+8ks+4db..+3];
+; -delta of the lane's query, 16 copies: v[64+16qb..]; -lse/scale: v[96+16qb..]; dQ^T(qb,db) a[32qb+16db..+15];
+; QF(qb,s) a[64+32qb+4s..+3], DOF(qb,s) a[80+32qb+4s..+3]; key-row fragments AK(s) a[128+4s..], AV(s) a[144+4s..]
+.macro Q4_M2 n
+  v_mfma_f32_32x32x16_bf16 a[32*((\n)/4)+16*((\n)%%2):32*((\n)/4)+16*((\n)%%2)+15], v[48+8*(((\n)/2)%%2)+4*((\n)%%2):48+8*(((\n)/2)%%2)+4*((\n)%%2)+3], v[32+8*((\n)/4)+4*(((\n)/2)%%2):32+8*((\n)/4)+4*(((\n)/2)%%2)+3], a[32*((\n)/4)+16*((\n)%%2):32*((\n)/4)+16*((\n)%%2)+15]
+.endm
+.macro Q4_M1 n, g
+  ; chain (\n)/4: 0 S qb0, 1 dP qb0, 2 S qb1, 3 dP qb1; k-step (\n)%%4
+  .if ((\n) %% 4) == 0
+    v_mfma_f32_32x32x16_bf16 v[\g+16*(((\n)/4)%%2)+32*((\n)/8):\g+16*(((\n)/4)%%2)+32*((\n)/8)+15], a[128+16*(((\n)/4)%%2):128+16*(((\n)/4)%%2)+3], a[64+16*(((\n)/4)%%2)+32*((\n)/8):64+16*(((\n)/4)%%2)+32*((\n)/8)+3], v[96-32*(((\n)/4)%%2)+16*((\n)/8):96-32*(((\n)/4)%%2)+16*((\n)/8)+15]
+  .else
+    v_mfma_f32_32x32x16_bf16 v[\g+16*(((\n)/4)%%2)+32*((\n)/8):\g+16*(((\n)/4)%%2)+32*((\n)/8)+15], a[128+16*(((\n)/4)%%2)+4*((\n)%%4):128+16*(((\n)/4)%%2)+4*((\n)%%4)+3], a[64+16*(((\n)/4)%%2)+32*((\n)/8)+4*((\n)%%4):64+16*(((\n)/4)%%2)+32*((\n)/8)+4*((\n)%%4)+3], v[\g+16*(((\n)/4)%%2)+32*((\n)/8):\g+16*(((\n)/4)%%2)+32*((\n)/8)+15]
+  .endif
+.endm
+; row read i (0..7) of a 32-key block (half \hf of its tile): 0-3 K rows -> AK, 4-7 V rows -> AV
+.macro Q4_RD1 i, rb, hf
+  .if (\i) < 4
+    ds_read_b128 a[128+4*(\i):128+4*(\i)+3], \rb offset:512*\hf+32*(\i)
+  .else
+    ds_read_b128 a[144+4*((\i)-4):144+4*((\i)-4)+3], \rb offset:10240+512*\hf+32*((\i)-4)
+  .endif
+.endm
+; transposed K read m (0..7) in the order the dQ MFMAs consume them: (ks, db) = (m/4, (m/2)%%2), t = m%%2
+.macro Q4_RD2 m, tb, hf
+  ds_read_b64_tr_b16 v[48+8*((\m)/4)+4*(((\m)/2)%%2)+2*((\m)%%2):48+8*((\m)/4)+4*(((\m)/2)%%2)+2*((\m)%%2)+1], \tb offset:5152*((\m)%%2)+128*(4*\hf+2*((\m)/4))+64*(((\m)/2)%%2)
+.endm
+; next 64-key tile: K / V sources += 64 rows, bounds shrink with them (not below zero)
+.macro Q4_ADVANCE
+  s_add_u32 s40, s40, s56
+  s_addc_u32 s41, s41, 0
+  s_sub_u32 s42, s42, s56
+  s_cselect_b32 s42, 0, s42
+  s_add_u32 s44, s44, s57
+  s_addc_u32 s45, s45, 0
+  s_sub_u32 s46, s46, s57
+  s_cselect_b32 s46, 0, s46
+.endm
+; step i (0..3) of this wave's share of one tile -> the buffer at LDS offset \boff: pieces 2 wave, 2 wave + 1 of K (0, 1) and V (2, 3)
+.macro Q4_DMA i, boff
+  .if (\i) == 0
+    s_add_u32 m0, s58, \boff
+    s_nop 0
+    buffer_load_dwordx4 %[voK0], s[40:43], 0 offen lds
+  .elseif (\i) == 1
+    s_add_u32 m0, s59, \boff
+    s_nop 0
+    buffer_load_dwordx4 %[voK1], s[40:43], 0 offen lds
+  .elseif (\i) == 2
+    s_add_u32 m0, s58, \boff
+    s_add_u32 m0, m0, 10240
+    s_nop 0
+    buffer_load_dwordx4 %[voV0], s[44:47], 0 offen lds
+  .else
+    s_add_u32 m0, s59, \boff
+    s_add_u32 m0, m0, 10240
+    s_nop 0
+    buffer_load_dwordx4 %[voV1], s[44:47], 0 offen lds
+  .endif
+.endm
+.macro Q4_STAGE boff
+  Q4_DMA 0, \boff
+  Q4_DMA 1, \boff
+  Q4_DMA 2, \boff
+  Q4_DMA 3, \boff
+.endm
+; one iteration.  gV: generation whose block is exponentiated, gM: target of the S^T / dP^T MFMAs; rb1, hf1: base / tile half of the
+; block whose row fragments are read; tb2, hf2: of the block whose transposed fragments are read; dma: LDS-DMA of the tile three
+; ahead in slots 8-11; mask: keys at or past \lim + (8 a + e) are switched off (\lim: VGPR = Tk - first key of the block - 4 h)
+.macro Q4_ITER gV, gM, rb1, hf1, tb2, hf2, dma, mask, lim
+  .set q4_s, 0
+  .rept 24
+    .if q4_s < 4
+      s_waitcnt lgkmcnt(6-q4_s)
+    .elseif q4_s == 8
+      s_waitcnt lgkmcnt(4)
+    .elseif q4_s == 12
+      s_waitcnt lgkmcnt(0)
+    .endif
+    .if q4_s < 8
+      Q4_M2 q4_s
+    .else
+      Q4_M1 q4_s-8, \gM
+    .endif
+    .if q4_s < 16
+      .if \mask
+        v_cmp_gt_i32 vcc, \lim, 8*(q4_s/4)+(q4_s%%4)
+        v_cndmask_b32 v[\gV+q4_s], v31, v[\gV+q4_s], vcc
+      .endif
+      v_exp_f32 v[\gV+q4_s], v[\gV+q4_s]
+      v_mul_f32 v[\gV+32+q4_s], %[c], v[\gV+32+q4_s]
+      .if q4_s < 8
+        Q4_RD1 q4_s, \rb1, \hf1
+      .endif
+      .if q4_s >= 12
+        Q4_RD2 q4_s-12, \tb2, \hf2
+      .endif
+      .if \mask
+        v_cndmask_b32 v[\gV+32+q4_s], v31, v[\gV+32+q4_s], vcc
+      .endif
+      v_exp_f32 v[\gV+32+q4_s], v[\gV+32+q4_s]
+      .if q4_s >= 1
+        v_mul_f32 v[\gV+16+q4_s-1], v[\gV+q4_s-1], v[\gV+16+q4_s-1]
+      .endif
+      .if \dma && q4_s >= 8 && q4_s < 12
+        Q4_DMA q4_s-8, s65
+      .endif
+      .if \dma && q4_s == 12
+        Q4_ADVANCE
+      .endif
+    .else
+      .if q4_s == 16
+        v_mul_f32 v[\gV+16+15], v[\gV+15], v[\gV+16+15]
+      .endif
+      v_mul_f32 v[\gV+48+2*(q4_s-16)], v[\gV+32+2*(q4_s-16)], v[\gV+48+2*(q4_s-16)]
+      v_mul_f32 v[\gV+48+2*(q4_s-16)+1], v[\gV+32+2*(q4_s-16)+1], v[\gV+48+2*(q4_s-16)+1]
+      .if q4_s < 20
+        Q4_RD2 q4_s-12, \tb2, \hf2
+      .endif
+      v_cvt_pk_bf16_f32 v[32+(q4_s-16)], v[\gV+16+2*(q4_s-16)], v[\gV+16+2*(q4_s-16)+1]
+      v_mul_f32 v[\gM+2*(q4_s-16)], %[c], v[\gM+2*(q4_s-16)]
+      v_mul_f32 v[\gM+2*(q4_s-16)+1], %[c], v[\gM+2*(q4_s-16)+1]
+      v_cvt_pk_bf16_f32 v[40+(q4_s-16)], v[\gV+48+2*(q4_s-16)], v[\gV+48+2*(q4_s-16)+1]
+    .endif
+    .set q4_s, q4_s+1
+  .endr
+.endm
+; one 64-key tile: boundary + its two iterations (+ the buffer rotation)
+.macro Q4_PAIR mask
+    ; tile T+1 has landed for every wave (tile T+2's four pieces may still fly), tile T-1's buffer is free -> tile T+3 goes into it
+    s_waitcnt vmcnt(4)
+    s_barrier
+    Q4_ITER 128, 192, v24, 1, v25, 0, 1, \mask, v29
+    Q4_ITER 192, 128, v27, 0, v25, 1, 0, \mask, v30
+    s_mov_b32 s67, s63
+    s_mov_b32 s63, s64
+    s_mov_b32 s64, s52
+    s_mov_b32 s52, s65
+    s_mov_b32 s65, s67
+    v_add_u32 v24, s63, %[rb]
+    v_add_u32 v25, s63, %[tb]
+    v_add_u32 v27, s64, %[rb]
+.endm
+)ASM"
+#define Q4_ASM_PURGE R"ASM(
+.purgem Q4_M2
+.purgem Q4_M1
+.purgem Q4_RD1
+.purgem Q4_RD2
+.purgem Q4_ADVANCE
+.purgem Q4_DMA
+.purgem Q4_STAGE
+.purgem Q4_ITER
+.purgem Q4_PAIR
+)ASM"
+// a0..a159
+#define Q4_CLOBBER_A "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", D4_A8(1), D4_A8(2), D4_A8(3), D4_A8(4), D4_A8(5), D4_A8(6), D4_A8(7), D4_A8(8), D4_A8(9), D4_A8(10), D4_A8(11), D4_A8(12), D4_A8(13), D4_A8(14), D4_A8(15)
+
+__global__ __launch_bounds__(256) void attn_bwd_dq4w_kernel(AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  int bx, hd, b;
+  att_block_coords((p.Tq + 255) >> 8, p.H, p.B, p.xcd, bx, hd, b);
+  const int qw0 = bx * 256 + wave * 64;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+  // fragment read bases in a tile buffer (layout: see attn_bwd_dkdv4w_kernel)
+  const int c = r & 15, pidr = (c & 1) | ((c >> 2) << 1);
+  const unsigned rb = lds0 + pidr * D4_PIECE + 64 * (pidr & 1) + 16 * (pidr >> 1) + (2 * (r >> 4) + ((c >> 1) & 1)) * 128 + h * 16;
+  const int g4 = lane >> 4, i16 = lane & 15, pidt = ((i16 >> 2) & 1) | ((g4 >> 1) << 1);
+  const unsigned tb = lds0 + pidt * D4_PIECE + 64 * (pidt & 1) + 16 * (pidt >> 1) + ((i16 >> 3) & 1) * 128 + 32 * (g4 & 1) + 8 * (i16 & 3);
+  // LDS-DMA share of this wave: pieces 2 wave and 2 wave + 1 of K and of V
+  const int slot = lane >> 3, ch = lane & 7;
+  auto krow = [&](int pid) { return (pid & 1) + 4 * (pid >> 1) + 2 * (slot & 1) + 16 * (slot >> 1); };
+  const unsigned voK0 = (unsigned)(krow(2 * wave) * (int)p.ldk + ch * 8) * 2u, voK1 = (unsigned)(krow(2 * wave + 1) * (int)p.ldk + ch * 8) * 2u;
+  const unsigned voV0 = (unsigned)(krow(2 * wave) * (int)p.ldv + ch * 8) * 2u, voV1 = (unsigned)(krow(2 * wave + 1) * (int)p.ldv + ch * 8) * 2u;
+  auto sg64 = [](unsigned long long x) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)x), hi = __builtin_amdgcn_readfirstlane((unsigned)(x >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+  };
+  const unsigned long long bQ = sg64((unsigned long long)(p.q + (long)b * p.q_bs + hd * 64));
+  const unsigned long long bD = sg64((unsigned long long)(p.d_o + (long)b * p.do_bs + hd * 64));
+  const unsigned long long bK = sg64((unsigned long long)(p.k + (long)b * p.k_bs + hd * 64));
+  const unsigned long long bV = sg64((unsigned long long)(p.v + (long)b * p.v_bs + hd * 64));
+  // row constants of this lane's two queries (query blocks 0 / 1 of the wave), negated; written for the dK/dV kernel
+  float nl[2], nd[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int qi = qw0 + 32 * qb + r;
+    const int qc = qi < p.Tq ? qi : p.Tq - 1;
+    const long sidx = ((long)b * p.H + hd) * p.Tq + qc;
+    nl[qb] = -p.lse[sidx] / p.scale;
+    const unsigned short* orow = p.o + (long)b * p.o_bs + (long)qc * p.ldo + hd * 64;
+    const unsigned short* dorow = p.d_o + (long)b * p.do_bs + (long)qc * p.lddo + hd * 64;
+    float part = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bf16x8 of = att_load_reg_frag(orow, s, h), df = att_load_reg_frag(dorow, s, h);
+      const u32x4 ou = __builtin_bit_cast(u32x4, of), du = __builtin_bit_cast(u32x4, df);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        part += bf2f((unsigned short)(ou[e] & 0xffff)) * bf2f((unsigned short)(du[e] & 0xffff));
+        part += bf2f((unsigned short)(ou[e] >> 16)) * bf2f((unsigned short)(du[e] >> 16));
+      }
+    }
+    nd[qb] = -(part + __shfl_xor(part, 32, 64));
+    if (h == 0 && qi < p.Tq) {
+      p.delta[sidx] = nd[qb];
+      p.delta[(long)p.B * p.H * p.Tq + sidx] = nl[qb];
+    }
+  }
+  // Q / dO row fragments of the lane's queries: byte offsets relative to the (batch, head) bases (rows past Tq load zeros)
+  const unsigned voQ = (unsigned)((qw0 + r) * (int)p.ldq + 8 * h) * 2u, voD = (unsigned)((qw0 + r) * (int)p.lddo + 8 * h) * 2u;
+  const unsigned tq = __builtin_amdgcn_readfirstlane((unsigned)p.Tq), tk = __builtin_amdgcn_readfirstlane((unsigned)p.Tk);
+  const unsigned ldq2 = __builtin_amdgcn_readfirstlane((unsigned)p.ldq * 2u), ldd2 = __builtin_amdgcn_readfirstlane((unsigned)p.lddo * 2u);
+  const unsigned stK = __builtin_amdgcn_readfirstlane((unsigned)p.ldk * 128u), stV = __builtin_amdgcn_readfirstlane((unsigned)p.ldv * 128u);
+  const unsigned npair = __builtin_amdgcn_readfirstlane((unsigned)((p.Tk + 63) >> 6));  // 64-key tiles
+  const int lim0 = p.Tk - 64 * ((p.Tk + 63) / 64 - 1) - 4 * h;  // keys left from the first key of the LAST tile, minus 4 h
+  const float cscale = p.scale * LOG2E;
+  const unsigned cbits = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, cscale));
+  const unsigned wv = (unsigned)wave;
+
+  asm volatile(Q4_ASM_MACROS R"ASM(
+    ; ---- descriptors: K s[40:43], V s[44:47] (tile strides s56, s57), Q s[68:71], dO s[72:75]
+    s_mov_b64 s[40:41], %[bK]
+    s_lshr_b32 s61, %[stK], 6
+    s_sub_u32 s62, %[tk], 1
+    s_mul_i32 s42, s62, s61
+    s_add_u32 s42, s42, 128
+    s_mov_b32 s43, 0x20000
+    s_mov_b64 s[44:45], %[bV]
+    s_lshr_b32 s61, %[stV], 6
+    s_mul_i32 s46, s62, s61
+    s_add_u32 s46, s46, 128
+    s_mov_b32 s47, 0x20000
+    s_mov_b32 s56, %[stK]
+    s_mov_b32 s57, %[stV]
+    s_mov_b64 s[68:69], %[bQ]
+    s_sub_u32 s62, %[tq], 1
+    s_mul_i32 s70, s62, %[ldq2]
+    s_add_u32 s70, s70, 128
+    s_mov_b32 s71, 0x20000
+    s_mov_b64 s[72:73], %[bD]
+    s_mul_i32 s74, s62, %[ldd2]
+    s_add_u32 s74, s74, 128
+    s_mov_b32 s75, 0x20000
+    ; Q / dO row fragments of the two query blocks -> a[64:127]
+    s_lshl_b32 s61, %[ldq2], 5
+    v_add_u32 v29, s61, %[voQ]
+    s_lshl_b32 s61, %[ldd2], 5
+    v_add_u32 v30, s61, %[voD]
+    .set q4_i, 0
+    .rept 4
+      buffer_load_dwordx4 a[64+4*q4_i:64+4*q4_i+3], %[voQ], s[68:71], 0 offen offset:32*q4_i
+      buffer_load_dwordx4 a[80+4*q4_i:80+4*q4_i+3], %[voD], s[72:75], 0 offen offset:32*q4_i
+      buffer_load_dwordx4 a[96+4*q4_i:96+4*q4_i+3], v29, s[68:71], 0 offen offset:32*q4_i
+      buffer_load_dwordx4 a[112+4*q4_i:112+4*q4_i+3], v30, s[72:75], 0 offen offset:32*q4_i
+      .set q4_i, q4_i+1
+    .endr
+    ; LDS-DMA destinations inside a buffer: piece 2 wave (s58), 2 wave + 1 (s59)
+    s_lshl_b32 s61, %[wave], 1
+    s_mul_i32 s58, s61, 1280
+    s_lshr_b32 s62, s61, 1
+    s_lshl_b32 s62, s62, 4
+    s_add_u32 s58, s58, s62
+    s_add_u32 s58, s58, %[lds0]
+    s_add_u32 s59, s58, 1344
+    ; buffer offsets: cur (tile T) s63, nxt (T+1) s64, after next (T+2) s52, ld (T+3) s65; loop counter s66
+    s_mov_b32 s63, 0
+    s_mov_b32 s64, )ASM" D4_STR(Q4_BUF) R"ASM(
+    s_mov_b32 s52, 2*)ASM" D4_STR(Q4_BUF) R"ASM(
+    s_mov_b32 s65, 3*)ASM" D4_STR(Q4_BUF) R"ASM(
+    s_sub_u32 s66, %[npair], 1
+    ; ---- tiles 0, 1, 2
+    Q4_STAGE s63
+    Q4_ADVANCE
+    s_nop 4
+    Q4_STAGE s64
+    Q4_ADVANCE
+    s_nop 4
+    Q4_STAGE s52
+    Q4_ADVANCE
+    ; ---- (under the loads) accumulators, packed dS and transposed fragments start from zero; the row constants spread out
+    .set q4_i, 0
+    .rept 64
+      v_accvgpr_write_b32 a[q4_i], 0
+      .set q4_i, q4_i+1
+    .endr
+    .set q4_i, 32
+    .rept 32
+      v_mov_b32 v[q4_i], 0
+      .set q4_i, q4_i+1
+    .endr
+    .set q4_i, 0
+    .rept 16
+      v_mov_b32 v[64+q4_i], %[nd0]
+      v_mov_b32 v[80+q4_i], %[nd1]
+      v_mov_b32 v[96+q4_i], %[nl0]
+      v_mov_b32 v[112+q4_i], %[nl1]
+      .set q4_i, q4_i+1
+    .endr
+    v_mov_b32 v31, 0xf149f2ca      ; -1e30
+    v_mov_b32 v29, %[lim0]
+    v_add_u32 v30, -32, v29
+    v_mov_b32 v24, %[rb]
+    v_mov_b32 v25, %[tb]
+    v_add_u32 v27, s64, v24
+    s_waitcnt vmcnt(8)             ; Q / dO fragments and tile 0 (tiles 1, 2: four pieces each may still be in flight)
+    s_barrier
+    ; ---- block 0: row fragments, S^T / dP^T -> generation 128
+    .set q4_i, 0
+    .rept 8
+      Q4_RD1 q4_i, v24, 0
+      .set q4_i, q4_i+1
+    .endr
+    s_waitcnt lgkmcnt(0)
+    .set q4_i, 0
+    .rept 16
+      Q4_M1 q4_i, 128
+      .set q4_i, q4_i+1
+    .endr
+    s_nop 15
+    s_nop 15
+    .set q4_i, 0
+    .rept 16
+      v_mul_f32 v[128+q4_i], %[c], v[128+q4_i]
+      .set q4_i, q4_i+1
+    .endr
+    s_cmp_eq_u32 s66, 0
+    s_cbranch_scc1 5f
+1:
+    Q4_PAIR 0
+    s_sub_u32 s66, s66, 1
+    s_cmp_eq_u32 s66, 0
+    s_cbranch_scc0 1b
+5:
+    ; ---- the last tile: keys past Tk are switched off element by element
+    Q4_PAIR 1
+    ; ---- dQ of the last block
+    s_waitcnt lgkmcnt(0)
+    s_nop 1
+    .set q4_i, 0
+    .rept 8
+      Q4_M2 q4_i
+      .set q4_i, q4_i+1
+    .endr
+    s_waitcnt vmcnt(0)
+    s_nop 15
+  )ASM" Q4_ASM_PURGE
+               :
+               : [rb] "v"(rb), [tb] "v"(tb), [voK0] "v"(voK0), [voK1] "v"(voK1), [voV0] "v"(voV0), [voV1] "v"(voV1), [voQ] "v"(voQ),
+                 [voD] "v"(voD), [nl0] "v"(nl[0]), [nl1] "v"(nl[1]), [nd0] "v"(nd[0]), [nd1] "v"(nd[1]), [lim0] "v"(lim0), [bK] "s"(bK),
+                 [bV] "s"(bV), [bQ] "s"(bQ), [bD] "s"(bD), [tq] "s"(tq), [tk] "s"(tk), [ldq2] "s"(ldq2), [ldd2] "s"(ldd2), [stK] "s"(stK),
+                 [stV] "s"(stV), [npair] "s"(npair), [c] "s"(cbits), [lds0] "s"(lds0), [wave] "s"(wv)
+               : "memory", "vcc", "scc", Q4_CLOBBER_A, D4_CLOBBER_V, "v30", "v31", D4_CLOBBER_S);
+
+  // ---- epilogue: lane (r, h) holds dQ [query qw0 + 32 qb + r][d = 32 db + 8 a + 4 h + e] in register 4 a + e of (qb, db)
+  auto row16 = [&](const f32x16& acc, int m, float mul) {
+    const unsigned x0 = pack2bf(acc[8 * m] * mul, acc[8 * m + 1] * mul), x1 = pack2bf(acc[8 * m + 2] * mul, acc[8 * m + 3] * mul);
+    const unsigned y0 = pack2bf(acc[8 * m + 4] * mul, acc[8 * m + 5] * mul), y1 = pack2bf(acc[8 * m + 6] * mul, acc[8 * m + 7] * mul);
+    const auto s0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false), s1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+    u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+    return o;
+  };
+  auto store = [&](auto qbc) {
+    constexpr int qb = decltype(qbc)::value;
+    const int qb0 = qw0 + 32 * qb, qi = qb0 + r;
+    f32x16 dq[2];
+    dq[0] = d4_get16<32 * qb>(); dq[1] = d4_get16<32 * qb + 16>();
+    unsigned short* drow = p.dq + (long)b * p.dq_bs + (long)qi * p.lddq + hd * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const u32x4 pk = row16(dq[db], m, p.scale);  // (every lane takes part in the swaps)
+        if (qi < p.Tq) *(u32x4*)(drow + 32 * db + 8 * (2 * m + h)) = pk;
+      }
+    if (p.cs_q && qb0 < p.Tq) {  // q-projection bias gradient: column sums of the bf16 values written (halving butterfly, see dK/dV)
+      float cv[32];
+      const bool ok = qi < p.Tq;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) cv[i] = ok ? bf2f(f2bf(dq[i >> 4][i & 15] * p.scale)) : 0.f;
+#pragma unroll
+      for (int m = 16; m >= 1; m >>= 1) {
+        const bool up = (r & m) != 0;
+#pragma unroll
+        for (int i = 0; i < m; ++i) {
+          const float keep = up ? cv[i + m] : cv[i], send = up ? cv[i] : cv[i + m];
+          cv[i] = keep + __shfl_xor(send, m, 64);
+        }
+      }
+      float* dst = p.cs_q + ((long)b * ((p.Tq + 31) >> 5) + (qb0 >> 5)) * (p.H * 64) + hd * 64;
+      dst[32 * (r >> 4) + 8 * ((r >> 2) & 3) + 4 * h + (r & 3)] = cv[0];
+    }
+  };
+  store(IntC<0>{});
+  store(IntC<1>{});
+}
+
+
 #define ATT_ALIGNED(ptr, ld, bs) ((((uintptr_t)(ptr)) & 15) == 0 && ((ld) % 8) == 0 && ((bs) % 8) == 0)
 
 extern "C" int wft_attn_fwd_bf16(const wft_attn_args* a, void* stream) {
@@ -1486,6 +1903,21 @@ extern "C" int wft_attn_set_dkdv_variant(int v) {
   if (v >= 0) g_dkdv_variant = v ? 1 : 0;
   return old;
 }
+// the same for the dQ kernel (attn_bwd_dq4w_kernel): WFT_DQ_VARIANT=8w|4w
+static int g_dq_variant = [] { const char* e = getenv("WFT_DQ_VARIANT"); return (e && !strcmp(e, "8w")) ? 1 : 0; }();
+extern "C" int wft_attn_set_dq_variant(int v) {
+  const int old = g_dq_variant;
+  if (v >= 0) g_dq_variant = v ? 1 : 0;
+  return old;
+}
+// non-causal calls with enough queries to fill 256-query workgroups; byte offsets must fit the asm block's 32-bit buffer addressing
+static bool wft_dq4w_eligible(const wft_attn_args* a) {
+  static const int min_tq = [] { const char* e = getenv("WFT_DQ4W_MIN_TQ"); return e ? atoi(e) : 512; }();
+  if (g_dq_variant != 0 || a->causal || a->Tq < min_tq) return false;
+  const long lim = 0x7fffffffL;
+  return (long)(a->Tq + 256) * a->ldq * 2 < lim && (long)(a->Tq + 256) * a->lddo * 2 < lim && (long)(a->Tk + 256) * a->ldk * 2 < lim &&
+         (long)(a->Tk + 256) * a->ldv * 2 < lim;
+}
 // non-causal sweeps over at least two 64-query tiles whose byte offsets fit the 32-bit buffer addressing of the asm block
 static bool wft_dkdv4w_eligible(const wft_attn_args* a) {
   if (g_dkdv_variant != 0 || a->causal || a->Tq < 128) return false;
@@ -1513,7 +1945,22 @@ extern "C" int wft_attn_bwd_bf16(const wft_attn_args* a, void* stream) {
     p.cs_v = a->colsum_ws + (long)a->B * ((a->Tq + 31) / 32) * a->H * 64;
   }
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(((a->Tq + 127) / 128) * a->H * a->B)), dim3(256), 0, s, p);
+  if (wft_dq4w_eligible(a)) {
+    static bool ldsq_set[64] = {false};
+    int devq = 0;
+    if (hipGetDevice(&devq) != hipSuccess || devq < 0 || devq >= 64) devq = 0;
+    if (!ldsq_set[devq]) {
+      const hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dq4w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Q4_LDS);
+      if (e != hipSuccess) {
+        wft_set_error("wft_attn_bwd_bf16: the dQ kernel needs %d bytes of dynamic LDS, hipFuncSetAttribute: %s", Q4_LDS, hipGetErrorString(e));
+        return WFT_ERR_LAUNCH;
+      }
+      ldsq_set[devq] = true;
+    }
+    hipLaunchKernelGGL(attn_bwd_dq4w_kernel, dim3((unsigned)(((a->Tq + 255) / 256) * a->H * a->B)), dim3(256), Q4_LDS, s, p);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(((a->Tq + 127) / 128) * a->H * a->B)), dim3(256), 0, s, p);
+  }
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   {
