@@ -829,7 +829,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
 // mul = 24).  Q / dO fragments and constants are shared by the wave's two key blocks (half the LDS traffic per MFMA).
 // Queries beyond Tq need no masks: their Q / dO rows and constants arrive as ZEROS (buffer descriptors that end at row Tq), so
 // they add exp2(0) * 0 = 0 to dV and 0 * finite = 0 to dK; keys beyond Tk are lanes whose results are not stored.
-// LDS: four buffers of one 64-query tile {Q, dO: 8 pieces of 8 rows, 1 280 B apart, piece pid at pid * 1280 + 64 (pid & 1) +
+// LDS: three buffers of one 64-query tile {Q, dO: 8 pieces of 8 rows, 1 280 B apart, piece pid at pid * 1280 + 64 (pid & 1) +
 // 16 (pid >> 1); -lse/scale, -delta: 256 B each}.  Piece pid holds queries q0 + {0, 2} + 16 m, q0 = (pid & 1) + 4 (pid >> 1): row q sits
 // at 64 (q & 3) + 16 ((q >> 2) & 3) modulo 256 B, which makes BOTH the 32-row ds_read_b128 operand reads and the 4-row
 // ds_read_b64_tr_b16 reads bank-conflict-free with every fragment address = one base register + an immediate.
@@ -838,7 +838,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
 #define D4_LSE 20480
 #define D4_DLT 20736
 #define D4_BUF 20992
-#define D4_LDS (4 * D4_BUF)
+#define D4_KV 20480                      // one wave's K and V fragments in transit: two tiles of 10 240 B
+#define D4_LDS (3 * D4_BUF + 4 * D4_KV)
 #define D4_STR2(x) #x
 #define D4_STR(x) D4_STR2(x)
 
@@ -962,7 +963,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
 .endm
 ; one iteration.  gV: generation (128 / 192) whose block is exponentiated here, gM: the other (target of the S / dP MFMAs);
 ; rb1, cb1, qb1: bases / half of the block whose row fragments are read; tb2, qb2: of the block whose transposed fragments are read;
-; dma = 1: this wave's LDS-DMA share of the tile three ahead goes out in slots 16-20 (buffer offset s65), sources advance in slot 21.
+; dma = 1: this wave's LDS-DMA share of the tile two ahead goes out in slots 16-20 (buffer offset s65), sources advance in slot 21.
 ; A wave alone on its SIMD issues in order and an MFMA gap hides about 24 issue cycles (measured here: two junk v_mov per gap cost
 ; 1.4 cycles each, the third and fourth 3.4): every slot carries 20 cycles of vector work and ONE LDS read —
 ;   slots  0-15  c-multiply of key block 1, both exponentials; row read number slot
@@ -1070,7 +1071,7 @@ extern "C" void wft_dbg_read(unsigned long long* host, int reset) {
 #define D4_ASM_MACROS2 R"ASM(
 ; descriptors: Q s[40:43], dO s[44:47], this wave's constants (-lse/scale or -delta) s[48:51], K s[68:71], V s[72:75];
 ; tile strides s56, s57; LDS-DMA destinations inside a buffer: piece 2 wave (s58), 2 wave + 1 (s59), this wave's constant row (s60:
-; even waves lse, odd delta); buffer offsets: cur (tile T) s63, nxt (T+1) s64, after next (T+2) s52, ld (T+3) s65
+; even waves lse, odd delta); buffer offsets: cur (tile T) s63, nxt (T+1) s64, ld (T+2) s65; this wave's K / V transit area s52
 .macro D4_SRD_INIT
   s_mov_b64 s[40:41], %[bQ]
   s_lshr_b32 s61, %[stQ], 6
@@ -1112,36 +1113,54 @@ extern "C" void wft_dbg_read(unsigned long long* host, int reset) {
   s_add_u32 s60, s60, %[lds0]
   s_mov_b32 s63, 0
   s_mov_b32 s64, )ASM" D4_STR(D4_BUF) R"ASM(
-  s_mov_b32 s52, 2*)ASM" D4_STR(D4_BUF) R"ASM(
-  s_mov_b32 s65, 3*)ASM" D4_STR(D4_BUF) R"ASM(
+  s_mov_b32 s65, 2*)ASM" D4_STR(D4_BUF) R"ASM(
+  s_mul_i32 s52, %[wave], )ASM" D4_STR(D4_KV) R"ASM(
+  s_add_u32 s52, s52, 3*)ASM" D4_STR(D4_BUF) R"ASM(
+  s_add_u32 s52, s52, %[lds0]
 .endm
-; K / V row fragments of this wave's two 32-key blocks -> a[128:191] (rows past Tk lie beyond the descriptors: zeros)
-.macro D4_KV
+; K / V rows of this wave's 64 keys -> its transit area, as two tiles in the piece layout of the Q / dO tiles (8 + 8 LDS-DMA pieces of
+; eight whole 128-byte rows: the row-per-lane fragment loads they replace touched every line four times and cost ~400 cycles of
+; issue each).  Piece pid holds keys q0 + {0, 2} + 16 m, q0 = (pid & 1) + 4 (pid >> 1); rows past Tk lie beyond the descriptors: zeros.
+.macro D4_KVDMA
   .set d4_i, 0
-  .rept 4
-    buffer_load_dwordx4 a[128+4*d4_i:128+4*d4_i+3], %[voK0], s[68:71], 0 offen offset:32*d4_i
-    buffer_load_dwordx4 a[144+4*d4_i:144+4*d4_i+3], %[voV0], s[72:75], 0 offen offset:32*d4_i
-    buffer_load_dwordx4 a[160+4*d4_i:160+4*d4_i+3], %[voK1], s[68:71], 0 offen offset:32*d4_i
-    buffer_load_dwordx4 a[176+4*d4_i:176+4*d4_i+3], %[voV1], s[72:75], 0 offen offset:32*d4_i
+  .rept 8
+    s_mul_i32 s61, %[ldk2], (d4_i%%2)+4*(d4_i/2)
+    v_add_u32 v29, s61, %[voKp]
+    s_add_u32 m0, s52, d4_i*1280+64*(d4_i%%2)+16*(d4_i/2)
+    s_mul_i32 s62, %[ldv2], (d4_i%%2)+4*(d4_i/2)
+    buffer_load_dwordx4 v29, s[68:71], 0 offen lds
+    v_add_u32 v30, s62, %[voVp]
+    s_add_u32 m0, s52, 10240+d4_i*1280+64*(d4_i%%2)+16*(d4_i/2)
+    s_nop 0
+    buffer_load_dwordx4 v30, s[72:75], 0 offen lds
     .set d4_i, d4_i+1
   .endr
 .endm
-; first three tiles of a key block -> buffers 0, 1, 2 (sources end up three tiles on)
-.macro D4_STAGE3
+; ... and from there into a[128:191] as row fragments (lane (r, h): key 32 kb + r, columns 16 s + 8 h .. + 8)
+.macro D4_KVRD
+  s_sub_u32 s61, s52, %[lds0]
+  v_add_u32 v29, s61, %[rb]
+  .set d4_i, 0
+  .rept 8
+    ds_read_b128 a[128+32*(d4_i/4)+4*(d4_i%%4):128+32*(d4_i/4)+4*(d4_i%%4)+3], v29 offset:512*(d4_i/4)+32*(d4_i%%4)
+    ds_read_b128 a[144+32*(d4_i/4)+4*(d4_i%%4):144+32*(d4_i/4)+4*(d4_i%%4)+3], v29 offset:10240+512*(d4_i/4)+32*(d4_i%%4)
+    .set d4_i, d4_i+1
+  .endr
+.endm
+; first two tiles of an item -> buffers 0, 1 (sources end up two tiles on)
+.macro D4_STAGE2
   D4_STAGE s63
   D4_ADVANCE
   s_nop 4
   D4_STAGE s64
   D4_ADVANCE
-  s_nop 4
-  D4_STAGE s52
-  D4_ADVANCE
 .endm
 )ASM"
 #define D4_ASM_PURGE2 R"ASM(
 .purgem D4_SRD_INIT
-.purgem D4_KV
-.purgem D4_STAGE3
+.purgem D4_KVDMA
+.purgem D4_KVRD
+.purgem D4_STAGE2
 )ASM"
 
 __global__ __launch_bounds__(256) void attn_bwd_dkdv4w_kernel(AttnP p) {
@@ -1192,7 +1211,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv4w_kernel(AttnP p) {
   struct Item {
     int b, hd, kw0;
     unsigned long long bQ, bD, bL, bT, bK, bV;
-    unsigned voK0, voK1, voV0, voV1;
+    unsigned voKp, voVp;
   };
   auto item = [&](int t) {
     Item x;
@@ -1207,9 +1226,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv4w_kernel(AttnP p) {
     x.bT = sg64((unsigned long long)(p.delta + sbase));                            // -delta
     x.bK = sg64((unsigned long long)(p.k + (long)x.b * p.k_bs + x.hd * 64));
     x.bV = sg64((unsigned long long)(p.v + (long)x.b * p.v_bs + x.hd * 64));
-    // byte offsets of this lane's K / V rows (key blocks 0 / 1 of the wave) relative to the (batch, head) bases
-    x.voK0 = (unsigned)((x.kw0 + r) * (int)p.ldk + 8 * h) * 2u; x.voK1 = x.voK0 + 32u * ldk2;
-    x.voV0 = (unsigned)((x.kw0 + r) * (int)p.ldv + 8 * h) * 2u; x.voV1 = x.voV0 + 32u * ldv2;
+    // byte offset of this lane's share of K / V piece 0 of the wave's 64 keys (slot lane >> 3: key 2 (slot & 1) + 16 (slot >> 1),
+    // chunk lane & 7), relative to the (batch, head) bases
+    x.voKp = (unsigned)((x.kw0 + 2 * (slot & 1) + 16 * (slot >> 1)) * (int)p.ldk + ch * 8) * 2u;
+    x.voVp = (unsigned)((x.kw0 + 2 * (slot & 1) + 16 * (slot >> 1)) * (int)p.ldv + ch * 8) * 2u;
     return x;
   };
 
@@ -1223,13 +1243,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv4w_kernel(AttnP p) {
     s_mov_b32 s66, %[npair]      ; loop counter
     s_cmp_eq_u32 %[first], 0
     s_cbranch_scc1 2f
-    ; ---- first item of this workgroup: its K / V fragments and tiles 0, 1, 2 are requested here ...
-    D4_KV
-    D4_STAGE3
+    ; ---- first item of this workgroup: its K / V rows and tiles 0, 1 are requested here ...
+    D4_KVDMA
+    D4_STAGE2
     s_branch 3f
 2:
     ; ---- ... later ones found them requested by the prefetch block behind the previous item (below): only the descriptors move on
-    D4_ADVANCE
     D4_ADVANCE
     D4_ADVANCE
     s_waitcnt vmcnt(0)
@@ -1251,8 +1270,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv4w_kernel(AttnP p) {
     v_mov_b32 v26, %[cb]
     v_add_u32 v27, s64, v24
     v_add_u32 v28, s64, v26
-    s_waitcnt vmcnt(10)        ; K / V fragments and tile 0 (tiles 1, 2: five pieces each may still be in flight)
+    s_waitcnt vmcnt(5)         ; K / V rows and tile 0 (tile 1: five pieces may still be in flight)
     s_barrier
+    D4_KVRD
     )ASM" D4_STAMP_ASM(76) R"ASM(
     ; ---- block 0: row fragments + constants, S / dP -> generation 128
     .set d4_i, 0
@@ -1274,21 +1294,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv4w_kernel(AttnP p) {
       .set d4_i, d4_i+1
     .endr
 1:
-    ; ==== tile boundary: tile T+1 has landed for every wave (tile T+2's five pieces may still fly), tile T-1's buffer is free ->
-    ; tile T+3 goes into it during this iteration (three tiles = four to six iterations of memory latency covered)
+    ; ==== tile boundary: tile T+1 has landed for every wave, tile T-1's buffer is free -> tile T+2 goes into it during this
+    ; iteration (a fourth buffer and three tiles of distance measured the same; the space carries the K / V transit areas)
     .if d4_exp != 4
-    s_waitcnt vmcnt(5)
+    s_waitcnt vmcnt(0)
     s_barrier
     .endif
     ; even iteration (block 2T): row fragments of block 2T+1 (this tile, half 1), transposed fragments of block 2T (half 0)
     D4_ITER 128, 192, v24, v26, 1, v25, 0, 1
     ; odd iteration (block 2T+1): row fragments of block 2T+2 (next tile, half 0), transposed fragments of block 2T+1
     D4_ITER 192, 128, v27, v28, 0, v25, 1, 0
-    ; rotate the buffers: cur <- nxt <- after next <- ld <- cur
+    ; rotate the buffers: cur <- nxt <- ld <- cur
     s_mov_b32 s67, s63
     s_mov_b32 s63, s64
-    s_mov_b32 s64, s52
-    s_mov_b32 s52, s65
+    s_mov_b32 s64, s65
     s_mov_b32 s65, s67
     v_add_u32 v24, s63, %[rb]
     v_add_u32 v25, s63, %[tb]
@@ -1312,7 +1331,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv4w_kernel(AttnP p) {
   )ASM" D4_ASM_PURGE D4_ASM_PURGE2
                :
                : [rb] "v"(rb), [tb] "v"(tb), [cb] "v"(cb), [voQ0] "v"(voQ0), [voQ1] "v"(voQ1), [voD0] "v"(voD0), [voD1] "v"(voD1),
-                 [voC] "v"(voC), [voK0] "v"(cur.voK0), [voK1] "v"(cur.voK1), [voV0] "v"(cur.voV0), [voV1] "v"(cur.voV1), [bK] "s"(cur.bK),
+                 [voC] "v"(voC), [voKp] "v"(cur.voKp), [voVp] "v"(cur.voVp), [bK] "s"(cur.bK),
                  [bV] "s"(cur.bV), [bQ] "s"(cur.bQ), [bD] "s"(cur.bD), [bL] "s"(cur.bL), [bT] "s"(cur.bT), [tq] "s"(tq), [tk] "s"(tk),
                  [ldk2] "s"(ldk2), [ldv2] "s"(ldv2), [first] "s"(first), [stQ] "s"(stQ), [stD] "s"(stD), [npair] "s"(npair), [c] "s"(cbits),
                  [lds0] "s"(lds0), [wave] "s"(wv)
@@ -1322,18 +1341,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv4w_kernel(AttnP p) {
   const unsigned long long st3 = __builtin_amdgcn_s_memtime();
 #endif
   if (t + wstep < nitems) {
-    // ---- prefetch block: once every wave has left the LDS buffers, request the NEXT item's K / V fragments (a[128:191]) and
-    // first three tiles; they fly while the accumulators of this item are scaled, summed and stored below
+    // ---- prefetch block: once every wave has left the LDS buffers, request the NEXT item's K / V rows (transit area) and
+    // first two tiles; they fly while the accumulators of this item are scaled, summed and stored below
     const Item nx = item(t + wstep);
     asm volatile(D4_ASM_MACROS D4_ASM_MACROS2 R"ASM(
       s_barrier
       D4_SRD_INIT
-      D4_KV
-      D4_STAGE3
+      D4_KVDMA
+      D4_STAGE2
     )ASM" D4_ASM_PURGE D4_ASM_PURGE2
                  :
-                 : [voQ0] "v"(voQ0), [voQ1] "v"(voQ1), [voD0] "v"(voD0), [voD1] "v"(voD1), [voC] "v"(voC), [voK0] "v"(nx.voK0),
-                   [voK1] "v"(nx.voK1), [voV0] "v"(nx.voV0), [voV1] "v"(nx.voV1), [bK] "s"(nx.bK), [bV] "s"(nx.bV), [bQ] "s"(nx.bQ),
+                 : [voQ0] "v"(voQ0), [voQ1] "v"(voQ1), [voD0] "v"(voD0), [voD1] "v"(voD1), [voC] "v"(voC), [voKp] "v"(nx.voKp), [voVp] "v"(nx.voVp), [rb] "v"(rb), [bK] "s"(nx.bK), [bV] "s"(nx.bV), [bQ] "s"(nx.bQ),
                    [bD] "s"(nx.bD), [bL] "s"(nx.bL), [bT] "s"(nx.bT), [tq] "s"(tq), [tk] "s"(tk), [ldk2] "s"(ldk2), [ldv2] "s"(ldv2),
                    [stQ] "s"(stQ), [stD] "s"(stD), [lds0] "s"(lds0), [wave] "s"(wv), [c] "s"(cbits)
                  : "memory", "scc", D4_CLOBBER_S, D4_A8(13), D4_A8(14), D4_A8(15), D4_A8(16), D4_A8(17), D4_A8(18), "a128", "a129", "a190", "a191");
