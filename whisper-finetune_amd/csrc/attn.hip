@@ -1466,7 +1466,7 @@ static int attn_fill(const wft_attn_args* a, AttnP& p) {
 // The kernel also writes the row constants -delta = -rowsum(dO * O) and -lse / scale for the dK/dV kernel (same expression, same
 // order as attn_bwd_dq_kernel).
 #define Q4_BUF 20480
-#define Q4_LDS (4 * Q4_BUF)
+#define Q4_LDS (3 * Q4_BUF + 4 * D4_KV)  // three {K, V} tile buffers + one Q / dO transit area per wave
 #define Q4_ASM_MACROS R"ASM(
 ; registers: S(g,qb) v[g+32qb..+15], dP(g,qb) v[g+16+32qb..+15], g = 128 / 192; DSF(qb) v[32+8qb..+7]; TK(ks,db) v[48+8ks+4db..+3];
 ; -delta of the lane's query, 16 copies: v[64+16qb..]; -lse/scale: v[96+16qb..]; dQ^T(qb,db) a[32qb+16db..+15];
@@ -1534,7 +1534,7 @@ static int attn_fill(const wft_attn_args* a, AttnP& p) {
   Q4_DMA 3, \boff
 .endm
 ; one iteration.  gV: generation whose block is exponentiated, gM: target of the S^T / dP^T MFMAs; rb1, hf1: base / tile half of the
-; block whose row fragments are read; tb2, hf2: of the block whose transposed fragments are read; dma: LDS-DMA of the tile three
+; block whose row fragments are read; tb2, hf2: of the block whose transposed fragments are read; dma: LDS-DMA of the tile two
 ; ahead in slots 8-11; mask: keys at or past \lim + (8 a + e) are switched off (\lim: VGPR = Tk - first key of the block - 4 h)
 .macro Q4_ITER gV, gM, rb1, hf1, tb2, hf2, dma, mask, lim
   .set q4_s, 0
@@ -1596,15 +1596,14 @@ static int attn_fill(const wft_attn_args* a, AttnP& p) {
 .endm
 ; one 64-key tile: boundary + its two iterations (+ the buffer rotation)
 .macro Q4_PAIR mask
-    ; tile T+1 has landed for every wave (tile T+2's four pieces may still fly), tile T-1's buffer is free -> tile T+3 goes into it
-    s_waitcnt vmcnt(4)
+    ; tile T+1 has landed for every wave, tile T-1's buffer is free -> tile T+2 goes into it
+    s_waitcnt vmcnt(0)
     s_barrier
     Q4_ITER 128, 192, v24, 1, v25, 0, 1, \mask, v29
     Q4_ITER 192, 128, v27, 0, v25, 1, 0, \mask, v30
     s_mov_b32 s67, s63
     s_mov_b32 s63, s64
-    s_mov_b32 s64, s52
-    s_mov_b32 s52, s65
+    s_mov_b32 s64, s65
     s_mov_b32 s65, s67
     v_add_u32 v24, s63, %[rb]
     v_add_u32 v25, s63, %[tb]
@@ -1679,8 +1678,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq4w_kernel(AttnP p) {
       p.delta[(long)p.B * p.H * p.Tq + sidx] = nl[qb];
     }
   }
-  // Q / dO row fragments of the lane's queries: byte offsets relative to the (batch, head) bases (rows past Tq load zeros)
-  const unsigned voQ = (unsigned)((qw0 + r) * (int)p.ldq + 8 * h) * 2u, voD = (unsigned)((qw0 + r) * (int)p.lddo + 8 * h) * 2u;
+  // this lane's share of Q / dO piece 0 of the wave's 64 queries (slot: query 2 (slot & 1) + 16 (slot >> 1), chunk lane & 7): byte
+  // offsets relative to the (batch, head) bases (rows past Tq load zeros)
+  const unsigned voQ = (unsigned)((qw0 + 2 * (slot & 1) + 16 * (slot >> 1)) * (int)p.ldq + ch * 8) * 2u;
+  const unsigned voD = (unsigned)((qw0 + 2 * (slot & 1) + 16 * (slot >> 1)) * (int)p.lddo + ch * 8) * 2u;
   const unsigned tq = __builtin_amdgcn_readfirstlane((unsigned)p.Tq), tk = __builtin_amdgcn_readfirstlane((unsigned)p.Tk);
   const unsigned ldq2 = __builtin_amdgcn_readfirstlane((unsigned)p.ldq * 2u), ldd2 = __builtin_amdgcn_readfirstlane((unsigned)p.lddo * 2u);
   const unsigned stK = __builtin_amdgcn_readfirstlane((unsigned)p.ldk * 128u), stV = __builtin_amdgcn_readfirstlane((unsigned)p.ldv * 128u);
@@ -1714,17 +1715,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dq4w_kernel(AttnP p) {
     s_mul_i32 s74, s62, %[ldd2]
     s_add_u32 s74, s74, 128
     s_mov_b32 s75, 0x20000
-    ; Q / dO row fragments of the two query blocks -> a[64:127]
-    s_lshl_b32 s61, %[ldq2], 5
-    v_add_u32 v29, s61, %[voQ]
-    s_lshl_b32 s61, %[ldd2], 5
-    v_add_u32 v30, s61, %[voD]
+    ; Q / dO rows of this wave's 64 queries -> its transit area (s53) as two tiles in the piece layout (see D4_KVDMA: whole 128-byte
+    ; rows by LDS-DMA instead of row-per-lane fragment loads), from there into a[64:127] below
+    s_mul_i32 s53, %[wave], )ASM" D4_STR(D4_KV) R"ASM(
+    s_add_u32 s53, s53, 3*)ASM" D4_STR(Q4_BUF) R"ASM(
+    s_add_u32 s53, s53, %[lds0]
     .set q4_i, 0
-    .rept 4
-      buffer_load_dwordx4 a[64+4*q4_i:64+4*q4_i+3], %[voQ], s[68:71], 0 offen offset:32*q4_i
-      buffer_load_dwordx4 a[80+4*q4_i:80+4*q4_i+3], %[voD], s[72:75], 0 offen offset:32*q4_i
-      buffer_load_dwordx4 a[96+4*q4_i:96+4*q4_i+3], v29, s[68:71], 0 offen offset:32*q4_i
-      buffer_load_dwordx4 a[112+4*q4_i:112+4*q4_i+3], v30, s[72:75], 0 offen offset:32*q4_i
+    .rept 8
+      s_mul_i32 s61, %[ldq2], (q4_i%%2)+4*(q4_i/2)
+      v_add_u32 v29, s61, %[voQ]
+      s_add_u32 m0, s53, q4_i*1280+64*(q4_i%%2)+16*(q4_i/2)
+      s_mul_i32 s62, %[ldd2], (q4_i%%2)+4*(q4_i/2)
+      buffer_load_dwordx4 v29, s[68:71], 0 offen lds
+      v_add_u32 v30, s62, %[voD]
+      s_add_u32 m0, s53, 10240+q4_i*1280+64*(q4_i%%2)+16*(q4_i/2)
+      s_nop 0
+      buffer_load_dwordx4 v30, s[72:75], 0 offen lds
       .set q4_i, q4_i+1
     .endr
     ; LDS-DMA destinations inside a buffer: piece 2 wave (s58), 2 wave + 1 (s59)
@@ -1735,20 +1741,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq4w_kernel(AttnP p) {
     s_add_u32 s58, s58, s62
     s_add_u32 s58, s58, %[lds0]
     s_add_u32 s59, s58, 1344
-    ; buffer offsets: cur (tile T) s63, nxt (T+1) s64, after next (T+2) s52, ld (T+3) s65; loop counter s66
+    ; buffer offsets: cur (tile T) s63, nxt (T+1) s64, ld (T+2) s65; loop counter s66
     s_mov_b32 s63, 0
     s_mov_b32 s64, )ASM" D4_STR(Q4_BUF) R"ASM(
-    s_mov_b32 s52, 2*)ASM" D4_STR(Q4_BUF) R"ASM(
-    s_mov_b32 s65, 3*)ASM" D4_STR(Q4_BUF) R"ASM(
+    s_mov_b32 s65, 2*)ASM" D4_STR(Q4_BUF) R"ASM(
     s_sub_u32 s66, %[npair], 1
-    ; ---- tiles 0, 1, 2
+    ; ---- tiles 0, 1
     Q4_STAGE s63
     Q4_ADVANCE
     s_nop 4
     Q4_STAGE s64
-    Q4_ADVANCE
-    s_nop 4
-    Q4_STAGE s52
     Q4_ADVANCE
     ; ---- (under the loads) accumulators, packed dS and transposed fragments start from zero; the row constants spread out
     .set q4_i, 0
@@ -1775,8 +1777,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq4w_kernel(AttnP p) {
     v_mov_b32 v24, %[rb]
     v_mov_b32 v25, %[tb]
     v_add_u32 v27, s64, v24
-    s_waitcnt vmcnt(8)             ; Q / dO fragments and tile 0 (tiles 1, 2: four pieces each may still be in flight)
+    s_waitcnt vmcnt(4)             ; Q / dO rows and tile 0 (tile 1: four pieces may still be in flight)
     s_barrier
+    ; Q / dO row fragments (lane (r, h): query 32 qb + r, columns 16 s + 8 h .. + 8) from the transit area -> a[64:127]
+    s_sub_u32 s61, s53, %[lds0]
+    v_add_u32 v26, s61, %[rb]
+    .set q4_i, 0
+    .rept 8
+      ds_read_b128 a[64+32*(q4_i/4)+4*(q4_i%%4):64+32*(q4_i/4)+4*(q4_i%%4)+3], v26 offset:512*(q4_i/4)+32*(q4_i%%4)
+      ds_read_b128 a[80+32*(q4_i/4)+4*(q4_i%%4):80+32*(q4_i/4)+4*(q4_i%%4)+3], v26 offset:10240+512*(q4_i/4)+32*(q4_i%%4)
+      .set q4_i, q4_i+1
+    .endr
     ; ---- block 0: row fragments, S^T / dP^T -> generation 128
     .set q4_i, 0
     .rept 8
