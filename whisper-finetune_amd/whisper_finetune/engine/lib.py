@@ -108,6 +108,7 @@ SIGNATURES = {
     "wft_attn_bwd_colsum_workspace_bytes": [C.POINTER(AttnArgs)],
     "wft_attn_set_dkdv_variant": [C.c_int],
     "wft_attn_set_dq_variant": [C.c_int],
+    "wft_attn_set_fwd_variant": [C.c_int],
     "wft_embed_fwd": [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, C.c_int, c_i64, c_vp],
     "wft_embed_bwd": [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, C.c_int, c_i64, c_vp],
     "wft_ce_fwd": [c_vp, c_i64, c_vp, c_i64, c_i64, C.c_float, c_vp, c_vp, c_vp, c_vp, c_vp],
