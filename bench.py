@@ -12,8 +12,8 @@ into the libwft multi-tensor AdamW — driven by the product's own `model_utils.
 scheduler step included).  68 clips per GPU per step by default (180 GiB of the 288 GB HBM).
 Weights: random init of the whisper-large-v3 architecture; data: synthetic (no network).
 Rank 0 prints ONE JSON line (contract in the task statement); it also carries
-  "roofline":     the dominant kernel (gemm_nt256_kernel: the Linear / logits forward and
-                  backward-data GEMMs), algorithmic FLOPs (2*M*N*K) / HIP-event time of its launches
+  "roofline":     the dominant kernel (the NT GEMM family with the most time — gemm_nt4w_kernel since round 4: the
+                  Linear / logits forward and backward-data GEMMs), algorithmic FLOPs (2*M*N*K) / HIP-event time of its launches
                   during one instrumented step that follows the timed region; "traffic" = HBM-side
                   bytes per launch from the committed rocprofv3 PMC passes of this command (profiles/);
   "cpu_baseline": the CPU oracle (oracle/whisper_oracle.py, torch fp32) forward+backward on a
@@ -75,8 +75,8 @@ def lora_flops_per_clip(d, S: int, r: int) -> float:
 
 
 def pmc_traffic_per_launch(batch: int, lora: bool = False, kname: str = "gemm_nt256_kernel"):
-    """HBM bytes per gemm_nt256_kernel launch from the committed rocprofv3 PMC passes of THIS command
-    (profiles/collect_r01.sh: --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, the only tracing next to them
+    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes of THIS command
+    (profiles/collect_r04.sh: --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, the only tracing next to them
     being --kernel-trace).  FETCH_SIZE is in KiB and counts 64 B per 128-B request on gfx950 for 16-B/lane streaming
     reads, so it is doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE (KiB) is exact.  Counters cannot be
     collected inside the timed run, so the value is only reported when the committed pass used the same batch."""
