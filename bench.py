@@ -336,6 +336,7 @@ class Case:
             import os as _os
             res["ddp"] = {"rccl_ranks": self.world, "bucket_cap_mb": 64, "gradient_as_bucket_view": True,
                           "nt_persistent_launches": _os.environ.get("WFT_NT256_PERSISTENT", "1") != "0",
+                          "attn_persistent_launches": _os.environ.get("WFT_ATTN_PERSISTENT", "1") != "0",
                           "ms_per_step_no_sync": round(t.item() * 1e3, 2),
                           "exposed_exchange_ms": round(dt / steps * 1e3 - t.item() * 1e3, 2)}
         if hand_rolled_steps > 0:

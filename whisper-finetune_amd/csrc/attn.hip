@@ -2349,7 +2349,9 @@ static bool wft_dq4w_eligible(const wft_attn_args* a) {
 static bool wft_dkdv4w_eligible(const wft_attn_args* a) {
   if (g_dkdv_variant != 0 || a->causal || a->Tq < 128) return false;
   const long lim = 0x7fffffffL;
-  return (long)a->Tq * a->ldq * 2 < lim && (long)a->Tq * a->lddo * 2 < lim && (long)a->Tk * a->ldk * 2 < lim && (long)a->Tk * a->ldv * 2 < lim;
+  // (+ 256: the last workgroup's lanes address rows up to 255 past the end; the descriptors return zeros for them)
+  return (long)(a->Tq + 256) * a->ldq * 2 < lim && (long)(a->Tq + 256) * a->lddo * 2 < lim && (long)(a->Tk + 256) * a->ldk * 2 < lim &&
+         (long)(a->Tk + 256) * a->ldv * 2 < lim;
 }
 
 extern "C" int wft_attn_bwd_bf16(const wft_attn_args* a, void* stream) {
@@ -2412,10 +2414,14 @@ extern "C" int wft_attn_bwd_bf16(const wft_attn_args* a, void* stream) {
       }
       lds4_set[dev] = true;
     }
-    // persistent: one workgroup per CU (WFT_DKDV_WGS overrides: A/B runs; >= the number of items = one item per workgroup)
+    // persistent: one workgroup per CU (WFT_DKDV_WGS overrides: A/B runs; >= the number of items = one item per workgroup).
+    // WFT_ATTN_PERSISTENT=0 (set by engine/lib.py in a multi-GPU job, like WFT_NT256_PERSISTENT): one item per workgroup — RCCL's
+    // collective kernels hold CUs during the backward pass, and a static walk would leave those CUs' share of the items for a
+    // second round; the hardware dispatcher balances single-item workgroups (measured equal on one GPU: 732 vs 735 us)
     static const int wgs_env = [] { const char* e = getenv("WFT_DKDV_WGS"); return e ? atoi(e) : 0; }();
+    static const bool persistent = [] { const char* e = getenv("WFT_ATTN_PERSISTENT"); return !(e && e[0] == '0'); }();
     const long items = (long)((a->Tk + 255) / 256) * a->H * a->B;
-    long wgs = wgs_env > 0 ? wgs_env : wft_num_cus();
+    long wgs = wgs_env > 0 ? wgs_env : (persistent ? wft_num_cus() : items);
     if (wgs > items) wgs = items;
     if (((long)a->H * a->B) % 8 == 0 && wgs >= 8) wgs -= wgs % 8;  // XCD mode needs the same number of workgroups on every XCD
     hipLaunchKernelGGL(attn_bwd_dkdv4w_kernel, dim3((unsigned)wgs), dim3(256), D4_LDS, s, p);

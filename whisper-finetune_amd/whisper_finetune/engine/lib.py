@@ -168,6 +168,7 @@ def load():
         # NT kernel is launched one workgroup per tile (hardware-balanced) instead of persistent (csrc/gemm.hip;
         # the library reads the variable once, when it is loaded)
         os.environ.setdefault("WFT_NT256_PERSISTENT", "0")
+        os.environ.setdefault("WFT_ATTN_PERSISTENT", "0")  # the same for the persistent dK/dV attention kernel (csrc/attn.hip)
     lib = C.CDLL(str(LIB_PATH))
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
