@@ -392,7 +392,6 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmP p) {
   Nt4wTile cur, nxt;
   desc_of(t, cur);
   unsigned first = 1;
-  const int q = lane >> 4, mr = lane & 15;
   constexpr bool RD_AUX = (EPI == WFT_EPI_MUL_AUX), WR_AUX = (EPI == WFT_EPI_GELU_GRAD);
   constexpr bool has_res = RES;  // (a residual operand; MUL_AUX reads aux instead)
   // vector-memory operations every wave issues per tile AFTER the K loop (a lower bound: the column-sum stores are not counted):
@@ -411,9 +410,6 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmP p) {
     const int m0 = tm << 8, n0 = tn << 8;
     desc_of(t + gridDim.x, nxt);
 
-    // lane (q, mr) ends up with, for X fragment fx and W fragment pair u, the 8 consecutive columns
-    // n0 + wn*128 + 32 u + 8 q .. +7 of row m0 + wm*128 + 16 fx + mr
-    const int ncol = n0 + wn * 128 + 8 * q;
     // The tile's 256 bias values travel like the operands: one LDS-DMA piece issued by wave 0 in the PREVIOUS tile's K loop
     // (its head for a workgroup's first tile) into one of two 1 KiB slices.  A plain load before the loop would hold 32
     // registers across it, one after the loop would queue behind the next tile's LDS-DMA pieces (vmcnt retires in order).
@@ -440,10 +436,19 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmP p) {
     const int r0 = (wave & 1) * 8;
     const unsigned voX = (unsigned)(((wm * 128 + 16 * ldf + r0) * (int)p.lda + ldc8 * 8) * 2);
     const unsigned voW = (unsigned)(((wm * 128 + 32 * (ldf >> 1) + 4 * (ldf & 1) + 8 * (r0 >> 2)) * (int)p.ldb + ldc8 * 8) * 2);
-    nt4w_kloop(rdX0, rdX1, rdW0, rdW1, voX, voW, cur, nxt, lda2, ldb2, mdst, nblk, first, nt4w_sgpr(t + (int)gridDim.x < total ? 1u : 0u), nt4w_sgpr(nops), lane_o * 16, nt4w_sgpr(bgo), cbias, nbias, cbdst, nbdst);
+    nt4w_kloop(rdX0, rdX1, rdW0, rdW1, voX, voW, cur, nxt, lda2, ldb2, mdst, nblk, first, nt4w_sgpr(t + (int)gridDim.x < total ? 1u : 0u), nops, lane_o * 16, nt4w_sgpr(bgo), cbias, nbias, cbdst, nbdst);
     first = 0;
     cur = nxt;
 
+    // The epilogue's lane coordinates are derived HERE, from an opaque copy of the thread id: computed in front of the K loop they
+    // are live across it, and in the variants that need the most registers behind it (column sums) hipcc spilled them — the
+    // reload in front of the NEXT K loop is a vmcnt(0) that drains this tile's stores (the seam the persistent loop exists to hide).
+    // lane (q, mr) holds, for X fragment fx and W fragment pair u, the 8 consecutive columns n0 + wn*128 + 32 u + 8 q .. +7 of
+    // row m0 + wm*128 + 16 fx + mr
+    unsigned tid_e = tid;
+    asm volatile("" : "+v"(tid_e));
+    const int q = (tid_e & 63) >> 4, mr = tid_e & 15;
+    const int ncol = n0 + wn * 128 + 8 * q;
     // (without a bias the slices hold zeros, written once below)
     const float* const bias_l = (const float*)(dsmem + NT4W_BIAS + bpar * 1024) + wn * 128 + 8 * q;
     bpar ^= 1;
@@ -463,8 +468,8 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmP p) {
     // at 102000 x 5120 x 1280 with half-line stores: 1 215 TF/s, 1 430 without the stores' traffic, 1 267 with whole lines; handing
     // half of the stores to the next tile's K loop (2 per k-step) costs exactly what it saves — the per-CU memory path, shared with
     // the K loop's 64 KiB per k-step, is the limit (profiles/README.md, round 4).
-    const auto srdC = srd_of((const unsigned short*)p.C + (long)bz * p.sC + (long)m0 * p.ldc, p.diag == 22 ? 0 : p.ldc);
-    const unsigned offC = (row_l * (unsigned)p.ldc + (unsigned)ncol) * 2u, stepC = nt4w_sgpr(32u * (unsigned)p.ldc);
+    const auto srdC = srd_of((const unsigned short*)p.C + (long)bz * p.sC + (long)m0 * p.ldc, (p.diag == 22 || p.diag == 23) ? 0 : p.ldc);
+    const unsigned offC = (row_l * (unsigned)p.ldc + (unsigned)ncol) * 2u, stepC = 32u * (unsigned)p.ldc;
     // The 32 groups (fx, u) of a lane are walked in column-chunk PAIRS: order o = 16 up + 2 fx + (u & 1), u = 2 up + (u & 1): both
     // chunks of a row band are converted, then stored together as whole 128-byte lines (store_pair below).
     // Residual / aux rows of this lane: a ring of 16 groups (64 registers; all 32 would leave the lane constants no room beside
@@ -473,14 +478,14 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmP p) {
     const unsigned short* const ob = RD_AUX ? p.aux + (long)bz * p.sAux + (long)m0 * p.ldaux : p.res + (long)bz * p.sR + (long)m0 * p.ldr;
     const long ldo = RD_AUX ? p.ldaux : p.ldr;
     const auto srdO = srd_of((RD_AUX || has_res) ? (const void*)ob : (const void*)p.C, (RD_AUX || has_res) ? ldo : 0);
-    const unsigned offO = (row_l * (unsigned)ldo + (unsigned)ncol) * 2u, stepO = nt4w_sgpr(32u * (unsigned)ldo);
+    const unsigned offO = (row_l * (unsigned)ldo + (unsigned)ncol) * 2u, stepO = 32u * (unsigned)ldo;
     auto load_o = [&](auto oc) {  // group number oc in walking order
       constexpr int o = decltype(oc)::value, fx = (o >> 1) & 7, u = 2 * (o >> 4) + (o & 1);
       opq[o & 15] = __builtin_amdgcn_raw_buffer_load_b128(srdO, offO + fx * stepO + 64u * u, 0, 0);
     };
     if constexpr (RD_AUX || has_res) nt4w_for<0, 16>(load_o);
-    const auto srdA = srd_of(WR_AUX ? p.aux + (long)bz * p.sAux + (long)m0 * p.ldaux : (const unsigned short*)p.C, WR_AUX ? p.ldaux : 0);
-    const unsigned stepA = nt4w_sgpr(32u * (unsigned)p.ldaux);
+    const auto srdA = srd_of(WR_AUX ? p.aux + (long)bz * p.sAux + (long)m0 * p.ldaux : (const unsigned short*)p.C, (WR_AUX && p.diag != 23 && p.diag != 24) ? p.ldaux : 0);  // (DIAG 23: C and aux stores dropped, 24: aux only — timing)
+    const unsigned stepA = 32u * (unsigned)p.ldaux;  // (wave-uniform by construction: no readfirstlane — it would cost a vector register across the K loop)
     // Whole-line stores.  As they leave the MFMA a lane (q, mr) holds 16 bytes of row mr in each column chunk, so one store
     // instruction would write 16 rows x 64 B: half lines, and the CU's store path is paid per request (measured: whole lines cost
     // 27 % less, profiles/README.md round 4).  Two DPP moves per dword (row_ror:8 = lanes mr <-> mr + 8 of a 16-lane row, bank
@@ -539,10 +544,11 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmP p) {
           }
           if constexpr ((RD_AUX || has_res) && o < 16) load_o(std::integral_constant<int, o + 16>{});
           pk[hh] = u32x4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
-          if constexpr (CS) {  // (rows >= M hold exact zeros only without a bias; the engine asks for column sums of bias-free products)
-            const bool row_ok = (int)(row_l + 16 * fx) < rows;
+          if constexpr (CS) {
+            // rows >= M add exact zeros: CS is only instantiated with MUL_AUX (no bias), their accumulators are products of the
+            // zeros the A descriptor returns past M, and so are their aux values — no select per element
 #pragma unroll
-            for (int e = 0; e < 8; ++e) cs[hh][e] += row_ok ? v[e] : 0.f;
+            for (int e = 0; e < 8; ++e) cs[hh][e] += v[e];
           }
         });
         if constexpr (WR_AUX) store_pair(srdA, offAL + fx * stepA + 128u * up, stepA >> 1, dpk[0], dpk[1]);
@@ -553,24 +559,25 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmP p) {
           store_pair(srdC, offCL + fx * stepC + 128u * up, stepC >> 1, pk[0], pk[1]);
         }
       });
-      if constexpr (CS) {  // column sums of this wave's 128 rows in chunks 2 up, 2 up + 1: reduce over the 16 row lanes; lane mr == 0 stores
-        nt4w_for<0, 2>([&](auto hc) {
-          constexpr int hh = decltype(hc)::value, u = 2 * up + hh;
+      if constexpr (CS) {
+        // column sums of this wave's 128 rows in chunks 2 up, 2 up + 1: 16 values per lane (8 hh + e), summed over the 16 row lanes mr by
+        // a halving butterfly — a lane keeps the half of its values its lane bit selects and adds the partner's copy of that half:
+        // 15 exchanges instead of 64; lane mr ends with value index mr and stores that one float
+        float cv[16];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float sacc = cs[hh][e];
-            sacc += __shfl_xor(sacc, 1, 64);
-            sacc += __shfl_xor(sacc, 2, 64);
-            sacc += __shfl_xor(sacc, 4, 64);
-            sacc += __shfl_xor(sacc, 8, 64);
-            cs[hh][e] = sacc;
+        for (int i = 0; i < 16; ++i) cv[i] = cs[i >> 3][i & 7];
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) {
+          const bool upper = (mr & m) != 0;
+#pragma unroll
+          for (int i = 0; i < m; ++i) {
+            const float keep = upper ? cv[i + m] : cv[i], send = upper ? cv[i] : cv[i + m];
+            cv[i] = keep + __shfl_xor(send, m, 64);
           }
-          if (mr == 0) {
-            float* dst = p.cs_part + (long)(tm * 2 + wm) * p.N + ncol + 32 * u;
-            *(f32x4*)dst = f32x4{cs[hh][0], cs[hh][1], cs[hh][2], cs[hh][3]};
-            *(f32x4*)(dst + 4) = f32x4{cs[hh][4], cs[hh][5], cs[hh][6], cs[hh][7]};
-          }
-        });
+        }
+        // (row base formed on the scalar unit: a 64-bit per-lane product would keep p.N in a vector register across the K loop)
+        float* const csb = (float*)nt4w_sgpr64((unsigned long long)(p.cs_part + (long)(tm * 2 + wm) * p.N));
+        csb[ncol + 32 * (2 * up + (mr >> 3)) + (mr & 7)] = cv[0];
       }
     });
   }
