@@ -766,3 +766,42 @@ def test_batched_weight_shadow_refresh_is_bit_identical_to_the_per_weight_kernel
     assert c1[1]["mt"] == 1 and c1[2]["mt"] == 1 and c1[1]["cast"] <= c0[1]["cast"] - (4 * 6 + 4 * 10) + 4, (c1, c0)
     # ... and ONE wft_mt_copy_f32 launch restacks the q / v (and cross k / v) bias vectors of all fused groups
     assert c0[1]["bias"] == 0 and c1[1]["bias"] == 1 and c1[2]["bias"] == 1, (c1, c0)
+
+
+def test_encoder_output_gradient_accumulated_in_the_gemm_epilogues():
+    """ops.GradAccum: the key / value projections of all decoder blocks add their input gradients inside their backward-data GEMMs
+    (whisper's MultiHeadAttention.forward with `xa`, reached from the reference's model_utils.py:320-322).  Same sum as autograd's
+    pairwise adds up to one bf16 rounding per block: every encoder-side gradient agrees with the autograd-summed run, with stochastic
+    depth (skipped decoder blocks never register) and under checkpoint recompute (a recomputed forward must not count twice)."""
+    from whisper_finetune.engine import whisper_model as WM
+    from whisper_finetune.model.model_utils import CheckpointedStochasticTextDecoder
+    dims, params, audio, y_in, y_out = _tiny_case()
+    mel = K.logmel(audio.to(DEV), O.mel_filters(dims.n_mels).to(DEV))
+
+    def grads(accum: bool, sd: float, recompute: bool):
+        old = WM._XA_ACCUM
+        WM._XA_ACCUM = accum
+        try:
+            m = Whisper(MODEL_DIMS["tiny"])
+            if sd > 0 or recompute:
+                m.decoder = CheckpointedStochasticTextDecoder(dims.n_vocab, dims.n_text_ctx, dims.n_text_state, dims.n_text_head,
+                                                              dims.n_text_layer, sd)
+                m.decoder.recompute = recompute
+            m.load_state_dict(params)
+            m.to(DEV).train()
+            torch.manual_seed(123)  # the same skip draws in both runs
+            loss = m(mel, y_in.to(DEV), targets=y_out.to(DEV), label_smoothing=0.1)
+            loss.backward()
+            return loss.item(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+        finally:
+            WM._XA_ACCUM = old
+
+    for sd, recompute in ((0.0, False), (0.5, False), (0.0, True), (0.5, True)):
+        l0, g0 = grads(False, sd, recompute)
+        l1, g1 = grads(True, sd, recompute)
+        assert l0 == l1
+        assert g0.keys() == g1.keys()
+        enc = [n for n in g0 if n.startswith("encoder.")]
+        assert enc and all(g0[n].abs().sum() > 0 for n in enc if "blocks.0.attn.query.weight" in n)
+        for n in g0:
+            assert rel(g1[n], g0[n]) < (1e-2 if n.startswith("encoder.") else 1e-6), (n, sd, recompute, rel(g1[n], g0[n]))

@@ -18,7 +18,10 @@ import warnings
 from dataclasses import dataclass
 from typing import Dict, Iterable, Optional
 
+import os
+
 import numpy as np
+
 import torch
 import torch.nn.functional as F
 from torch import Tensor, nn
@@ -28,6 +31,10 @@ from . import ops
 from . import ops32
 
 BF16 = torch.bfloat16
+
+
+# WFT_XA_ACCUM=0: the encoder-output gradient is summed by autograd (A/B runs)
+_XA_ACCUM = os.environ.get("WFT_XA_ACCUM", "1") != "0"
 
 
 @dataclass
@@ -179,8 +186,17 @@ class MultiHeadAttention(nn.Module):
             Ta = xa.shape[1]
             q = self.query(x2)
             lin = [self.key, self.value]
+            # every decoder block projects the SAME encoder output: their input gradients are summed inside the backward-data
+            # GEMMs (ops.GradAccum) instead of by 31 elementwise adds; the accumulator rides on the tensor itself, so any
+            # decoder class (plain, checkpointed, stochastic depth) shares it without knowing
+            acc = None
+            if _XA_ACCUM and torch.is_grad_enabled() and xa.requires_grad and xa.dtype == torch.bfloat16:
+                acc = getattr(xa, "_wft_dx_accum", None)
+                if acc is None:
+                    acc = ops.GradAccum()
+                    xa._wft_dx_accum = acc
             kv = ops.linear(_as2d(_to_bf16(xa)), self._kv_group, [m.base_weight() for m in lin], [m.bias for m in lin],
-                            [m.lora_spec() for m in lin])
+                            [m.lora_spec() for m in lin], dx_accum=acc)
             o = ops.CrossAttnFn.apply(q.view(B, T, d), kv.view(B, Ta, 2 * d), self.n_head)
         out = self.out(o.view(B * T, d), residual=None if residual is None else _as2d(residual))
         return out.view(B, T, d), None
