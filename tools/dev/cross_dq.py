@@ -1,0 +1,20 @@
+"""Developer script (GPU box): attention backward on the decoder's cross-attention shapes (68 x 20 heads, Tq = 128 / 448, Tk = 1500) for
+the current WFT_DQ4W_MIN_TQ: the 4-wave dQ kernel loses at Tq = 128 (0.613 vs 0.550 ms) and ties at 448 (1.021 vs 1.036), hence 512.
+    for m in 512 128; do WFT_DQ4W_MIN_TQ=$m python tools/dev/cross_dq.py; done"""
+import sys, time, torch
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[2] / "whisper-finetune_amd"))
+from whisper_finetune.engine import kernels as K, lib as L
+dev = torch.device("cuda:0"); lib = L.load()
+def t(f, n=20):
+    for _ in range(5): f()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): f()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
+for B, H, Tq, Tk in ((68, 20, 128, 1500), (68, 20, 448, 1500)):
+    q = torch.randn(B, Tq, H * 64, device=dev).to(torch.bfloat16)
+    kv = torch.randn(B, Tk, 2 * H * 64, device=dev).to(torch.bfloat16)
+    k, v = kv[..., :H * 64], kv[..., H * 64:]
+    do = torch.randn(B, Tq, H * 64, device=dev).to(torch.bfloat16)
+    o, lse = K.attn_fwd(q, k, v, H, False, 0.125)
+    print(f"B{B} {Tq}x{Tk}: bwd {t(lambda: K.attn_bwd(q, k, v, o, lse, do, H, False, 0.125)):.3f} ms", flush=True)
