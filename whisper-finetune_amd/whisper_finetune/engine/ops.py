@@ -449,7 +449,10 @@ class GradAccum:
     32 gradients of large-v3 pairwise, 31 elementwise kernels over a [B*1500, d] tensor per step (3.6 ms at 68 clips).
     Here every consumer's GEMM adds its product to the running sum in its epilogue (C = acc + residual, in place) and
     only the LAST one to arrive hands the sum to autograd; the others return None.  Consumers register by the identity of
-    their LinearGroup, so a recomputed forward (torch.utils.checkpoint) does not count twice."""
+    their LinearGroup, so a recomputed forward (torch.utils.checkpoint) does not count twice.
+    Contract: every consumer that registered in a forward pass takes part in the SAME backward pass (true for a model's
+    own loss; a second head that consumes the same encoder output and is never backpropagated would withhold the sum —
+    WFT_XA_ACCUM=0 restores autograd's own summation for such set-ups)."""
 
     __slots__ = ("ids", "done", "buf")
 
