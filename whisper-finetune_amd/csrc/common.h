@@ -98,14 +98,16 @@ __device__ __forceinline__ float dgelu_f(float x) {
 // gelu(x) = x Phi(x) and gelu'(x) from the same exponential, reciprocal and polynomial (WFT_EPI_GELU_GRAD: the forward
 // GEMM stores gelu' so that the backward-data GEMM's epilogue is a single multiply)
 __device__ __forceinline__ void gelu_both_f(float x, float& g, float& d) {
-  const float ax = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-  const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);
-  float poly = fmaf(1.061405429f, t, -1.453152027f);
-  poly = fmaf(poly, t, 1.421413741f);
-  poly = fmaf(poly, t, -0.284496736f);
-  poly = fmaf(poly, t, 0.254829592f);
-  const float half_erfc = 0.5f * poly * t * e;
+  // (p / sqrt 2 in one constant; the polynomial's coefficients carry the factor 0.5 of half_erfc — exact, a power of two;
+  // x^2 / (2 ln 2) as the product of two scaled copies of x: all three keep the packed-fp32 forms and save single-lane issues)
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.23164189f, fabsf(x), 1.0f));
+  const float xs = x * 0.84932180f;  // sqrt(1 / (2 ln 2))
+  const float e = __builtin_amdgcn_exp2f(-(xs * xs));
+  float poly = fmaf(0.5307027145f, t, -0.7265760135f);
+  poly = fmaf(poly, t, 0.7107068705f);
+  poly = fmaf(poly, t, -0.142248368f);
+  poly = fmaf(poly, t, 0.127414796f);
+  const float half_erfc = poly * t * e;
   const float cdf = x >= 0.f ? 1.0f - half_erfc : half_erfc;
   g = x * cdf;
   d = fmaf(x, 0.39894228040143267794f * e, cdf);
