@@ -211,14 +211,19 @@ typedef struct {
 } wft_gemm_args;
 int wft_gemm_nt_bf16(const wft_gemm_args* args, void* stream);
 /* Which 256x256 NT kernel serves the encoder-sized problems: 0 (default) = the one-wave-per-SIMD kernel (csrc/gemm_nt4w.hip)
- * wherever it applies, 1 = always the 8-wave ping-pong kernel (csrc/gemm.hip).  Environment: WFT_NT_VARIANT=4w|pp, read once at
+ * wherever it applies, 1 = always the 8-wave ping-pong kernel (csrc/gemm.hip).  Environment (libwft_timing.so only, `make TIMING=1`): WFT_NT_VARIANT=4w|pp, read once at
  * load time.  Returns the previous setting; v < 0 only queries.  A/B tool and test hook: the two kernels accumulate in the same
  * k order and give bit-identical C.                                                                        */
 int wft_gemm_set_nt_variant(int v);
 /* The same switch for the weight-gradient GEMM: 0 (default) = gemm_tn4w_kernel (csrc/gemm_tn4w.hip) where it applies, 1 = always
- * gemm_tn256_kernel.  WFT_TN_VARIANT=4w|pp at load time.  Both sum the reduction in ascending 32-row MFMA steps inside a split;
+ * gemm_tn256_kernel.  WFT_TN_VARIANT=4w|pp at load time (timing builds only).  Both sum the reduction in ascending 32-row MFMA steps inside a split;
  * their split-K plans may differ (different partial sums, same fixed order from run to run).                          */
 int wft_gemm_set_tn_variant(int v);
+/* Launch mode of the 256x256 NT kernels: 1 (default) = persistent, one workgroup per CU walks the tiles; 0 = one workgroup per
+ * tile (the mode of a multi-GPU job, where RCCL's collective kernels hold CUs during the backward pass: engine/lib.py sets
+ * WFT_NT256_PERSISTENT=0 when WORLD_SIZE > 1, the reference's DDP wrap at scripts/finetune.py:694-710).  Same results either
+ * way.  Returns the previous setting; v < 0 only queries.                                                          */
+int wft_gemm_set_persistent(int v);
 /* Which kernel wft_gemm_nt_bf16 dispatches these arguments to: 4 (gemm_nt4w_kernel: 256x256 tiles, four waves with 128x128
  * accumulators each), 256 (gemm_nt256_kernel, the 8-wave ping-pong 256x256 kernel) or 128 (gemm_nt_kernel).  Pure host
  * function (used by bench.py to attribute HIP-event timings to the kernel names rocprofv3 reports).        */
@@ -272,7 +277,7 @@ int64_t wft_attn_bwd_colsum_workspace_bytes(const wft_attn_args* args);
 /* Which dK/dV kernel wft_attn_bwd_bf16 launches: 0 (default) the one-wave-per-SIMD kernel (csrc/attn.hip, attn_bwd_dkdv4w_kernel)
  * for non-causal calls with Tq >= 128, the 8-wave kernel otherwise; 1 always the 8-wave kernel.  Same results up to the
  * rounding of a different summation order over queries.  Returns the previous value; a negative argument only reads.
- * Start value from WFT_DKDV_VARIANT=4w|8w.  (A/B measurements and tests; not part of the reference's interface.)          */
+ * Start value from WFT_DKDV_VARIANT=4w|8w (read by timing builds only, like the two below).  (A/B measurements and tests; not part of the reference's interface.)          */
 int wft_attn_set_dkdv_variant(int variant);
 /* The same switch for the dQ kernel (attn_bwd_dq4w_kernel: non-causal calls with Tq >= 512).  Start value from
  * WFT_DQ_VARIANT=4w|8w.                                                                                                    */
@@ -281,6 +286,8 @@ int wft_attn_set_dq_variant(int variant);
  * faster; it serves non-causal calls with Tq >= 512 when selected and moves the running maximum per 32-key block where the 8-wave
  * kernel does per 64-key tile, so outputs agree to fp32 rounding, not bit for bit).  Start value from WFT_FWD_VARIANT=4w|8w.  */
 int wft_attn_set_fwd_variant(int variant);
+/* Launch mode of the persistent dK/dV kernel, like wft_gemm_set_persistent (start value from WFT_ATTN_PERSISTENT).      */
+int wft_attn_set_persistent(int v);
 
 /* -------------------------------------------------------------- Embedding */
 /* TextDecoder: x = token_embedding(tokens) + positional_embedding[:S]

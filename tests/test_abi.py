@@ -54,3 +54,28 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         monkeypatch.undo()
         L._lib = None
         L.load()
+
+
+def test_shipped_library_cannot_read_timing_switches():
+    """WFT_GEMM_DIAG=6/22/23/24 drop stores / epilogues "for timing only", the *_VARIANT / *_VAR / thresholds are A/B switches: they
+    exist only in libwft_timing.so (`make TIMING=1`, -DWFT_TIMING_BUILDS).  The shipped library does not contain their names at
+    all, so no environment can change what it computes; the two launch-mode variables of a multi-GPU job are the only ones it
+    reads, and wft_version() says which build is loaded."""
+    blob = L.LIB_PATH.read_bytes()
+    names = sorted(set(m.decode() for m in re.findall(rb"WFT_[A-Z0-9_]{3,}", blob)) - {"WFT_EPI_DGELU", "WFT_EPI_GELU_GRAD", "WFT_EPI_MUL_AUX"})
+    assert names == ["WFT_ATTN_PERSISTENT", "WFT_NT256_PERSISTENT"], names  # (WFT_EPI_*: enum names inside error messages)
+    # every getenv of a developer switch in the sources goes through wft_dev_getenv (compiled to nullptr without the flag)
+    for src in (ROOT / "whisper-finetune_amd" / "csrc").glob("*.hip"):
+        for var in re.findall(r'[^_]getenv\("(WFT_[A-Z0-9_]+)"\)', src.read_text()):
+            assert var in ("WFT_ATTN_PERSISTENT", "WFT_NT256_PERSISTENT"), (src.name, var)
+    assert b"timing-builds" not in blob
+    assert L.load().wft_version().decode() == "wft 0.1 gfx950"
+
+
+def test_launch_mode_setters_round_trip():
+    handle = L.load()
+    for fn in (handle.wft_gemm_set_persistent, handle.wft_attn_set_persistent):
+        before = fn(-1)
+        assert fn(0) == before and fn(-1) == 0
+        assert fn(1) == 0 and fn(-1) == 1
+        fn(before)

@@ -2,6 +2,7 @@
 the current WFT_DQ4W_MIN_TQ: the 4-wave dQ kernel loses at Tq = 128 (0.613 vs 0.550 ms) and ties at 448 (1.021 vs 1.036), hence 512.
     for m in 512 128; do WFT_DQ4W_MIN_TQ=$m python tools/dev/cross_dq.py; done"""
 import sys, time, torch
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.abspath(__file__))); import _timing_lib  # noqa: E702 (WFT_LIB -> libwft_timing.so)
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[2] / "whisper-finetune_amd"))
 from whisper_finetune.engine import kernels as K, lib as L

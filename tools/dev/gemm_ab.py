@@ -1,4 +1,5 @@
 import os, sys, time, subprocess
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.abspath(__file__))); import _timing_lib  # noqa: E702 (WFT_LIB -> libwft_timing.so)
 # A/B of WFT_GEMM_DIAG variants in interleaved rounds (each variant in its own process: the library reads the variable once)
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     import torch

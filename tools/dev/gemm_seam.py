@@ -1,6 +1,7 @@
 """Developer script (GPU box): fixed cost per 256x256 tile of gemm_nt256_kernel — time vs K at fixed M, N (tiles per CU fixed),
 for the store-only epilogue, and with WFT_GEMM_DIAG=6 (staged epilogue skipped: timing only) in a child process."""
 import os, sys, time, subprocess
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.abspath(__file__))); import _timing_lib  # noqa: E702 (WFT_LIB -> libwft_timing.so)
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     import torch
     from pathlib import Path

@@ -2,6 +2,7 @@
 WFT_GEMM_DIAG: 22 C stores dropped, 23 C and aux stores dropped, 24 aux stores dropped).  One process per setting:
     for d in 0 22 23 24; do WFT_GEMM_DIAG=$d python tools/dev/nt4w_epi.py; done"""
 import os, sys, time
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.abspath(__file__))); import _timing_lib  # noqa: E702 (WFT_LIB -> libwft_timing.so)
 from pathlib import Path
 import torch
 sys.path.insert(0, str(Path(__file__).resolve().parents[2] / "whisper-finetune_amd"))

@@ -1,6 +1,7 @@
 """Developer script (GPU box, WFT_GEMM_DIAG=12): where does an NT256 tile's time go?  s_memrealtime stamps (100 MHz) of waves 0 / 4
 of every persistent workgroup: kernel entry, per tile {main loop start, main loop end, after the end barrier, epilogue end}."""
 import ctypes as C, os, sys
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.abspath(__file__))); import _timing_lib  # noqa: E702 (WFT_LIB -> libwft_timing.so)
 DIAG = os.environ.get("WFT_GEMM_DIAG", "12")
 os.environ["WFT_GEMM_DIAG"] = DIAG
 import torch

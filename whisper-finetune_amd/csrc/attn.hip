@@ -1446,7 +1446,7 @@ static int attn_fill(const wft_attn_args* a, AttnP& p) {
   p.dk = a->dk; p.lddk = a->lddk; p.dk_bs = a->dk_bs;
   p.dv = a->dv; p.lddv = a->lddv; p.dv_bs = a->dv_bs;
   p.cs_q = nullptr; p.cs_v = nullptr;
-  static const int xcd_on = [] { const char* e = getenv("WFT_ATTN_XCD"); return e ? atoi(e) : 1; }();
+  static const int xcd_on = [] { const char* e = wft_dev_getenv("WFT_ATTN_XCD"); return e ? atoi(e) : 1; }();
   p.xcd = xcd_on;
   return 0;
 }
@@ -2251,14 +2251,14 @@ __global__ __launch_bounds__(256) void attn_fwd4w_kernel(AttnP p) {
 // WFT_FWD_VARIANT=8w|4w sets the start value.  The forward is bound by vector issue (per MFMA: 8 vector instructions, against 4 in
 // the backward kernels) and gains nothing from the 4-wave frame: 505-546 us against 541-547 us per encoder call at B = 32, whole
 // step 626 against 623-626 ms (profiles/README.md, round 4).  The kernel stays as the measured alternative.
-static int g_fwd_variant = [] { const char* e = getenv("WFT_FWD_VARIANT"); return (e && !strcmp(e, "4w")) ? 0 : 1; }();
+static int g_fwd_variant = [] { const char* e = wft_dev_getenv("WFT_FWD_VARIANT"); return (e && !strcmp(e, "4w")) ? 0 : 1; }();
 extern "C" int wft_attn_set_fwd_variant(int v) {
   const int old = g_fwd_variant;
   if (v >= 0) g_fwd_variant = v ? 1 : 0;
   return old;
 }
 static bool wft_fwd4w_eligible(const wft_attn_args* a) {
-  static const int min_tq = [] { const char* e = getenv("WFT_FWD4W_MIN_TQ"); return e ? atoi(e) : 512; }();
+  static const int min_tq = [] { const char* e = wft_dev_getenv("WFT_FWD4W_MIN_TQ"); return e ? atoi(e) : 512; }();
   if (g_fwd_variant != 0 || a->causal || a->Tq < min_tq) return false;
   const long lim = 0x7fffffffL;
   return (long)(a->Tq + 256) * a->ldq * 2 < lim && (long)(a->Tk + 256) * a->ldk * 2 < lim && (long)(a->Tk + 256) * a->ldv * 2 < lim;
@@ -2324,14 +2324,18 @@ extern "C" int64_t wft_attn_bwd_colsum_workspace_bytes(const wft_attn_args* a) {
 
 // Which dK/dV kernel: 0 (default) the one-wave-per-SIMD kernel where it applies, 1 always the 8-wave kernel.  WFT_DKDV_VARIANT=8w|4w
 // sets the start value; returns the previous one (a negative argument only reads).
-static int g_dkdv_variant = [] { const char* e = getenv("WFT_DKDV_VARIANT"); return (e && !strcmp(e, "8w")) ? 1 : 0; }();
+// persistent dK/dV launches (one workgroup per CU) or one item per workgroup: WFT_ATTN_PERSISTENT=0 at load time (engine/lib.py sets it
+// in a multi-GPU job), wft_attn_set_persistent() inside a process (bench.py's ddp_mode_1gpu block)
+static int g_attn_persistent = [] { const char* e = getenv("WFT_ATTN_PERSISTENT"); return (e && e[0] == '0') ? 0 : 1; }();
+extern "C" int wft_attn_set_persistent(int v) { const int o = g_attn_persistent; if (v >= 0) g_attn_persistent = v ? 1 : 0; return o; }
+static int g_dkdv_variant = [] { const char* e = wft_dev_getenv("WFT_DKDV_VARIANT"); return (e && !strcmp(e, "8w")) ? 1 : 0; }();
 extern "C" int wft_attn_set_dkdv_variant(int v) {
   const int old = g_dkdv_variant;
   if (v >= 0) g_dkdv_variant = v ? 1 : 0;
   return old;
 }
 // the same for the dQ kernel (attn_bwd_dq4w_kernel): WFT_DQ_VARIANT=8w|4w
-static int g_dq_variant = [] { const char* e = getenv("WFT_DQ_VARIANT"); return (e && !strcmp(e, "8w")) ? 1 : 0; }();
+static int g_dq_variant = [] { const char* e = wft_dev_getenv("WFT_DQ_VARIANT"); return (e && !strcmp(e, "8w")) ? 1 : 0; }();
 extern "C" int wft_attn_set_dq_variant(int v) {
   const int old = g_dq_variant;
   if (v >= 0) g_dq_variant = v ? 1 : 0;
@@ -2339,7 +2343,7 @@ extern "C" int wft_attn_set_dq_variant(int v) {
 }
 // non-causal calls with enough queries to fill 256-query workgroups; byte offsets must fit the asm block's 32-bit buffer addressing
 static bool wft_dq4w_eligible(const wft_attn_args* a) {
-  static const int min_tq = [] { const char* e = getenv("WFT_DQ4W_MIN_TQ"); return e ? atoi(e) : 512; }();
+  static const int min_tq = [] { const char* e = wft_dev_getenv("WFT_DQ4W_MIN_TQ"); return e ? atoi(e) : 512; }();
   if (g_dq_variant != 0 || a->causal || a->Tq < min_tq) return false;
   const long lim = 0x7fffffffL;
   return (long)(a->Tq + 256) * a->ldq * 2 < lim && (long)(a->Tq + 256) * a->lddo * 2 < lim && (long)(a->Tk + 256) * a->ldk * 2 < lim &&
@@ -2418,8 +2422,8 @@ extern "C" int wft_attn_bwd_bf16(const wft_attn_args* a, void* stream) {
     // WFT_ATTN_PERSISTENT=0 (set by engine/lib.py in a multi-GPU job, like WFT_NT256_PERSISTENT): one item per workgroup — RCCL's
     // collective kernels hold CUs during the backward pass, and a static walk would leave those CUs' share of the items for a
     // second round; the hardware dispatcher balances single-item workgroups (measured equal on one GPU: 732 vs 735 us)
-    static const int wgs_env = [] { const char* e = getenv("WFT_DKDV_WGS"); return e ? atoi(e) : 0; }();
-    static const bool persistent = [] { const char* e = getenv("WFT_ATTN_PERSISTENT"); return !(e && e[0] == '0'); }();
+    static const int wgs_env = [] { const char* e = wft_dev_getenv("WFT_DKDV_WGS"); return e ? atoi(e) : 0; }();
+    const bool persistent = g_attn_persistent != 0;
     const long items = (long)((a->Tk + 255) / 256) * a->H * a->B;
     long wgs = wgs_env > 0 ? wgs_env : (persistent ? wft_num_cus() : items);
     if (wgs > items) wgs = items;

@@ -20,6 +20,19 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 void wft_set_error(const char* fmt, ...);
 
+// Developer switches (WFT_GEMM_DIAG and the A/B variables listed in DESIGN.md §3) exist only in a library built with
+// -DWFT_TIMING_BUILDS (`make TIMING=1` -> libwft_timing.so): some of them drop stores or epilogues "for timing only", and a stray
+// variable in a job script must not be able to make the shipped library train on garbage.  The default build never reads them
+// (the names are not even in the binary: tests/test_abi.py), and wft_version() says which build is loaded.
+#include <stdlib.h>
+#ifdef WFT_TIMING_BUILDS
+static inline const char* wft_dev_getenv(const char* name) { return getenv(name); }
+#define WFT_BUILD_KIND " timing-builds"
+#else
+static inline const char* wft_dev_getenv(const char*) { return nullptr; }
+#define WFT_BUILD_KIND ""
+#endif
+
 #define WFT_CHECK_ARG(cond, msg)                                   \
   do {                                                             \
     if (!(cond)) {                                                 \

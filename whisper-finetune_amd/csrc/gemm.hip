@@ -1434,9 +1434,12 @@ void wft_tn4w_plan(const wft_gemm_args* a, int* nsplit_out, int* per_out);
 int wft_tn4w_launch(const wft_gemm_args* a, GemmP p, int nsplit, int per, void* stream);
 extern "C" int wft_gemm_set_tn_variant(int v) { const int o = g_tn_variant; if (v >= 0) g_tn_variant = v; return o; }
 int wft_nt4w_launch(const wft_gemm_args* a, const GemmP& p, bool persistent, void* stream);
+extern "C" int wft_gemm_set_persistent(int v);
 extern "C" int wft_gemm_set_nt_variant(int v) { const int o = g_nt_variant; if (v >= 0) g_nt_variant = v; return o; }
 static bool g_force_128 = false;  // debugging / A-B switch: WFT_GEMM_FORCE_128=1
-static struct EnvInit { EnvInit() { const char* e = getenv("WFT_GEMM_FORCE_128"); g_force_128 = e && e[0] == '1'; const char* d = getenv("WFT_GEMM_DIAG"); g_diag = d ? atoi(d) : 0; const char* t1 = getenv("WFT_NT256_MIN_TILES"); if (t1) g_nt256_min_tiles = atoi(t1); const char* t2 = getenv("WFT_TN256_MIN_STEPS"); if (t2) g_tn256_min_steps = atoi(t2); const char* pe = getenv("WFT_NT256_PERSISTENT"); if (pe) g_nt256_persistent = pe[0] != '0'; const char* bw = getenv("WFT_NT256_BAND"); if (bw && atoi(bw) > 0) g_nt256_band = atoi(bw); const char* nv = getenv("WFT_NT_VARIANT"); if (nv) g_nt_variant = (nv[0] == 'p') ? 1 : 0; const char* tv = getenv("WFT_TN_VARIANT"); if (tv) g_tn_variant = (tv[0] == 'p') ? 1 : 0; } } g_env_init;
+static struct EnvInit { EnvInit() { const char* e = wft_dev_getenv("WFT_GEMM_FORCE_128"); g_force_128 = e && e[0] == '1'; const char* d = wft_dev_getenv("WFT_GEMM_DIAG"); g_diag = d ? atoi(d) : 0; const char* t1 = wft_dev_getenv("WFT_NT256_MIN_TILES"); if (t1) g_nt256_min_tiles = atoi(t1); const char* t2 = wft_dev_getenv("WFT_TN256_MIN_STEPS"); if (t2) g_tn256_min_steps = atoi(t2); const char* pe = getenv("WFT_NT256_PERSISTENT"); if (pe) g_nt256_persistent = pe[0] != '0'; const char* bw = wft_dev_getenv("WFT_NT256_BAND"); if (bw && atoi(bw) > 0) g_nt256_band = atoi(bw); const char* nv = wft_dev_getenv("WFT_NT_VARIANT"); if (nv) g_nt_variant = (nv[0] == 'p') ? 1 : 0; const char* tv = wft_dev_getenv("WFT_TN_VARIANT"); if (tv) g_tn_variant = (tv[0] == 'p') ? 1 : 0; } } g_env_init;
+
+extern "C" int wft_gemm_set_persistent(int v) { const int o = g_nt256_persistent ? 1 : 0; if (v >= 0) g_nt256_persistent = v != 0; return o; }
 
 static int fill_params(const wft_gemm_args* a, GemmP& p) {
   p.A = a->A; p.lda = a->lda; p.sA = a->strideA;

@@ -13,7 +13,7 @@ void wft_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* wft_last_error(void) { return g_err; }
-extern "C" const char* wft_version(void) { return "wft 0.1 gfx950"; }
+extern "C" const char* wft_version(void) { return "wft 0.1 gfx950" WFT_BUILD_KIND; }
 
 static inline int ew_grid(int64_t nvec) {
   int64_t g = (nvec + 255) / 256;

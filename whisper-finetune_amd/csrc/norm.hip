@@ -331,7 +331,7 @@ extern "C" int wft_layernorm_fwd(const wft_bf16* x, const float* gamma, const fl
   // tensor is larger than the caches could keep for the consumer anyway (5.4 -> 6.5 TB/s at 68 x 1500 x 1280);
   // VAR 0 (no prefetch, 3.4 TB/s) only through WFT_LN_FWD_VAR for A/B runs
   static int forced = -2;
-  if (forced == -2) { const char* e = getenv("WFT_LN_FWD_VAR"); forced = e ? atoi(e) : -1; }
+  if (forced == -2) { const char* e = wft_dev_getenv("WFT_LN_FWD_VAR"); forced = e ? atoi(e) : -1; }
   const int var = forced >= 0 ? forced : ((long)rows * cols * 2 >= LN_NT_BYTES ? 2 : 1);
 #define LN_FWD_LAUNCH_V(NQV, V)                                                                                     \
   hipLaunchKernelGGL((ln_fwd_kernel<NQV, V>), dim3(ln_fwd_grid<NQV, V>(rows)), dim3(256), 0, (hipStream_t)stream, x, gamma, \
@@ -361,7 +361,7 @@ extern "C" int wft_layernorm_bwd(const wft_bf16* dy, const wft_bf16* x, const fl
   if (!want_params && !dx_colsum) partial = nullptr;  // nothing to reduce: the kernel stops after dx, no reduce launches
   // VAR 2 (non-temporal dy / x / dres loads and dx stores) for tensors the caches cannot keep; WFT_LN_BWD_VAR forces one
   static int forced = -2;
-  if (forced == -2) { const char* e = getenv("WFT_LN_BWD_VAR"); forced = e ? atoi(e) : -1; }
+  if (forced == -2) { const char* e = wft_dev_getenv("WFT_LN_BWD_VAR"); forced = e ? atoi(e) : -1; }
   const int var = forced >= 0 ? forced : ((long)rows * cols * 2 >= LN_NT_BYTES ? 2 : 0);
 #define LN_BWD_LAUNCH_V(DX, NCV, V)                                                                                 \
   hipLaunchKernelGGL((ln_bwd_kernel<DX, NCV, V>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean, rstd, \

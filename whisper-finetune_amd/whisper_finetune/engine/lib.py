@@ -98,6 +98,7 @@ SIGNATURES = {
     "wft_gemm_nt_variant": [C.POINTER(GemmArgs)],
     "wft_gemm_set_nt_variant": [C.c_int],
     "wft_gemm_set_tn_variant": [C.c_int],
+    "wft_gemm_set_persistent": [C.c_int],
     "wft_gemm_nt_colsum_workspace_bytes": [C.POINTER(GemmArgs)],
     "wft_gemm_tn_bf16": [C.POINTER(GemmArgs), c_vp],
     "wft_gemm_nt_rank_pair_bf16": [C.POINTER(GemmArgs), C.POINTER(GemmArgs), c_vp],
@@ -109,6 +110,7 @@ SIGNATURES = {
     "wft_attn_set_dkdv_variant": [C.c_int],
     "wft_attn_set_dq_variant": [C.c_int],
     "wft_attn_set_fwd_variant": [C.c_int],
+    "wft_attn_set_persistent": [C.c_int],
     "wft_embed_fwd": [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, C.c_int, c_i64, c_vp],
     "wft_embed_bwd": [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, C.c_int, c_i64, c_vp],
     "wft_ce_fwd": [c_vp, c_i64, c_vp, c_i64, c_i64, C.c_float, c_vp, c_vp, c_vp, c_vp, c_vp],
