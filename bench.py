@@ -28,6 +28,8 @@ and, on the default (headline) invocation, extra keys measured in the same proce
                              timestamp tokens every 16th position, B = 64 — SURVEY.md §8d config 5),
   "entrypoint_loop":         scripts/finetune.py's real loop (SyntheticDataset -> DataLoader workers -> GpuMelLoader ->
                              train_step, tools/e2e_entrypoint.py) at B = 32 next to the same batches replayed from HBM.
+  "ddp_mode_1gpu":           the headline re-timed in the WORLD_SIZE > 1 launch configuration on this one GPU (DDP wrapper + per-tile
+                             launches), with and without a side-stream kernel that holds CUs and moves the ring's bytes,
   "cpu_baseline_small_models": the oracle's step for whisper-tiny / whisper-base (B = 2) on all host cores and on one.
 `ms_per_step` is the mean over the K timed steps (the contract's clock); `ms_per_step_median` is the median of the per-step
 wall times inside that region (train_step ends with loss.item()).  `--no-extras` prints the headline only.
@@ -265,7 +267,7 @@ class Case:
             return (2.0 * (f_fwd - f_att) + 3.0 * f_att + 3.0 * lora_flops_per_clip(self.dims, S, 16)) * B
         return 3.0 * f_fwd * B
 
-    def measure(self, B, S, steps, warmup, roofline=True, hand_rolled_steps=0):
+    def measure(self, B, S, steps, warmup, roofline=True, hand_rolled_steps=0, ddp_twin=True):
         """-> dict(value, ms_per_step, ...) for `B` clips per GPU and decoder length S; max over ranks of the wall time of
         exactly `steps` optimizer steps between barrier + synchronize."""
         import whisper_finetune.runtime as rt
@@ -320,25 +322,38 @@ class Case:
         tf = self.step_flops(B, S) / (dt / steps) / 1e12
         res["step_tflops_per_gpu"] = round(tf, 1)
         res["step_frac_of_bf16_peak"] = round(tf / PEAK_BF16_TFLOPS, 4)
-        if self.ddp:
+        if self.ddp and ddp_twin:
             # The multi-GPU line describes itself: ranks, bucket size, and what the gradient exchange costs in
-            # the step — the same step under no_sync() (no all-reduce, gradients stay local) timed right behind the timed region;
-            # the difference is the exposed communication + reducer work (the part NOT hidden under the backward).
-            nosync_steps = min(3, steps)
-            self.fence()
-            t0 = time.perf_counter()
-            for _ in range(nosync_steps):
-                with net.no_sync():
-                    step()
-            self.fence()
-            t = torch.tensor([(time.perf_counter() - t0) / nosync_steps], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            import os as _os
+            # the step.  Forward + backward only (no optimizer step: under no_sync() every rank would apply its local, un-reduced
+            # gradients and the replicas would diverge for the rest of the run — ADVICE r4), once with the all-reduce and once under
+            # no_sync(), one untimed warm-up pass each; the difference is the exposed communication + reducer work (the part NOT
+            # hidden under the backward).
+            import contextlib
+
+            def fwd_bwd(sync: bool):
+                with (contextlib.nullcontext() if sync else net.no_sync()):
+                    mel = frontend(audio, training=True)
+                    net(mel, y_in, targets=y_out, label_smoothing=0.1).backward()
+                opt.zero_grad(set_to_none=True)
+
+            twin = {}
+            for sync in (True, False):
+                fwd_bwd(sync)
+                self.fence()
+                t0 = time.perf_counter()
+                for _ in range(min(3, steps)):
+                    fwd_bwd(sync)
+                self.fence()
+                t = torch.tensor([(time.perf_counter() - t0) / min(3, steps)], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                twin[sync] = t.item() * 1e3
+            from whisper_finetune.engine import lib as L_
+
             res["ddp"] = {"rccl_ranks": self.world, "bucket_cap_mb": 64, "gradient_as_bucket_view": True,
-                          "nt_persistent_launches": _os.environ.get("WFT_NT256_PERSISTENT", "1") != "0",
-                          "attn_persistent_launches": _os.environ.get("WFT_ATTN_PERSISTENT", "1") != "0",
-                          "ms_per_step_no_sync": round(t.item() * 1e3, 2),
-                          "exposed_exchange_ms": round(dt / steps * 1e3 - t.item() * 1e3, 2)}
+                          "nt_persistent_launches": bool(L_.load().wft_gemm_set_persistent(-1)),
+                          "attn_persistent_launches": bool(L_.load().wft_attn_set_persistent(-1)),
+                          "fwd_bwd_ms_all_reduce": round(twin[True], 2), "fwd_bwd_ms_no_sync": round(twin[False], 2),
+                          "exposed_exchange_ms": round(twin[True] - twin[False], 2)}
         if hand_rolled_steps > 0:
             self.fence()
             t0 = time.perf_counter()
@@ -388,6 +403,86 @@ class Case:
 
         gc.collect()
         torch.cuda.empty_cache()
+
+
+def ddp_mode_1gpu(case, B, S, plain_ms):
+    """the WORLD_SIZE = 8 launch configuration as a measured mode on ONE GPU.  The headline model is wrapped in
+    DDP over a 1-rank RCCL group (what WFT_BENCH_FORCE_DDP=1 does) and re-timed with per-tile NT / dK/dV launches (what
+    engine/lib.py selects when WORLD_SIZE > 1) and with persistent ones, each (a) with the 1-rank all-reduce and (b) with a DDP
+    communication hook that launches, per 64 MB gradient bucket and on a side stream, a kernel that HOLDS `thief_cus` CUs and
+    moves the bytes an 8-rank ring moves for that bucket (2 * 7/8 of it, read and written) paced at `thief_gbps` — RCCL's
+    footprint on this rank (10.8 GB per step).  "persistent vs per-tile under a CU thief" is decided by these four
+    numbers, not by a comment."""
+    import ctypes
+
+    from torch.nn.parallel import DistributedDataParallel as DDP
+
+    from whisper_finetune.engine import lib as L
+
+    lib = L.load()
+    dev = case.device
+    thief_cus, thief_gbps = 24, 250.0
+    side_lib = ctypes.CDLL(str(ROOT / "whisper-finetune_amd" / "libwft_bench.so"))
+    side_lib.wft_bench_cu_thief.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_long, ctypes.c_int,
+                                            ctypes.c_double, ctypes.c_void_p]
+    own_pg = not dist.is_initialized()
+    if own_pg:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29534")
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    scratch = torch.empty(2, 256 << 20, dtype=torch.uint8, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    moved = [0]
+
+    def thief_hook(state, bucket):
+        buf = bucket.buffer()
+        nbytes = int(buf.numel() * buf.element_size() * 2 * 7 / 8)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            rc = side_lib.wft_bench_cu_thief(scratch[0].data_ptr(), scratch[1].data_ptr(), scratch[0].numel(), nbytes, thief_cus,
+                                             thief_gbps, ctypes.c_void_p(side.cuda_stream))
+            assert rc == 0, rc
+            moved[0] += nbytes
+            fut = torch.futures.Future(devices=[dev])
+            fut.set_result(buf)  # (a CUDA-aware future: consumers wait for the side stream's work up to here)
+        return fut
+
+    out = {"batch": B, "seq_len": S, "plain_ms_per_step": plain_ms, "thief_cus": thief_cus, "thief_gbps": thief_gbps,
+           "what": "headline workload under DDP (1-rank RCCL group, gradient_as_bucket_view, 64 MB buckets); per_tile = "
+                   "wft_gemm_set_persistent(0) + wft_attn_set_persistent(0), the launch modes of a WORLD_SIZE > 1 job; thief = a "
+                   "side-stream kernel per gradient bucket holding thief_cus CUs and copying 2*7/8 of the bucket at thief_gbps"}
+    old = (lib.wft_gemm_set_persistent(-1), lib.wft_attn_set_persistent(-1))
+    saved = (case.net, case.ddp)
+    try:
+        for thief in (False, True):
+            case.net = DDP(case.model, device_ids=[case.local_rank], output_device=case.local_rank, broadcast_buffers=False,
+                           gradient_as_bucket_view=True, bucket_cap_mb=64)
+            case.ddp = True
+            if thief:
+                case.net.register_comm_hook(None, thief_hook)
+            for mode, flag in (("per_tile", 0), ("persistent", 1)):
+                lib.wft_gemm_set_persistent(flag)
+                lib.wft_attn_set_persistent(flag)
+                moved[0] = 0
+                r = case.measure(B, S, 3, 1, roofline=False, ddp_twin=(not thief and mode == "per_tile"))
+                key = f"ddp_{mode}" + ("_thief" if thief else "")
+                out[key + "_ms_per_step"] = r["ms_per_step"]
+                if thief:
+                    out["thief_gb_per_step"] = round(moved[0] / 4 / 1e9, 2)  # (3 timed + 1 warm-up step)
+                if "ddp" in r:
+                    out["exposed_exchange_ms_1rank"] = r["ddp"]["exposed_exchange_ms"]
+            case.net = None
+        out["hbm_peak_gib_under_ddp"] = round(torch.cuda.max_memory_allocated() / 2**30, 1)
+        out["ddp_mode_overhead_pct"] = round((out["ddp_per_tile_ms_per_step"] / plain_ms - 1.0) * 100.0, 2)
+        out["per_tile_vs_persistent_under_thief_pct"] = round((out["ddp_per_tile_thief_ms_per_step"] / out["ddp_persistent_thief_ms_per_step"] - 1.0) * 100.0, 2)
+    finally:
+        lib.wft_gemm_set_persistent(old[0])
+        lib.wft_attn_set_persistent(old[1])
+        case.net, case.ddp = saved
+        del scratch
+        if own_pg:
+            dist.destroy_process_group()
+    return out
 
 
 def main():
@@ -447,6 +542,10 @@ def main():
         # S = 128 and the max-context stress S = 448; same model / optimizer state, 2 + 4 steps each
         for b2, s2 in ((32, 128), (32, 448)):
             other.append(case.measure(b2, s2, 4, 2, roofline=False))
+        try:
+            ddp_block = ddp_mode_1gpu(case, B, S, head["ms_per_step"])
+        except Exception as exc:  # informative; never lose the headline over it
+            ddp_block = {"failed": repr(exc)}
         mode = case.mode()
         dims = case.dims
         case.release()
@@ -480,7 +579,7 @@ def main():
         torch.cuda.empty_cache()
     else:
         mode, dims = case.mode(), case.dims
-        base_line = turbo_line = entry_line = None
+        base_line = turbo_line = entry_line = ddp_block = None
 
     if rank == 0:
         out = {
@@ -504,6 +603,8 @@ def main():
             out["ddp"] = head["ddp"]  # multi-GPU (or WFT_BENCH_FORCE_DDP=1): ranks, bucket size, the no_sync twin, exposed exchange
         if "hand_rolled_ms_per_step" in head:
             out["hand_rolled_ms_per_step"] = head["hand_rolled_ms_per_step"]  # round 1's loop, 3 steps: cross-check of the product loop
+        if ddp_block is not None:
+            out["ddp_mode_1gpu"] = ddp_block
         if other:
             out["reference_yaml_shapes"] = other
         if lora_line is not None:

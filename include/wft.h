@@ -208,6 +208,14 @@ typedef struct {
    *    off-diagonal blocks are not stored): dB of adapter b of a group of equally shaped Linears, as [out, r] row-major. */
   const float* tn_col_scale; int tn_scale_rows;
   int tn_block_n; int tn_block_r;
+  /* wft_gemm_tn_bf16 on its 256x256 paths (ask wft_gemm_tn_segments_ok): tn_seg_count in 1..4 row ranges of the product go to
+   * SEPARATE contiguous f32 [rows_i][Q] destinations instead of C — tn_seg_ptr[i] receives rows [tn_seg_end[i-1], tn_seg_end[i])
+   * (tn_seg_end[count-1] = P) — with `accumulate` read-modify-write like C.  One weight-gradient GEMM of a fused Linear group
+   * (q, k, v share one [3d, d] product) then writes each parameter's gradient where it lives: the `gradient_as_bucket_view` slices
+   * of torch DDP's buckets (reference: scripts/finetune.py:698-705), no copy between the last dW GEMM and the bucket's all-reduce.
+   * Always through the workspace (wft_gemm_tn_workspace_bytes with these fields set), summed by the reduce kernel in the same
+   * fixed order as the unsegmented call: bit-identical values.  C must still be a valid pointer (it is not written).           */
+  int tn_seg_count; int tn_seg_end[4]; float* tn_seg_ptr[4];
 } wft_gemm_args;
 int wft_gemm_nt_bf16(const wft_gemm_args* args, void* stream);
 /* Which 256x256 NT kernel serves the encoder-sized problems: 0 (default) = the one-wave-per-SIMD kernel (csrc/gemm_nt4w.hip)
@@ -228,6 +236,9 @@ int wft_gemm_set_persistent(int v);
  * accumulators each), 256 (gemm_nt256_kernel, the 8-wave ping-pong 256x256 kernel) or 128 (gemm_nt_kernel).  Pure host
  * function (used by bench.py to attribute HIP-event timings to the kernel names rocprofv3 reports).        */
 int wft_gemm_nt_variant(const wft_gemm_args* args);
+/* 1 if wft_gemm_tn_bf16 takes these arguments' tn_seg_* fields (a 256x256 weight-gradient path, f32 C, no rank-r forms, a
+ * well-formed segment list), 0 if the caller has to use C and copy.  Pure host function.                                    */
+int wft_gemm_tn_segments_ok(const wft_gemm_args* args);
 int64_t wft_gemm_nt_colsum_workspace_bytes(const wft_gemm_args* args);
 /* C[p, q] (+)= alpha * sum_r A[r, p] * B[r, q]   (weight gradients dW = dY^T X:
  * what autograd's mm-backward computes for whisper.model.Linear).

@@ -226,3 +226,78 @@ def ddp_engine_two_rank_worker(rank, world, port, out):
     dist.barrier()
     dist.destroy_process_group()
     out.put((rank, loss, rloss, worst, same, n_local_unused))
+
+
+def ddp_grad_homes_worker(rank, world, port, out):
+    """whisper-base (d = 512: its weight-gradient GEMMs run on the 256x256 paths at 12 clips) under DDP on a 1-rank RCCL group with
+    gradient_as_bucket_view and local accumulation 2: from the third optimizer step on (DDP rebuilds its buckets after the first
+    iteration, the optimizer notes the new views at the second step) every large weight gradient is written by the GEMM's reduce
+    kernel straight into its bucket view — no reducer copy — and the parameters equal the run without DDP bit for bit."""
+    _setup(rank, world, port, "nccl")
+    import torch
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    import whisper_finetune.runtime as rt
+    from oracle import whisper_oracle as O
+    from whisper_finetune.engine import kernels as K
+    from whisper_finetune.engine.whisper_model import ModelDimensions, Whisper
+    from whisper_finetune.model import model_utils
+    from whisper_finetune.model.optimizer import WftAdamW
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    dims = O.DIMS["base"]
+    params = O.init_params(dims, seed=3)
+    audio, y_in, y_out = O.synthetic_batch(dims, 12, 16)
+    mel = K.logmel(audio.to(dev), O.mel_filters(dims.n_mels).to(dev))
+    y_in, y_out = y_in.to(dev), y_out.to(dev)
+    t_cfg = {"mixed_precision_training": True, "accum_grad_steps": 2, "max_grad_norm": 1.0, "mp_dtype": "bf16", "label_smoothing": 0.1}
+
+    def batches():
+        while True:
+            yield mel, y_in, y_out
+
+    seg_calls = {"n": 0, "acc": 0}
+    real_tn = K.gemm_tn
+
+    def counting_tn(*a, **kw):
+        r = real_tn(*a, **kw)
+        if kw.get("seg_out") is not None and r is not None:
+            seg_calls["n"] += 1
+            seg_calls["acc"] += int(bool(kw.get("accumulate")))
+        return r
+
+    def run(wrap):
+        m = Whisper(ModelDimensions(**vars(dims)))
+        m.load_state_dict(params)
+        m.to(dev)
+        model = DDP(m, device_ids=[0], output_device=0, broadcast_buffers=False, gradient_as_bucket_view=True, bucket_cap_mb=64) if wrap else m
+        opt = WftAdamW(m.parameters(), lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.1)
+        sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: 1.0)
+        rt.IS_DISTRIBUTED = wrap
+        K.gemm_tn = counting_tn
+        import whisper_finetune.engine.ops as ops
+        alias = []
+        try:
+            for step in range(4):
+                seg_calls["n"] = seg_calls["acc"] = 0
+                copies = {"n": 0}
+                model_utils.train_step(model, batches(), opt, sched, dict(t_cfg))
+                big = [p for n, p in m.named_parameters() if p.dim() == 2 and p.shape[0] % 256 == 0 and p.shape[1] % 256 == 0
+                       and "embedding" not in n]
+                homes = [p.__dict__.get("_wft_grad_home") for p in big]
+                # a home that is a slice of a larger storage = a bucket view (a plain gradient tensor owns its storage)
+                alias.append((seg_calls["n"], seg_calls["acc"],
+                              sum(1 for h in homes if h is not None and h.untyped_storage().nbytes() > h.numel() * 4), len(big)))
+        finally:
+            K.gemm_tn = real_tn
+            rt.IS_DISTRIBUTED = False
+        return {n: p.detach().clone() for n, p in m.named_parameters()}, alias
+
+    p_plain, a_plain = run(False)
+    p_ddp, a_ddp = run(True)
+    worst = max((p_plain[n] - p_ddp[n]).abs().max().item() for n in p_plain)
+    dist.barrier(device_ids=[0])
+    dist.destroy_process_group()
+    out.put((rank, worst, a_plain, a_ddp))

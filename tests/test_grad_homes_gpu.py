@@ -1,0 +1,97 @@
+"""Gradient homes (engine/ops.py `note_grad_homes`, wft.h tn_seg_*): the weight-gradient GEMM of a fused Linear group writes each
+parameter's gradient where it lives.  Reference behaviour: torch DDP with gradient_as_bucket_view=True keeps gradients as slices of
+its buckets (scripts/finetune.py:698-705); values must not depend on where they are written."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from whisper_finetune.engine import kernels as K  # noqa: E402
+from whisper_finetune.engine import lib as L  # noqa: E402
+
+DEV = torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("variant", [0, 1])           # 0: gemm_tn4w_kernel, 1: gemm_tn256_kernel
+@pytest.mark.parametrize("R", [20000, 16500])         # two split-K plans; 16500: a ragged last reduction step
+def test_segmented_weight_gradient_equals_the_sliced_one_bit_for_bit(variant, R):
+    lib = L.load()
+    old = lib.wft_gemm_set_tn_variant(variant)
+    try:
+        torch.manual_seed(R + variant)
+        dy = torch.randn(R, 1536, device=DEV).bfloat16()
+        x = torch.randn(R, 512, device=DEV).bfloat16()
+        full = K.gemm_tn(dy, x)
+        segs = [torch.full((512, 512), float("nan"), device=DEV) for _ in range(3)]
+        got = K.gemm_tn(dy, x, seg_out=segs)
+        if got is None:
+            pytest.skip("this shape does not run on a 256x256 weight-gradient path")
+        for i, s in enumerate(segs):
+            assert torch.equal(s, full[512 * i:512 * (i + 1)])
+        # uneven segments, accumulating: C += product in the same order as the unsegmented accumulating call
+        base = torch.randn(1536, 512, device=DEV)
+        want = K.gemm_tn(dy, x, out=base.clone(), accumulate=True)
+        segs = [base[:256].clone(), base[256:1280].clone(), base[1280:].clone()]
+        assert K.gemm_tn(dy, x, seg_out=segs, accumulate=True) is not None
+        assert torch.equal(torch.cat(segs), want)
+    finally:
+        lib.wft_gemm_set_tn_variant(old)
+
+
+def test_unsegmentable_calls_are_refused_by_the_query_not_by_an_error():
+    dy = torch.randn(512, 384, device=DEV).bfloat16()   # whisper-tiny: 128-tile path
+    x = torch.randn(512, 384, device=DEV).bfloat16()
+    segs = [torch.empty(384, 384, device=DEV)]
+    assert K.gemm_tn(dy, x, seg_out=segs) is None
+    a, _ = K.gemm_tn(torch.randn(20000, 512, device=DEV).bfloat16(), torch.randn(20000, 512, device=DEV).bfloat16(), _args_only=True)
+    a.tn_seg_count = 2
+    a.tn_seg_end[0], a.tn_seg_end[1] = 256, 500          # does not end at P
+    a.tn_seg_ptr[0] = a.tn_seg_ptr[1] = a.C
+    assert L.load().wft_gemm_tn_segments_ok(a) == 0
+
+
+def test_training_with_gradient_homes_matches_fresh_gradient_tensors():
+    """whisper-base, 12 clips, accumulation 2, four optimizer steps: homes on (gradients written / accumulated in place by the reduce
+    kernel) against WFT_GRAD_HOMES=0 (autograd's own tensors and adds).  The second micro-batch's sum is (g + s0) + s1 + ... instead of
+    g + (s0 + s1 + ...): fp32 rounding only."""
+    from oracle import whisper_oracle as O
+    from whisper_finetune.engine import ops
+    from whisper_finetune.engine.whisper_model import ModelDimensions, Whisper
+    from whisper_finetune.model import model_utils
+    from whisper_finetune.model.optimizer import WftAdamW
+
+    dims = O.DIMS["base"]
+    params = O.init_params(dims, seed=3)
+    audio, y_in, y_out = O.synthetic_batch(dims, 12, 16)
+    mel = K.logmel(audio.to(DEV), O.mel_filters(dims.n_mels).to(DEV))
+    y_in, y_out = y_in.to(DEV), y_out.to(DEV)
+    t_cfg = {"mixed_precision_training": True, "accum_grad_steps": 2, "max_grad_norm": 1.0, "mp_dtype": "bf16", "label_smoothing": 0.1}
+
+    def batches():
+        while True:
+            yield mel, y_in, y_out
+
+    def run(homes: bool):
+        old = ops._GRAD_HOMES
+        ops._GRAD_HOMES = homes
+        try:
+            m = Whisper(ModelDimensions(**vars(dims)))
+            m.load_state_dict(params)
+            m.to(DEV)
+            opt = WftAdamW(m.parameters(), lr=1e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.1)
+            sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: 1.0)
+            losses = [model_utils.train_step(m, batches(), opt, sched, dict(t_cfg)) for _ in range(4)]
+            n_home = sum(1 for p in m.parameters() if "_wft_grad_home" in p.__dict__)
+            return losses, {n: p.detach().clone() for n, p in m.named_parameters()}, n_home
+        finally:
+            ops._GRAD_HOMES = old
+
+    l0, p0, h0 = run(False)
+    l1, p1, h1 = run(True)
+    assert h0 == 0 and h1 > 30
+    assert l0[0] == l1[0]
+    for a, b in zip(l0, l1):
+        assert a == pytest.approx(b, rel=1e-5)
+    for n in p0:
+        err = ((p0[n] - p1[n]).norm() / (p0[n].norm() + 1e-20)).item()
+        assert err < 1e-5, (n, err)

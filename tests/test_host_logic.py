@@ -314,6 +314,116 @@ def test_lora_mask_pool_draws_once_per_forward_and_is_dropped_on_merge():
     assert not m.encoder._forward_pre_hooks and not m.decoder._forward_pre_hooks
 
 
+def test_deepcopy_of_a_lora_model_owns_its_pool_and_forward_loss():
+    """a deep copy of a LoRA model (EMA / teacher / eval-on-a-copy) must evaluate the COPY: its forward_loss shadow, its
+    hooks and its adapters all refer to the copy's own pool, the pool's root is the copy, the original is untouched, and merging
+    the copy drops the copy's hooks only."""
+    import copy
+
+    m = _tiny()
+    lora.apply_lora(m, {"rank": 4, "lora_alpha": 8, "lora_dropout": 0.5})
+    c = copy.deepcopy(m)
+    pm, pc = m.__dict__["_wft_lora_pool"], c.__dict__["_wft_lora_pool"]
+    assert pc is not pm and pc.root is c and pm.root is m
+    fl = c.__dict__["forward_loss"]
+    assert fl.__self__ is pc and fl.__func__ is lora.LoraMaskPool._forward_loss       # a bound method of the copy's pool
+    assert m.__dict__["forward_loss"].__self__ is pm
+    ads_m = [mod.parametrizations.weight[0] for mod in m.modules() if "parametrizations" in mod._modules]
+    ads_c = [mod.parametrizations.weight[0] for mod in c.modules() if "parametrizations" in mod._modules]
+    assert all(a._pool is pc for a in ads_c) and all(a._pool is pm for a in ads_m)
+    assert [id(a) for a in pc.adapters] == [id(a) for a in ads_c]
+    hooks = list(c._forward_pre_hooks.values()) + list(c._forward_hooks.values()) + list(c.encoder._forward_pre_hooks.values())
+    assert hooks and all(h.__self__ is pc for h in hooks)
+    # a draw on the copy does not touch the original's pool, and the copy's adapters read the copy's masks
+    c.train(); m.train()
+    serial_m, depth_m = pm.serial, pm.depth
+    pc._on_root_forward(c, ())
+    assert pc.depth == 1 and pm.depth == depth_m and pm.serial == serial_m and pm.buf is None
+    mk = ads_c[3].draw_mask(True)
+    assert mk.untyped_storage().data_ptr() == pc.store.untyped_storage().data_ptr() and ads_m[3]._pool.buf is None
+    pc._after_root_forward(c, (), None)
+    lora.merge_lora(c)
+    assert "forward_loss" not in c.__dict__ and not c._forward_pre_hooks and not c.encoder._forward_pre_hooks
+    assert len(m._forward_pre_hooks) == 1 and len(m.encoder._forward_pre_hooks) == 1 and "forward_loss" in m.__dict__
+
+
+def test_grad_fork_sums_like_autograd_in_partial_repeated_and_aborted_passes():
+    """ops.GradAccum counted arrivals against every consumer ever registered — a partial backward, two decoder passes with
+    different skips or an aborted pass handed the sum over early and lost the tail.  The fork node (ops.grad_fork) counts nothing:
+    consumers add into the running sum and return None, autograd runs the fork's backward after the consumers of THIS pass.  A CPU
+    stand-in consumer (the real one is LinearFn's backward-data GEMM) against plain autograd."""
+    from whisper_finetune.engine import ops
+
+    class Consumer(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w, accum, fail):
+            ctx.save_for_backward(x, w)
+            ctx.accum, ctx.fail = accum, fail
+            return x * w
+
+        @staticmethod
+        def backward(ctx, g):
+            x, w = ctx.saved_tensors
+            if ctx.fail and ctx.fail.pop():
+                raise RuntimeError("boom")
+            def dx_fn(run):
+                return (g * w).clone() if run is None else run.add_(g * w)
+            return ctx.accum.arrive(dx_fn), (g * x).sum(), None, None
+
+    def build(use_fork, fail=None):
+        x = torch.arange(1.0, 5.0, requires_grad=True)
+        enc = x * 2
+        ws = [torch.tensor(float(i + 1), requires_grad=True) for i in range(4)]
+        if use_fork:
+            xf, acc = ops.grad_fork(enc)
+            assert ops.grad_fork(enc)[0] is xf  # cached on the tensor object: every consumer reads the same fork
+            outs = [Consumer.apply(xf, w, acc, fail) for w in ws]
+        else:
+            xf = enc
+            outs = [enc * w for w in ws]
+        return x, xf, ws, outs
+
+    # 1. every consumer, plus an ordinary autograd user of the forked tensor
+    for extra in (False, True):
+        ref = build(False)
+        got = build(True)
+        for x, xf, ws, outs in (ref, got):
+            loss = sum(o.sum() for o in outs) + ((xf * 10).sum() if extra else 0)
+            loss.backward()
+        assert torch.equal(ref[0].grad, got[0].grad) and all(torch.equal(a.grad, b.grad) for a, b in zip(ref[2], got[2]))
+    # 2. a partial pass (two of four consumers: stochastic-depth skips), then the other two in a second pass over the same graph
+    ref, got = build(False), build(True)
+    for x, xf, ws, outs in (ref, got):
+        (outs[0].sum() + outs[2].sum()).backward(retain_graph=True)
+        first = x.grad.clone()
+        (outs[1].sum() + outs[3].sum()).backward()
+        x.first = first
+    assert torch.equal(ref[0].first, got[0].first) and torch.equal(ref[0].grad, got[0].grad)
+    # 3. a pass that never reaches the fork (inputs = one consumer's weight) leaves a sum behind: the next pass drops it
+    ref, got = build(False), build(True)
+    for x, xf, ws, outs in (ref, got):
+        loss = sum(o.sum() for o in outs)
+        torch.autograd.grad(loss, [ws[0]], retain_graph=True)
+        loss.backward()
+    assert torch.equal(ref[0].grad, got[0].grad)
+    # 4. an exception in the middle of a pass, then a clean pass
+    fail = [False, True, False]  # (popped from the end: the second consumer to run raises)
+    x, xf, ws, outs = build(True, fail)
+    loss = sum(o.sum() for o in outs)
+    try:
+        loss.backward(retain_graph=True)
+    except RuntimeError as e:
+        assert "boom" in str(e)
+    else:
+        raise AssertionError("expected the injected failure")
+    x.grad = None
+    for w in ws:
+        w.grad = None
+    fail.clear()
+    loss.backward()
+    assert torch.equal(x.grad, torch.full((4,), 2.0 * (1 + 2 + 3 + 4)))
+
+
 def test_optimizer_post_hook_only_counts_optimizers_that_own_shadowed_parameters():
     """engine/ops.py: torch's fused optimizers do not bump tensor._version, so an optimizer step invalidates the bf16 weight
     shadows through a global post-hook — scoped to optimizers that own a parameter the engine has shadowed: an

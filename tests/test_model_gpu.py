@@ -805,3 +805,44 @@ def test_encoder_output_gradient_accumulated_in_the_gemm_epilogues():
         assert enc and all(g0[n].abs().sum() > 0 for n in enc if "blocks.0.attn.query.weight" in n)
         for n in g0:
             assert rel(g1[n], g0[n]) < (1e-2 if n.startswith("encoder.") else 1e-6), (n, sd, recompute, rel(g1[n], g0[n]))
+
+
+def test_encoder_output_gradient_fork_survives_two_decoder_passes_and_partial_backwards():
+    """ADVICE r4 on ops.GradAccum: (1) two decoder passes over ONE encoder output with different stochastic-depth skips (31 + 31
+    arrivals against 32 registered ids used to hand the sum over early and drop the rest); (2) `autograd.grad(inputs=subset)` in
+    front of the real backward used to leave a count behind.  With the fork node both give the encoder the gradient autograd's own
+    summation gives (WFT_XA_ACCUM=0 twin, same skip draws)."""
+    from whisper_finetune.engine import whisper_model as WM
+    from whisper_finetune.model.model_utils import CheckpointedStochasticTextDecoder
+    dims, params, audio, y_in, y_out = _tiny_case()
+    mel = K.logmel(audio.to(DEV), O.mel_filters(dims.n_mels).to(DEV))
+
+    def run(accum: bool):
+        old = WM._XA_ACCUM
+        WM._XA_ACCUM = accum
+        try:
+            m = Whisper(MODEL_DIMS["tiny"])
+            m.decoder = CheckpointedStochasticTextDecoder(dims.n_vocab, dims.n_text_ctx, dims.n_text_state, dims.n_text_head,
+                                                          dims.n_text_layer, 0.5)
+            m.decoder.recompute = False
+            m.load_state_dict(params)
+            m.to(DEV).train()
+            torch.manual_seed(7)
+            xa = m.encoder(mel)
+            la = m.decoder(y_in.to(DEV), xa).float()          # two passes of the decoder over one encoder output: the skip draws differ
+            lb = m.decoder(y_in.flip(1).to(DEV), xa).float()
+            loss = la.square().mean() + lb.square().mean()
+            # a partial pass first: gradients of one decoder weight only — the fork node is not part of it
+            w = m.decoder.blocks[0].cross_attn.key.weight
+            (gw,) = torch.autograd.grad(loss, [w], retain_graph=True, allow_unused=True)
+            loss.backward()
+            return {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}, gw
+        finally:
+            WM._XA_ACCUM = old
+
+    g0, w0 = run(False)
+    g1, w1 = run(True)
+    assert g0.keys() == g1.keys() and any(n.startswith("encoder.") for n in g0)
+    assert (w0 is None) == (w1 is None) and (w0 is None or rel(w1, w0) < 1e-6)
+    for n in g0:
+        assert rel(g1[n], g0[n]) < (1e-2 if n.startswith("encoder.") else 1e-6), (n, rel(g1[n], g0[n]))

@@ -1300,7 +1300,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmP p) {
   if (!grp_b) __builtin_amdgcn_s_barrier();
 
   // D[q][p]: lane (li, g) holds acc[i][j][e] = C[p = j*16 + li][q = i*16 + 4g + e] of the wave tile
-  if (nsplit > 1) {
+  if (nsplit > 1 || p.ws) {  // (a workspace with ONE split: segmented output, written by the reduce kernel)
     float* lds = (float*)(dsmem + wave * 8448);  // [16 p][132] fp32 per pass
     if (p.ws) {
       // deterministic split-K: this split's partial tile goes to the workspace with plain 16-byte stores
@@ -1407,6 +1407,23 @@ __global__ __launch_bounds__(256) void tn_splitk_reduce_kernel(const float* ws, 
                                                                 int accumulate, int Pz, const float* col_scale, int scale_rows,
                                                                 int blk_n, int blk_r, int Pv) {
   tn_splitk_reduce_body(ws, C, ldc, P, Q, nsplit, accumulate, Pz, col_scale, scale_rows, blk_n, blk_r, Pv, (long)blockIdx.x, (long)gridDim.x);
+}
+// the plain form with SEGMENTED output (wft_gemm_args tn_seg_*): row range i of the product goes to its own contiguous [rows][Q]
+// tensor — each parameter of a fused Linear group gets its gradient where it lives (a DDP bucket view).  Same order of additions
+// as tn_splitk_reduce_body: C first when accumulating, then the splits in index order.
+struct TnSegs { float* ptr[4]; int end[4]; };
+__global__ __launch_bounds__(256) void tn_splitk_reduce_seg_kernel(const float* ws, TnSegs sg, int P, int Q, int nsplit, int accumulate) {
+  const long nq4 = Q >> 2;
+  const long total = (long)P * nq4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long pp = i / nq4, q4 = (i - pp * nq4) * 4;
+    int sgi = 0, start = 0;
+    while (sgi < 3 && pp >= sg.end[sgi]) start = sg.end[sgi++];
+    float* cp = sg.ptr[sgi] + (pp - start) * Q + q4;
+    f32x4 s = accumulate ? *(const f32x4*)cp : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < nsplit; ++k) s += *(const f32x4*)(ws + ((long)k * P + pp) * Q + q4);
+    *(f32x4*)cp = s;
+  }
 }
 // both adapter gradients of a group (dA with its column scale, dB in block layout) in ONE launch: workgroups >= g0 take r1
 __global__ __launch_bounds__(256) void tn_splitk_reduce_pair_kernel(TnReduceP r0, TnReduceP r1, int g0) {
@@ -1542,7 +1559,7 @@ extern "C" int wft_gemm_nt_bf16(const wft_gemm_args* a, void* stream) {
   do {                                                                                                    \
     auto kfn = gemm_nt256_kernel<E, F>;                                                                   \
     static DynLdsOnce once;                                                                               \
-    once.set(kfn, 163840);                                                                                \
+    if (!once.set(kfn, 163840)) return WFT_ERR_LAUNCH;                                                                                \
     hipLaunchKernelGGL(kfn, grid, block, 163840, s, p);                                                   \
   } while (0)
     switch (a->epilogue) {
@@ -1574,7 +1591,7 @@ extern "C" int wft_gemm_nt_bf16(const wft_gemm_args* a, void* stream) {
     constexpr int bytes = nst * (16384 + 2048 * (PBV));                                           \
     static DynLdsOnce once;                                                                       \
     auto kfn = gemm_nt_rank_kernel<PBV>;                                                          \
-    once.set(kfn, bytes);                                                                         \
+    if (!once.set(kfn, bytes)) return WFT_ERR_LAUNCH;                                                                         \
     hipLaunchKernelGGL(kfn, g1, dim3(256), bytes, s, p, p, (int)g1.x);                            \
   }
     if (npb == 1) WFT_NT_RANK_LAUNCH(1)
@@ -1657,9 +1674,35 @@ static int64_t tn_ws_rows(const wft_gemm_args* a) {
 }
 // the adapter-gradient forms (column scale / block-transposed output) are applied by the reduce kernel: always through the workspace
 static bool tn_needs_reduce(const wft_gemm_args* a) { return a->tn_col_scale != nullptr || a->tn_block_n > 0; }
+extern "C" int wft_gemm_tn_segments_ok(const wft_gemm_args* a) {
+  if (!a || a->tn_seg_count < 1 || a->tn_seg_count > 4 || !tn_uses_256(a) || tn_needs_reduce(a) || a->p_valid != 0 || a->batch != 1) return 0;
+  int prev = 0;
+  for (int i = 0; i < a->tn_seg_count; ++i) {
+    if (a->tn_seg_end[i] <= prev || !a->tn_seg_ptr[i] || (((uintptr_t)a->tn_seg_ptr[i]) & 15) != 0) return 0;
+    prev = a->tn_seg_end[i];
+  }
+  return prev == a->M ? 1 : 0;
+}
+static TnSegs tn_segs_of(const wft_gemm_args* a) {
+  TnSegs sg;
+  for (int i = 0; i < 4; ++i) {
+    const int j = i < a->tn_seg_count ? i : a->tn_seg_count - 1;
+    sg.ptr[i] = a->tn_seg_ptr[j];
+    sg.end[i] = i < a->tn_seg_count ? a->tn_seg_end[i] : 0x7fffffff;
+  }
+  return sg;
+}
 extern "C" int64_t wft_gemm_tn_workspace_bytes(const wft_gemm_args* a) {
   if (!a) return 0;
   int nsplit = tn_uses_256(a) ? tn256_nsplit(a) : tn128_nsplit(a);
+  if (a->tn_seg_count > 0) {  // segmented output: always through the workspace, even unsplit
+    if (tn_uses_256(a) && wft_tn4w_eligible(a)) {
+      int ns4, per4;
+      wft_tn4w_plan(a, &ns4, &per4);
+      if (ns4 > nsplit) nsplit = ns4;
+    }
+    return (int64_t)nsplit * a->M * a->N * 4;
+  }
   if (tn_uses_256(a) && wft_tn4w_eligible(a)) {  // (the larger of the two plans: the variant switch may change between this call and the launch)
     int ns4, per4;
     wft_tn4w_plan(a, &ns4, &per4);
@@ -1686,6 +1729,10 @@ extern "C" int wft_gemm_tn_bf16(const wft_gemm_args* a, void* stream) {
       WFT_CHECK_ARG(a->tn_block_n % 4 == 0 && a->N % a->tn_block_n == 0 && a->tn_block_r >= 1 &&
                     (a->N / a->tn_block_n) * (int64_t)a->tn_block_r <= 16 * tn128_pb(a), "tn_block_n / tn_block_r do not tile the product");
   }
+  const bool seg = a->tn_seg_count > 0;
+  if (seg)
+    WFT_CHECK_ARG(wft_gemm_tn_segments_ok(a) && a->workspace && a->workspace_bytes >= wft_gemm_tn_workspace_bytes(a) &&
+                  (((uintptr_t)a->workspace) & 15) == 0, "tn_seg_*: not a segmentable call (wft_gemm_tn_segments_ok) or no workspace");
   GemmP p;
   fill_params(a, p);
   hipStream_t s = (hipStream_t)stream;
@@ -1693,12 +1740,19 @@ extern "C" int wft_gemm_tn_bf16(const wft_gemm_args* a, void* stream) {
   if (tn_uses_256(a) && g_tn_variant != 1 && wft_tn4w_eligible(a)) {
     int nsplit, per;
     wft_tn4w_plan(a, &nsplit, &per);
-    const bool use_ws = nsplit > 1 && a->workspace && a->workspace_bytes >= (int64_t)nsplit * a->M * a->N * 4 &&
+    const bool use_ws = (nsplit > 1 || seg) && a->workspace && a->workspace_bytes >= (int64_t)nsplit * a->M * a->N * 4 &&
                         (((uintptr_t)a->workspace) & 15) == 0;
     if (nsplit == 1 || use_ws) {  // (split without a workspace: the ping-pong kernel's atomic path below)
       if (use_ws) p.ws = (float*)a->workspace;
-      wft_tn4w_launch(a, p, nsplit, per, stream);
-      if (use_ws) {
+      const int rc4 = wft_tn4w_launch(a, p, nsplit, per, stream);
+      if (rc4 != WFT_OK) return rc4;
+      if (use_ws && seg) {
+        const long total = a->M * (a->N / 4);
+        long g = (total + 255) / 256;
+        if (g > 2048) g = 2048;
+        hipLaunchKernelGGL(tn_splitk_reduce_seg_kernel, dim3((unsigned)g), dim3(256), 0, s, (const float*)a->workspace, tn_segs_of(a),
+                           (int)a->M, (int)a->N, nsplit, a->accumulate);
+      } else if (use_ws) {
         const long total = a->M * (a->N / 4);
         long g = (total + 255) / 256;
         if (g > 2048) g = 2048;
@@ -1713,17 +1767,23 @@ extern "C" int wft_gemm_tn_bf16(const wft_gemm_args* a, void* stream) {
     // 256x256 tiles, one workgroup per CU: pick the split-K factor that fills 256 slots in whole waves
     const long t256 = (a->M / 256) * (a->N / 256);
     const int nsplit = tn256_nsplit(a);
-    const bool use_ws = nsplit > 1 && a->workspace && a->workspace_bytes >= (int64_t)nsplit * a->M * a->N * 4 &&
+    const bool use_ws = (nsplit > 1 || seg) && a->workspace && a->workspace_bytes >= (int64_t)nsplit * a->M * a->N * 4 &&
                         (((uintptr_t)a->workspace) & 15) == 0;
     if (use_ws) p.ws = (float*)a->workspace;
     if (nsplit > 1 && !use_ws && !a->accumulate)
       (void)hipMemset2DAsync(a->C, (size_t)a->ldc * 4, 0, (size_t)a->N * 4, (size_t)a->M, s);
     static DynLdsOnce once;
     auto kfn = gemm_tn256_kernel<true>;
-    once.set(kfn, WFT_TN_RING * 32768);
+    if (!once.set(kfn, WFT_TN_RING * 32768)) return WFT_ERR_LAUNCH;
     p.nsplit = g_diag == 20 ? -nsplit : nsplit;  // (WFT_GEMM_DIAG=20: round 2's tile-major placement, A/B runs)
     hipLaunchKernelGGL(kfn, dim3((unsigned)(t256 * nsplit)), dim3(512), WFT_TN_RING * 32768, s, p);
-    if (use_ws) {
+    if (use_ws && seg) {
+      const long total = a->M * (a->N / 4);
+      long g = (total + 255) / 256;
+      if (g > 2048) g = 2048;
+      hipLaunchKernelGGL(tn_splitk_reduce_seg_kernel, dim3((unsigned)g), dim3(256), 0, s, (const float*)a->workspace, tn_segs_of(a),
+                         (int)a->M, (int)a->N, nsplit, a->accumulate);
+    } else if (use_ws) {
       const long total = a->M * (a->N / 4);
       long g = (total + 255) / 256;
       if (g > 2048) g = 2048;
@@ -1753,7 +1813,7 @@ extern "C" int wft_gemm_tn_bf16(const wft_gemm_args* a, void* stream) {
     constexpr int bytes = nst * (16384 + 2048 * (PBV));                                           \
     static DynLdsOnce once;                                                                       \
     auto kfn = gemm_tn_rank_kernel<PBV>;                                                          \
-    once.set(kfn, bytes);                                                                         \
+    if (!once.set(kfn, bytes)) return WFT_ERR_LAUNCH;                                                                         \
     hipLaunchKernelGGL(kfn, g1, block, bytes, s, p, p, (int)g1.x);                                \
   }
     if (pb == 1) WFT_RANK_LAUNCH(1)
@@ -1811,7 +1871,7 @@ extern "C" int wft_gemm_nt_rank_pair_bf16(const wft_gemm_args* a0, const wft_gem
     constexpr int bytes = nst * (16384 + 2048 * (PBV));                                           \
     static DynLdsOnce once;                                                                       \
     auto kfn = gemm_nt_rank_kernel<PBV>;                                                          \
-    once.set(kfn, bytes);                                                                         \
+    if (!once.set(kfn, bytes)) return WFT_ERR_LAUNCH;                                                                         \
     hipLaunchKernelGGL(kfn, dim3((unsigned)(n0 + n1)), dim3(256), bytes, s, p0, p1, n0);          \
   }
   if (pb0 == 1) WFT_NT_RANK_PAIR(1)
@@ -1865,7 +1925,7 @@ extern "C" int wft_gemm_tn_rank_pair_bf16(const wft_gemm_args* a0, const wft_gem
     constexpr int bytes = nst * (16384 + 2048 * (PBV));                                           \
     static DynLdsOnce once;                                                                       \
     auto kfn = gemm_tn_rank_kernel<PBV>;                                                          \
-    once.set(kfn, bytes);                                                                         \
+    if (!once.set(kfn, bytes)) return WFT_ERR_LAUNCH;                                                                         \
     hipLaunchKernelGGL(kfn, dim3((unsigned)(nb[0] + nb[1])), dim3(256), bytes, s, p[0], p[1], nb[0]); \
   }
   if (pb == 1) WFT_TN_RANK_PAIR(1)

@@ -64,11 +64,16 @@ static inline int wft_num_cus() {
 struct DynLdsOnce {
   bool done[WFT_MAX_DEVICES] = {false};
   template <class K>
-  void set(K kfn, int bytes) {
+  bool set(K kfn, int bytes) {  // false (and wft_last_error says why): the caller returns WFT_ERR_LAUNCH instead of launching
     const int dev = wft_cur_device();
     if (!done[dev]) {
-      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+      const hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+      if (e != hipSuccess) {
+        wft_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d) failed on device %d: %s", bytes, dev, hipGetErrorString(e));
+        return false;
+      }
       done[dev] = true;
     }
+    return true;
   }
 };

@@ -605,7 +605,7 @@ int wft_nt4w_launch(const wft_gemm_args* a, const GemmP& p, bool persistent, voi
   do {                                                                    \
     auto kfn = gemm_nt4w_kernel<E, R, CSF>;                               \
     static DynLdsOnce once;                                               \
-    once.set(kfn, NT4W_LDS);                                              \
+    if (!once.set(kfn, NT4W_LDS)) return WFT_ERR_LAUNCH;                                              \
     hipLaunchKernelGGL(kfn, grid, block, NT4W_LDS, s, p);                 \
   } while (0)
   const bool res = a->residual != nullptr, csf = p.cs_part != nullptr;

@@ -363,7 +363,7 @@ int wft_tn4w_launch(const wft_gemm_args* a, GemmP p, int nsplit, int per, void* 
   p.band = per;  // (reused field: reduction steps per split)
   static DynLdsOnce once;
   auto kfn = gemm_tn4w_kernel;
-  once.set(kfn, TN4W_LDS);
+  if (!once.set(kfn, TN4W_LDS)) return WFT_ERR_LAUNCH;
   hipLaunchKernelGGL(kfn, dim3((unsigned)(t256 * nsplit)), dim3(256), TN4W_LDS, (hipStream_t)stream, p);
   return WFT_OK;
 }

@@ -288,14 +288,17 @@ def gemm_nt(a, b, *, M=None, N=None, K=None, lda=None, ldb=None, out=None, out_f
 
 def gemm_tn(a, b, *, P=None, Q=None, R=None, lda=None, ldb=None, out=None, out_f32=True, accumulate=False,
             alpha=1.0, batch=1, strideA=0, strideB=0, p_valid=0, col_scale=None, scale_rows=0, block_n=0, block_r=0,
-            _args_only=False, _ws_slot="tn"):
+            seg_out=None, _args_only=False, _ws_slot="tn"):
     """C[P,Q] (+)= alpha * A[R,P]^T @ B[R,Q]  (weight gradients).  p_valid (P = 128 only): columns >= p_valid of A are zero
     padding (a rank-r LoRA operand): the reduction runs in the load-stream kernel for rank-r operands (gemm.hip
     gemm_tn_rank_kernel — 4-stage LDS-DMA ring, compact A, compact split-K workspace), bit-identical to the general path.
     With p_valid the kernel that sums the split-K partials can also finish the two LoRA adapter gradients (wft.h tn_col_scale /
     tn_block_n): col_scale f32 [S, Q] multiplies C[p, q] by col_scale[p // scale_rows, q] (dA = (du^T x) * mask);
     block_n / block_r return a flat f32 tensor of Q / block_n blocks [block_n, block_r], block b = the transpose of rows
-    b*block_r.., columns b*block_n.. of the product (dB of adapter b as [out, r] row-major)."""
+    b*block_r.., columns b*block_n.. of the product (dB of adapter b as [out, r] row-major).
+    seg_out: 1..4 contiguous f32 [rows_i, Q] tensors that receive consecutive row ranges of the product INSTEAD of one [P, Q]
+    tensor (wft.h tn_seg_*: each parameter of a fused Linear group gets its gradient where it lives — a DDP bucket view);
+    returns None if the library does not take the call in that form (the caller falls back to `out` + slicing), else seg_out."""
     _chk(a, BF16, "A"); _chk(b, BF16, "B")
     if R is None:
         R = a.shape[0]
@@ -307,7 +310,9 @@ def gemm_tn(a, b, *, P=None, Q=None, R=None, lda=None, ldb=None, out=None, out_f
         lda = a.stride(0)
     if ldb is None:
         ldb = b.stride(0)
-    if block_n:
+    if seg_out is not None:
+        out, ldc = seg_out[0], Q
+    elif block_n:
         if out is None:
             out = torch.empty(Q * block_r, dtype=F32, device=a.device)
             accumulate = False
@@ -332,6 +337,14 @@ def gemm_tn(a, b, *, P=None, Q=None, R=None, lda=None, ldb=None, out=None, out_f
         args.tn_col_scale, args.tn_scale_rows = col_scale.data_ptr(), int(scale_rows)
     args.tn_block_n, args.tn_block_r = int(block_n), int(block_r)
     lib = L.load()
+    if seg_out is not None:
+        end = 0
+        args.tn_seg_count = len(seg_out)
+        for i, t in enumerate(seg_out):
+            end += t.shape[0]
+            args.tn_seg_end[i], args.tn_seg_ptr[i] = end, t.data_ptr()
+        if not lib.wft_gemm_tn_segments_ok(C.byref(args)):
+            return None
     need = lib.wft_gemm_tn_workspace_bytes(C.byref(args))
     if need > 0:
         ws = _tn_workspace(a.device, need, slot=_ws_slot)
@@ -339,7 +352,7 @@ def gemm_tn(a, b, *, P=None, Q=None, R=None, lda=None, ldb=None, out=None, out_f
     if _args_only:  # (paired launches: gemm_tn_rank_pair)
         return args, out
     L.check(lib.wft_gemm_tn_bf16(C.byref(args), L.stream_ptr()), "wft_gemm_tn_bf16")
-    return out
+    return out if seg_out is None else seg_out
 
 
 def gemm_nt_rank_pair(a0, b0, a1, b1, p_valid: int):

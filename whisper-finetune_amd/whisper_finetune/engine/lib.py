@@ -36,6 +36,7 @@ class GemmArgs(C.Structure):
         ("beta", C.c_float), ("p_valid", C.c_int),
         ("colsum", c_vp),
         ("tn_col_scale", c_vp), ("tn_scale_rows", C.c_int), ("tn_block_n", C.c_int), ("tn_block_r", C.c_int),
+        ("tn_seg_count", C.c_int), ("tn_seg_end", C.c_int * 4), ("tn_seg_ptr", c_vp * 4),
     ]
 
 
@@ -96,6 +97,7 @@ SIGNATURES = {
                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp],
     "wft_gemm_nt_bf16": [C.POINTER(GemmArgs), c_vp],
     "wft_gemm_nt_variant": [C.POINTER(GemmArgs)],
+    "wft_gemm_tn_segments_ok": [C.POINTER(GemmArgs)],
     "wft_gemm_set_nt_variant": [C.c_int],
     "wft_gemm_set_tn_variant": [C.c_int],
     "wft_gemm_set_persistent": [C.c_int],

@@ -447,33 +447,105 @@ class GradAccum:
     The encoder output feeds the key / value projections of every decoder block (whisper's
     MultiHeadAttention.forward with `xa`, reached from the reference's model_utils.py:320-322): autograd would add the
     32 gradients of large-v3 pairwise, 31 elementwise kernels over a [B*1500, d] tensor per step (3.6 ms at 68 clips).
-    Here every consumer's GEMM adds its product to the running sum in its epilogue (C = acc + residual, in place) and
-    only the LAST one to arrive hands the sum to autograd; the others return None.  Consumers register by the identity of
-    their LinearGroup, so a recomputed forward (torch.utils.checkpoint) does not count twice.
-    Contract: every consumer that registered in a forward pass takes part in the SAME backward pass (true for a model's
-    own loss; a second head that consumes the same encoder output and is never backpropagated would withhold the sum —
-    WFT_XA_ACCUM=0 restores autograd's own summation for such set-ups)."""
+    Here the consumers read the tensor through ONE fork node (`grad_fork`): every consumer's GEMM adds its product to a
+    running sum in its epilogue (C = acc + residual, in place) and returns None; the fork's backward — which autograd
+    runs only after every consumer of the fork that takes part in THIS backward pass has run — hands the sum (plus
+    whatever other users of the forked tensor sent through autograd) to the producer of the tensor.  Nothing is counted,
+    so partial backward passes (stochastic-depth skips, `autograd.grad(inputs=subset)`, two decoder passes over one
+    encoder output, a consumer used twice) are summed exactly like autograd would; a sum left behind by a pass that
+    never reached the fork (an exception, the fork not in `inputs`) is recognised by its graph-task id and dropped."""
 
-    __slots__ = ("ids", "done", "buf")
+    __slots__ = ("buf", "task")
 
     def __init__(self):
-        self.ids, self.done, self.buf = set(), 0, None
+        self.buf, self.task = None, -1
+
+    def _fresh(self):
+        task = torch._C._current_graph_task_id()
+        if task != self.task:  # a new backward pass: whatever an unfinished one left is stale
+            self.buf, self.task = None, task
 
     def arrive(self, dx_fn):
-        """dx_fn(residual) -> the consumer's dx, added to `residual` in place when one is given."""
+        """dx_fn(residual) -> the consumer's dx, added to `residual` in place when one is given.  Returns None: the
+        fork hands the sum over."""
+        self._fresh()
         self.buf = dx_fn(self.buf)
-        return self._count()
+        return None
 
-    def skip(self):
-        """a consumer whose output gradient is None contributes nothing but still counts"""
-        return self._count()
-
-    def _count(self):
-        self.done += 1
-        if self.done < len(self.ids):
-            return None
-        out, self.buf, self.done = self.buf, None, 0
+    def take(self):
+        self._fresh()
+        out, self.buf = self.buf, None
         return out
+
+
+class _GradForkFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, accum):
+        ctx.set_materialize_grads(False)
+        ctx.accum, ctx.shape = accum, x.shape
+        return x.detach()  # (same storage; not a view of x, so the fork cached on x is not a reference cycle)
+
+    @staticmethod
+    def backward(ctx, g):
+        s = ctx.accum.take()
+        if s is None:
+            return g, None
+        s = s.view(ctx.shape)
+        return (s if g is None else s + g.to(s.dtype)), None
+
+
+def grad_fork(x: torch.Tensor):
+    """(x_fork, accum): the alias of `x` all accumulating consumers read, created by the first of them and cached on the
+    tensor object (pass `x` on by identity: a different tensor object for the same data gets a fork of its own — correct,
+    one more elementwise add in autograd)."""
+    ent = getattr(x, "_wft_fork", None)
+    if ent is None:
+        acc = GradAccum()
+        ent = x._wft_fork = (_GradForkFn.apply(x, acc), acc)
+    return ent
+
+
+# Gradient homes (VERDICT r4 item 3).  torch DDP with gradient_as_bucket_view=True (the reference's wrap, scripts/finetune.py:698-705)
+# keeps every parameter's gradient as a slice of a bucket; a gradient that arrives anywhere else is COPIED into its slice by the
+# reducer's hook — 6.2 GB and ~260 launches per large-v3 step between the last dW GEMM of a bucket and its all-reduce.  The libwft
+# optimizers note where each fp32 gradient lived at their step (`note_grad_homes`); the next backward's weight-gradient GEMM then
+# writes (first micro-batch: param.grad is None, the returned alias is adopted by AccumulateGrad without a copy) or accumulates
+# (later micro-batches under no_sync(): C += product in the reduce kernel, autograd gets None and adds nothing) straight into
+# that memory.  The reducer finds grad.is_alias_of(bucket_view) and skips its copy.  Without DDP the homes are last step's
+# gradient tensors: same code path, and gradient accumulation costs no elementwise add per parameter.  A home that no longer
+# matches (DDP rebuilt its buckets after the first iteration, the user replaced .grad) is simply not used for that call.
+# WFT_GRAD_HOMES=0 restores fresh gradient tensors per backward (A/B runs).
+_GRAD_HOMES = os.environ.get("WFT_GRAD_HOMES", "1") != "0"
+
+
+def note_grad_homes(params) -> None:
+    if not _GRAD_HOMES:
+        return
+    for p in params:
+        g = p.grad
+        if g is not None and g.dtype == F32 and g.dim() == 2 and g.shape == p.shape and g.is_contiguous() and g.data_ptr() % 16 == 0 \
+                and not p._backward_hooks:
+            p.__dict__["_wft_grad_home"] = g
+
+
+def _weight_grad_homes(weights, w_need):
+    """-> (homes, accumulate) if EVERY weight of the group has a usable home and they agree on the mode, else None."""
+    if not _GRAD_HOMES or not all(w_need):
+        return None
+    homes, modes = [], set()
+    for w in weights:
+        h = w.__dict__.get("_wft_grad_home")
+        if h is None or h.shape != w.shape or h.device != w.device or w._backward_hooks:
+            return None
+        g = w.grad
+        if g is None:
+            modes.add(False)
+        elif g.data_ptr() == h.data_ptr() and g.dtype == F32 and g.shape == h.shape and g.is_contiguous():
+            modes.add(True)
+        else:
+            return None
+        homes.append(h)
+    return (homes, modes.pop()) if len(modes) == 1 else None
 
 
 class _LinearCfg:
@@ -534,7 +606,6 @@ class LinearFn(torch.autograd.Function):
         ctx.cfg = cfg
         ctx.accum = None
         if cfg.accum is not None and ctx.needs_input_grad[0] and gelu_pre is None:
-            cfg.accum.ids.add(id(cfg.group))
             ctx.accum = cfg.accum
         ctx.has_res = residual is not None
         ctx.want_cs = BIAS_GRADS[0]
@@ -556,8 +627,7 @@ class LinearFn(torch.autograd.Function):
         has_lora = any(s is not None for s in cfg.loras)
         dy = grads[0]
         if dy is None:
-            dx_total = ctx.accum.skip() if ctx.accum is not None else None
-            return (dx_total,) + (None,) * (3 + len(params))
+            return (None,) * (4 + len(params))
         if dy.dtype != BF16:
             dy = dy.to(BF16)
         dy = dy.contiguous()
@@ -573,14 +643,19 @@ class LinearFn(torch.autograd.Function):
                 dpre = K.gemm_nt(dy, WT, epilogue=L.EPI_MUL_AUX if _GELU_PAIR else L.EPI_DGELU, aux=gelu_pre, colsum=cs)
                 if cs is not None:
                     _publish_colsum(dpre, cs)
-            elif ctx.accum is not None:  # one of several consumers of x: add into the running sum, the last arrival returns it
+            elif ctx.accum is not None:  # one of several consumers of x: add into the running sum, the fork node returns it
                 dx = ctx.accum.arrive(lambda run: K.gemm_nt(dy, WT) if run is None else K.gemm_nt(dy, WT, residual=run, out=run))
             else:
                 dx = K.gemm_nt(dy, WT)
         out: List[Optional[torch.Tensor]] = [dx, dy if ctx.has_res else None, dpre, None]
         # parameter grads: weights
         w_need = [ctx.needs_input_grad[4 + i] for i in range(n_w)]
-        if any(w_need):
+        homed = _weight_grad_homes(weights, w_need) if (any(w_need) and k == kpad and n == npad) else None
+        if homed is not None and K.gemm_tn(dy, x, seg_out=homed[0], accumulate=homed[1]) is not None:
+            # each gradient written where it lives (a DDP bucket view): an alias for AccumulateGrad to adopt, or — accumulated in
+            # place — nothing for it to add
+            out.extend([None] * n_w if homed[1] else [h.detach() for h in homed[0]])
+        elif any(w_need):
             dW = K.gemm_tn(dy, x)  # f32 [Npad, Kpad]
             off = 0
             for i, w in enumerate(weights):
@@ -734,7 +809,7 @@ def _bias_list(cfg, params):
 
 
 def linear(x, group: LinearGroup, weights, biases, loras=None, residual=None, gelu_out=False, gelu_pre=None, dx_accum=None):
-    """Functional front door of LinearFn. x bf16 [M, K] contiguous.  dx_accum: a GradAccum shared by all Linear consumers of x."""
+    """Functional front door of LinearFn. x bf16 [M, K] contiguous.  dx_accum: the GradAccum of `grad_fork(x)` (x must be that fork)."""
     loras = list(loras) if loras is not None else [None] * len(weights)
     cfg = _LinearCfg(group, len(weights), tuple(b is not None for b in biases), tuple(loras), gelu_out,
                      gelu_pre is not None, sum(w.shape[0] for w in weights), dx_accum)

@@ -187,14 +187,11 @@ class MultiHeadAttention(nn.Module):
             q = self.query(x2)
             lin = [self.key, self.value]
             # every decoder block projects the SAME encoder output: their input gradients are summed inside the backward-data
-            # GEMMs (ops.GradAccum) instead of by 31 elementwise adds; the accumulator rides on the tensor itself, so any
-            # decoder class (plain, checkpointed, stochastic depth) shares it without knowing
+            # GEMMs (ops.GradAccum) instead of by 31 elementwise adds; the fork node and its accumulator ride on the tensor
+            # itself, so any decoder class (plain, checkpointed, stochastic depth) shares them without knowing
             acc = None
             if _XA_ACCUM and torch.is_grad_enabled() and xa.requires_grad and xa.dtype == torch.bfloat16:
-                acc = getattr(xa, "_wft_dx_accum", None)
-                if acc is None:
-                    acc = ops.GradAccum()
-                    xa._wft_dx_accum = acc
+                xa, acc = ops.grad_fork(xa)
             kv = ops.linear(_as2d(_to_bf16(xa)), self._kv_group, [m.base_weight() for m in lin], [m.bias for m in lin],
                             [m.lora_spec() for m in lin], dx_accum=acc)
             o = ops.CrossAttnFn.apply(q.view(B, T, d), kv.view(B, Ta, 2 * d), self.n_head)

@@ -115,23 +115,49 @@ class LoraMaskPool:
         for child in root.children():  # (encoder, decoder): entry points of calls that bypass root.__call__
             self.handles.append(child.register_forward_pre_hook(self._on_child_forward))
         self.root = root
-        # `model.forward_loss(...)` is a plain method, not a child module: wrapped so that it counts as ONE forward of the root (one
-        # draw; without this its encoder and decoder calls each looked like an entry below the root — a second draw while the
-        # first one's specs were alive, and with checkpointed blocks a recompute against the wrong masks)
-        inner = getattr(root, "forward_loss", None)
-        if callable(inner) and "forward_loss" not in root.__dict__:
-            def forward_loss(*args, **kwargs):
-                if self.depth > 0:  # reached through root.forward(..., targets=...): that call already is the forward of the model
-                    return inner(*args, **kwargs)
-                self._on_root_forward(root, args)
-                try:
-                    return inner(*args, **kwargs)
-                finally:
-                    self._after_root_forward(root, args, None)
-            root.__dict__["forward_loss"] = forward_loss
+        # `model.forward_loss(...)` is a plain method, not a child module: shadowed by a BOUND METHOD of the pool so that it counts as
+        # ONE forward of the root (one draw; without this its encoder and decoder calls each looked like an entry below the root — a
+        # second draw while the first one's specs were alive, and with checkpointed blocks a recompute against the wrong masks).
+        # A bound method, not a closure: copy.deepcopy re-binds it to the copy's pool (a closure is copied by reference and would
+        # evaluate the ORIGINAL model from the copy — EMA / teacher / eval-on-a-copy flows).
+        if callable(getattr(type(root), "forward_loss", None)) and "forward_loss" not in root.__dict__:
+            root.__dict__["forward_loss"] = self._forward_loss
         # all merged shadows / gradient-GEMM operands of the model in one launch per training forward (WFT_LORA_BATCH=0: the
         # per-Linear kernels, A/B runs)
         self.plan = ops.LoraRefreshPlan() if os.environ.get("WFT_LORA_BATCH", "1") != "0" else None
+
+    def _forward_loss(self, *args, **kwargs):
+        root = self.root
+        inner = type(root).forward_loss
+        if self.depth > 0:  # reached through root.forward(..., targets=...): that call already is the forward of the model
+            return inner(root, *args, **kwargs)
+        self._on_root_forward(root, args)
+        try:
+            return inner(root, *args, **kwargs)
+        finally:
+            self._after_root_forward(root, args, None)
+
+    def __deepcopy__(self, memo):
+        """The pool of a deep-copied model: the copy's root, adapters and hook handles (the hooks themselves are bound methods of
+        the pool inside the root's hook dictionaries: deepcopy re-binds them to this object through the memo); offsets re-keyed to
+        the copied adapters; no masks drawn yet and an empty refresh plan — the original's plan holds device addresses of the
+        original's shadows, the copy rebuilds its own on its first training forward."""
+        import copy
+
+        new = object.__new__(type(self))
+        memo[id(self)] = new
+        new.root = copy.deepcopy(self.root, memo)
+        new.adapters = [copy.deepcopy(a, memo) for a in self.adapters]
+        new.offsets = {id(b): self.offsets[id(a)] for a, b in zip(self.adapters, new.adapters)}
+        new.buf = new.store = None
+        new.serial = 0
+        new.total = self.total
+        new.handed = []
+        new.depth = 0
+        new.handle = copy.deepcopy(self.handle, memo)
+        new.handles = [copy.deepcopy(h, memo) for h in self.handles]
+        new.plan = ops.LoraRefreshPlan() if self.plan is not None else None
+        return new
 
     def add(self, adapter: "LoRAParametrization") -> None:
         self.offsets[id(adapter)] = (self.total, adapter.lora_A.shape[1])

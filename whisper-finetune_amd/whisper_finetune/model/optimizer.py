@@ -104,7 +104,16 @@ class WftAdamW(_FusedClipMixin, torch.optim.Optimizer):
         loss = closure() if closure is not None else None
         sumsq, max_norm = self._take_clip()
         _adamw_groups_step(self, self.param_groups, sumsq, max_norm)
+        _note_homes(self)
         return loss  # the bf16 weight shadows are invalidated by the global optimizer post-hook (engine/ops.py)
+
+
+def _note_homes(optimizer) -> None:
+    """Where this step's fp32 weight gradients lived (DDP bucket views under gradient_as_bucket_view): the next backward's
+    weight-gradient GEMMs write there directly (engine/ops.py `note_grad_homes`)."""
+    from whisper_finetune.engine import ops
+
+    ops.note_grad_homes(p for g in optimizer.param_groups for p in g["params"])
 
 
 class WftMuonWithAuxAdam(_FusedClipMixin, torch.optim.Optimizer):
@@ -179,6 +188,7 @@ class WftMuonWithAuxAdam(_FusedClipMixin, torch.optim.Optimizer):
                 K.muon_group_step(pviews, grads, bviews, group["lr"], group["weight_decay"], group["momentum"], sumsq=sumsq,
                                   max_norm=max_norm, shard=shard, validated=True)
         _adamw_groups_step(self, [g for g in self.param_groups if not g["use_muon"]], sumsq, max_norm)
+        _note_homes(self)
         return loss
 
 
