@@ -398,6 +398,22 @@ int wft_mt_adamw(const void* tab, const int64_t* numel, const int32_t* chunk_sta
                  float weight_decay, float bias_corr1, float bias_corr2, const float* sumsq,
                  float max_norm, void* stream);
 
+/* 8-bit AdamW: `bnb.optim.AdamW8bit` / `Adam8bit` of the reference's `optimizer.8bit: True` (model/optimizer.py:241-256; the
+ * third-party package bitsandbytes is neither vendored nor installed: published algorithm, Dettmers et al. 2022 — PARITY
+ * UNPINNED, see oracle/adam8bit_oracle.py).  The two moments are stored as one byte per element in blocks of
+ * WFT_Q8_BLOCK = 2 048 elements with an f32 absmax per block; byte c decodes to qmap[c] * absmax.
+ * tab rows: 0 p (f32), 1 g (f32), 2 state1 (u8 codes of m), 3 state2 (u8 codes of v), 4 absmax1 (f32 [ceil(numel / 2048)]),
+ * 5 absmax2.  qmap1 / qmap2: the two ascending 256-entry f32 maps (signed / unsigned dynamic quantisation) in device memory.
+ * Per block: dequantise, m = b1 m + (1 - b1) g, v = b2 v + (1 - b2) g^2 (g scaled by the clip coefficient as in wft_mt_adamw),
+ * p += -lr * sqrt(bias_corr2) / bias_corr1 * m / (sqrt(v) + sqrt(bias_corr2) * eps), p *= 1 - lr * weight_decay, then the new
+ * absmax of the block and the nearest map entry of m / absmax1, v / absmax2.  16 B / parameter of HBM traffic (28 with f32
+ * state).  Chunks (WFT_MT_CHUNK elements) hold whole blocks, so blocks never span tensors.                               */
+#define WFT_Q8_BLOCK 2048
+int wft_mt_adamw8(const void* tab, const int64_t* numel, const int32_t* chunk_start, int n,
+                  int total_chunks, const float* qmap1, const float* qmap2, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, float bias_corr1, float bias_corr2, const float* sumsq,
+                  float max_norm, void* stream);
+
 /* --------------------------------------------------------------------- Muon */
 /* The reference builds `muon.MuonWithAuxAdam` (third-party package `muon`, git HEAD, not vendored:
  * pyproject.toml:29, model/optimizer.py:171-237).  Its update for a 2-D parameter is

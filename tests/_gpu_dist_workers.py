@@ -77,7 +77,7 @@ def ddp_engine_worker(rank, world, port, out):
     find_unused_parameters=True, gradient_as_bucket_view=True, local accumulation 2 (no_sync on the first micro-batch),
     the libwft optimizer reading the bucket views, per-tile GEMM launches — against the same steps without DDP."""
     _setup(rank, world, port, "nccl")
-    os.environ["WFT_NT256_PERSISTENT"] = "0"  # what engine/lib.py selects when WORLD_SIZE > 1 (RCCL kernels hold CUs)
+    os.environ["WFT_NT256_PERSISTENT"] = "0"  # the per-tile launch mode stays covered (default since round 5: persistent everywhere)
     import torch
     import torch.distributed as dist
     from torch.nn.parallel import DistributedDataParallel as DDP
@@ -282,14 +282,14 @@ def ddp_grad_homes_worker(rank, world, port, out):
         try:
             for step in range(4):
                 seg_calls["n"] = seg_calls["acc"] = 0
-                copies = {"n": 0}
                 model_utils.train_step(model, batches(), opt, sched, dict(t_cfg))
                 big = [p for n, p in m.named_parameters() if p.dim() == 2 and p.shape[0] % 256 == 0 and p.shape[1] % 256 == 0
                        and "embedding" not in n]
                 homes = [p.__dict__.get("_wft_grad_home") for p in big]
-                # a home that is a slice of a larger storage = a bucket view (a plain gradient tensor owns its storage)
+                # DDP's bucket views share a handful of storages (290 MB of fp32 gradients in 64 MB buckets); without DDP every
+                # Linear group's gradients are slices of that group's own [N, K] product
                 alias.append((seg_calls["n"], seg_calls["acc"],
-                              sum(1 for h in homes if h is not None and h.untyped_storage().nbytes() > h.numel() * 4), len(big)))
+                              len({h.untyped_storage().data_ptr() for h in homes if h is not None}), len(big)))
         finally:
             K.gemm_tn = real_tn
             rt.IS_DISTRIBUTED = False

@@ -69,8 +69,8 @@ def test_engine_under_a_two_rank_reducer_matches_a_hand_made_all_reduce():
 @pytest.mark.timeout(900)
 def test_weight_gradients_are_written_into_the_ddp_bucket_views():
     """VERDICT r4 item 3 (reference: scripts/finetune.py:698-705, gradient_as_bucket_view=True).  Per optimizer step of whisper-base
-    at 12 clips with accumulation 2: (segmented weight-gradient GEMM calls, of which accumulating, big weights whose noted home is a
-    slice of a bucket, big weights)."""
+    at 12 clips with accumulation 2: (segmented weight-gradient GEMM calls, of which accumulating, distinct storages behind the noted
+    homes of the big weights, big weights)."""
     from tests._gpu_dist_workers import ddp_grad_homes_worker
 
     (rank, worst, a_plain, a_ddp), = _spawn(ddp_grad_homes_worker, 1, timeout=800)
@@ -82,5 +82,5 @@ def test_weight_gradients_are_written_into_the_ddp_bucket_views():
         # from the second step on every group's dW GEMM is segmented, and the second micro-batch accumulates in place
         assert a[1][0] > 0 and a[1][1] * 2 == a[1][0], a
         assert a[3][0] == a[2][0] == a[1][0], a
-    assert all(x[2] == 0 for x in a_plain)          # without DDP the homes are ordinary gradient tensors
-    assert a_ddp[2][2] == n_big and a_ddp[3][2] == n_big, a_ddp  # under DDP they are the bucket views (after the rebuild)
+    assert a_plain[3][2] > 20, a_plain              # without DDP: one storage per Linear group's product
+    assert 1 <= a_ddp[3][2] <= 8, a_ddp             # under DDP (after the bucket rebuild): the buckets' storages and nothing else

@@ -132,6 +132,131 @@ extern "C" int wft_mt_adamw(const void* tab, const int64_t* numel, const int32_t
   return WFT_OK;
 }
 
+// ------------------------------------------------------------------ 8-bit AdamW (bnb.optim.AdamW8bit; reference model/optimizer.py:241-256)
+// Block-wise dynamic-quantised moments: one byte per element, blocks of 2 048 elements with an f32 absmax each (include/wft.h;
+// restated in oracle/adam8bit_oracle.py — the package is not in the image: parity unpinned).  HBM-bound: 16 B per parameter
+// (p read + written, g read, two code bytes read + written).  One workgroup walks the up to 32 blocks of a chunk; a thread owns
+// 8 consecutive elements of a block (two 16-byte loads of p and g, one 8-byte load of each code array).  Both maps live in LDS:
+// decoding is one LDS read per code; encoding is an 8-step bisection over the 255 midpoints between neighbouring map entries
+// (code = number of midpoints below the normalised value: the nearest entry, ties to the lower code).
+__device__ __forceinline__ unsigned q8_encode(const float* mid, float x) {
+  // mid[0..254] ascending; invariant: mid[lo - 1] < x (or lo == 0), and x <= mid[hi] (or hi == 255)
+  unsigned lo = 0;
+#pragma unroll
+  for (unsigned step = 128; step >= 1; step >>= 1) {
+    const unsigned probe = lo + step;  // candidate code: valid if mid[probe - 1] < x
+    if (probe <= 255 && mid[probe - 1] < x) lo = probe;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void mt_adamw8_kernel(const long* tab, const long* numel, const int* chunk_start, int n,
+                                                        const float* qmap1, const float* qmap2, float lr, float b1, float b2,
+                                                        float eps, float wd, float bc1, float bc2, const float* sumsq,
+                                                        float max_norm) {
+  __shared__ float q1[256], q2[256], mid1[256], mid2[256];
+  __shared__ float red[2][4];
+  const int tid = threadIdx.x;
+  q1[tid] = qmap1[tid];
+  q2[tid] = qmap2[tid];
+  if (tid < 255) {
+    mid1[tid] = (qmap1[tid] + qmap1[tid + 1]) * 0.5f;
+    mid2[tid] = (qmap2[tid] + qmap2[tid + 1]) * 0.5f;
+  }
+  const int t = mt_find(chunk_start, n, blockIdx.x);
+  const long off = (long)(blockIdx.x - chunk_start[t]) * MT_CHUNK;
+  const long cnt = numel[t] - off < MT_CHUNK ? numel[t] - off : MT_CHUNK;
+  float* p = (float*)tab[t] + off;
+  const float* g = (const float*)tab[n + t] + off;
+  unsigned char* s1 = (unsigned char*)tab[2 * n + t] + off;
+  unsigned char* s2 = (unsigned char*)tab[3 * n + t] + off;
+  float* am1 = (float*)tab[4 * n + t] + (off / WFT_Q8_BLOCK);
+  float* am2 = (float*)tab[5 * n + t] + (off / WFT_Q8_BLOCK);
+  float gs = 1.f;
+  if (sumsq) {
+    const float coef = max_norm / (sqrtf(sumsq[0]) + 1e-6f);
+    gs = coef < 1.f ? coef : 1.f;
+  }
+  const float c2 = sqrtf(bc2);
+  const float step_size = -lr * c2 / bc1, eps2 = c2 * eps, decay = 1.f - lr * wd;
+  const bool al = ((((uintptr_t)p) | ((uintptr_t)g)) & 15) == 0 && ((((uintptr_t)s1) | ((uintptr_t)s2)) & 7) == 0;
+  __syncthreads();
+  const int nblk = (int)((cnt + WFT_Q8_BLOCK - 1) / WFT_Q8_BLOCK);
+  for (int b = 0; b < nblk; ++b) {
+    const long e0 = (long)b * WFT_Q8_BLOCK + tid * 8;
+    const int nvalid = (int)(cnt - e0 < 8 ? (cnt - e0 < 0 ? 0 : cnt - e0) : 8);
+    float pv[8], gv[8], m[8], v[8];
+    unsigned char c1[8], c2b[8];
+    if (al && nvalid == 8) {
+      *(f32x4*)pv = *(const f32x4*)(p + e0);
+      *(f32x4*)(pv + 4) = *(const f32x4*)(p + e0 + 4);
+      *(f32x4*)gv = *(const f32x4*)(g + e0);
+      *(f32x4*)(gv + 4) = *(const f32x4*)(g + e0 + 4);
+      *(u32x2*)c1 = *(const u32x2*)(s1 + e0);
+      *(u32x2*)c2b = *(const u32x2*)(s2 + e0);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const bool ok = e < nvalid;
+        pv[e] = ok ? p[e0 + e] : 0.f;
+        gv[e] = ok ? g[e0 + e] : 0.f;
+        c1[e] = ok ? s1[e0 + e] : 0;
+        c2b[e] = ok ? s2[e0 + e] : 0;
+      }
+    }
+    const float a1 = am1[b], a2 = am2[b];
+    float mx1 = 0.f, mx2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float gg = gv[e] * gs;
+      m[e] = q1[c1[e]] * a1 * b1 + (1.f - b1) * gg;
+      v[e] = q2[c2b[e]] * a2 * b2 + (1.f - b2) * gg * gg;
+      if (e >= nvalid) { m[e] = 0.f; v[e] = 0.f; }
+      mx1 = fmaxf(mx1, fabsf(m[e]));
+      mx2 = fmaxf(mx2, v[e]);
+    }
+    mx1 = wave_max(mx1);
+    mx2 = wave_max(mx2);
+    __syncthreads();  // (the previous block's readers of `red` are done)
+    if ((tid & 63) == 0) { red[0][tid >> 6] = mx1; red[1][tid >> 6] = mx2; }
+    __syncthreads();
+    const float n1 = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    const float n2 = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+    const float i1 = n1 > 0.f ? 1.f / n1 : 0.f, i2 = n2 > 0.f ? 1.f / n2 : 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      pv[e] = pv[e] + step_size * (m[e] / (sqrtf(v[e]) + eps2));
+      if (wd > 0.f) pv[e] *= decay;
+      c1[e] = (unsigned char)q8_encode(mid1, m[e] * i1);
+      c2b[e] = (unsigned char)q8_encode(mid2, v[e] * i2);
+    }
+    if (al && nvalid == 8) {
+      *(f32x4*)(p + e0) = *(const f32x4*)pv;
+      *(f32x4*)(p + e0 + 4) = *(const f32x4*)(pv + 4);
+      *(u32x2*)(s1 + e0) = *(const u32x2*)c1;
+      *(u32x2*)(s2 + e0) = *(const u32x2*)c2b;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (e < nvalid) { p[e0 + e] = pv[e]; s1[e0 + e] = c1[e]; s2[e0 + e] = c2b[e]; }
+    }
+    if (tid == 0) { am1[b] = n1; am2[b] = n2; }
+  }
+}
+
+extern "C" int wft_mt_adamw8(const void* tab, const int64_t* numel, const int32_t* chunk_start, int n, int total_chunks,
+                             const float* qmap1, const float* qmap2, float lr, float beta1, float beta2, float eps,
+                             float weight_decay, float bias_corr1, float bias_corr2, const float* sumsq, float max_norm, void* stream) {
+  WFT_CHECK_ARG(tab && numel && chunk_start && qmap1 && qmap2 && n >= 1 && total_chunks >= 1, "bad args");
+  WFT_CHECK_ARG(!sumsq || max_norm > 0.f, "max_norm must be > 0 when a gradient norm is given");
+  WFT_CHECK_ARG(bias_corr1 > 0.f && bias_corr2 > 0.f, "bias corrections must be > 0");
+  hipLaunchKernelGGL(mt_adamw8_kernel, dim3(total_chunks), dim3(256), 0, (hipStream_t)stream, (const long*)tab, (const long*)numel,
+                     (const int*)chunk_start, n, qmap1, qmap2, lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, sumsq,
+                     max_norm);
+  WFT_CHECK_LAUNCH();
+  return WFT_OK;
+}
+
 // ------------------------------------------------------------------ Muon (muon.py: muon_update, zeropower_via_newtonschulz5)
 // Step 1, per matrix t of a same-shape group (tab rows: 0 p (unused here), 1 g, 2 momentum buffer):
 //   buf = lerp(buf, g, 1 - beta);  u = nesterov ? lerp(g, buf, beta) : buf      (g is overwritten with u, as grad.lerp_ does)

@@ -621,7 +621,7 @@ class TensorTable:
         self.numel = upload_table(numel, torch.int64, self.device)
         self.chunk_start = upload_table(starts, torch.int32, self.device)
 
-    def pointers(self, *rows, allow_none=False, static=()):
+    def pointers(self, *rows, allow_none=False, static=(), dtypes=None):
         """`static`: indices of rows whose tensors live as long as the table (parameters, optimizer state): each is checked once
         (dtype / layout / device do not change under a live tensor object) — with 1 259 parameters the three checks on four rows
         were most of the 2.6 ms the GPU idled in front of the AdamW launch (profiles/r03_headline_gap_analysis.log)."""
@@ -630,6 +630,7 @@ class TensorTable:
         for ri, r in enumerate(rows):
             assert len(r) == self.n
             trust = ri in static
+            want = F32 if dtypes is None else dtypes[ri]  # (the 8-bit optimizer's code rows are uint8)
             for t in r:
                 if t is None and allow_none:
                     flat.append(0)
@@ -639,8 +640,8 @@ class TensorTable:
                 # optimizer.load_state_dict, or a parameter re-typed in place (.data = ..., model.half()), is checked again
                 key = (id(t), ptr, t.dtype)
                 if not (trust and key in seen):
-                    if t.dtype != F32 or not t.is_contiguous() or not t.is_cuda:
-                        raise L.WftError("multi-tensor optimizer kernels need contiguous f32 HIP tensors")
+                    if t.dtype != want or not t.is_contiguous() or not t.is_cuda:
+                        raise L.WftError(f"multi-tensor optimizer kernels need contiguous {want} HIP tensors")
                     if trust:
                         seen.add(key)
                 flat.append(ptr)
@@ -662,6 +663,15 @@ def mt_adamw(table: TensorTable, params, grads, exp_avg, exp_avg_sq, lr, beta1, 
     tab = table.pointers(params, grads, exp_avg, exp_avg_sq, static=(0, 2, 3))
     L.check(L.load().wft_mt_adamw(_p(tab), _p(table.numel), _p(table.chunk_start), table.n, table.total_chunks, lr, beta1,
                                   beta2, eps, wd, bc1, bc2, _p(sumsq), float(max_norm), L.stream_ptr()), "wft_mt_adamw")
+
+
+def mt_adamw8(table: TensorTable, params, grads, state1, state2, absmax1, absmax2, qmap1, qmap2, lr, beta1, beta2, eps, wd, bc1, bc2,
+              sumsq=None, max_norm=0.0):
+    """Block-wise 8-bit AdamW for every tensor of the table in one launch (wft_mt_adamw8; include/wft.h)."""
+    U8 = torch.uint8
+    tab = table.pointers(params, grads, state1, state2, absmax1, absmax2, static=(0, 2, 3, 4, 5), dtypes=(F32, F32, U8, U8, F32, F32))
+    L.check(L.load().wft_mt_adamw8(_p(tab), _p(table.numel), _p(table.chunk_start), table.n, table.total_chunks, _p(qmap1), _p(qmap2),
+                                   lr, beta1, beta2, eps, wd, bc1, bc2, _p(sumsq), float(max_norm), L.stream_ptr()), "wft_mt_adamw8")
 
 
 def transpose_bf16(src: torch.Tensor, dst: torch.Tensor):

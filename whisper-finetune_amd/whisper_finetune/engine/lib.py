@@ -126,6 +126,7 @@ SIGNATURES = {
     "wft_sumsq_f32": [c_vp, c_i64, c_vp, c_vp],
     "wft_mt_sumsq_f32": [c_vp, c_vp, c_vp, C.c_int, C.c_int, c_vp, c_vp, c_vp],
     "wft_mt_adamw": [c_vp, c_vp, c_vp, C.c_int, C.c_int] + [C.c_float] * 7 + [c_vp, C.c_float, c_vp],
+    "wft_mt_adamw8": [c_vp, c_vp, c_vp, C.c_int, C.c_int, c_vp, c_vp] + [C.c_float] * 7 + [c_vp, C.c_float, c_vp],
     "wft_muon_momentum_mt": [c_vp, C.c_int, c_i64, C.c_float, C.c_int, c_vp, c_vp, c_vp, C.c_float, c_vp],
     "wft_muon_prepare": [c_vp, C.c_int, C.c_int, c_vp, C.c_int, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp],
     "wft_transpose_bf16": [c_vp, C.c_int, C.c_int, c_vp, C.c_int, c_vp],
@@ -167,12 +168,12 @@ def load():
             f"HIP extension {LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(make -C whisper-finetune_amd/csrc). There is no CPU fallback for the product path."
         )
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        # multi-GPU job: RCCL's collective kernels hold CUs while the GEMMs of the backward pass start, so the 256x256
-        # NT kernel is launched one workgroup per tile (hardware-balanced) instead of persistent (csrc/gemm.hip;
-        # the library reads the variable once, when it is loaded)
-        os.environ.setdefault("WFT_NT256_PERSISTENT", "0")
-        os.environ.setdefault("WFT_ATTN_PERSISTENT", "0")  # the same for the persistent dK/dV attention kernel (csrc/attn.hip)
+    # Launch modes of a multi-GPU job.  Rounds 3-4 switched the persistent NT / dK/dV grids to one workgroup per tile when
+    # WORLD_SIZE > 1, on the argument that RCCL's collective kernels hold CUs.  Round 5 measured it on one GPU (bench.py
+    # `ddp_mode_1gpu`: DDP wrapper, a side-stream kernel per gradient bucket that holds 24 CUs and moves the ring's bytes):
+    # per-tile 642.7 ms vs persistent 639.3 ms per step under the CU thief, 634.1 vs 628.8 without — persistent wins both, so
+    # it stays the default everywhere.  WFT_NT256_PERSISTENT=0 / WFT_ATTN_PERSISTENT=0 (or wft_gemm_set_persistent /
+    # wft_attn_set_persistent) still select per-tile launches.
     lib = C.CDLL(str(LIB_PATH))
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
