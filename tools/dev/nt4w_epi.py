@@ -29,4 +29,11 @@ for name, N, Kd in (("fc1", 5120, 1280), ("fc2 dgrad", 5120, 1280)):
         t1 = min(timeit(lambda: K.gemm_nt(a, b, out=c, epilogue=L.EPI_MUL_AUX, aux=aux)) for _ in range(3))
         t2 = min(timeit(lambda: K.gemm_nt(a, b, out=c, epilogue=L.EPI_MUL_AUX, aux=aux, colsum=cs)) for _ in range(3))
         out.append(f"MUL_AUX {t1*1e6:.0f} us ({fl/t1/1e12:.0f}) + colsum {t2*1e6:.0f} us ({fl/t2/1e12:.0f})")
-print(f"DIAG {os.environ.get('WFT_GEMM_DIAG', '0')}: " + " | ".join(out), flush=True)
+for name, N, Kd in (("out-proj + residual", 1280, 1280), ("fc2 + residual", 1280, 5120)):  # the <NONE, residual> variant
+    a = torch.randn(M, Kd, device=dev).to(torch.bfloat16); b = (torch.randn(N, Kd, device=dev) * 0.03).to(torch.bfloat16)
+    c = torch.empty(M, N, dtype=torch.bfloat16, device=dev); res = torch.randn(M, N, device=dev).to(torch.bfloat16); bias = torch.randn(N, device=dev)
+    fl = 2.0 * M * N * Kd
+    t0 = min(timeit(lambda: K.gemm_nt(a, b, out=c, bias=bias)) for _ in range(3))
+    t1 = min(timeit(lambda: K.gemm_nt(a, b, out=c, bias=bias, residual=res)) for _ in range(3))
+    out.append(f"{name}: bias only {t0*1e6:.0f} us ({fl/t0/1e12:.0f}) + residual {t1*1e6:.0f} us ({fl/t1/1e12:.0f})")
+print(f"{os.path.basename(os.environ.get('WFT_LIB', 'libwft.so'))} DIAG {os.environ.get('WFT_GEMM_DIAG', '0')}: " + " | ".join(out), flush=True)

@@ -268,6 +268,25 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
+#ifdef FWD_STAMPS  // developer build (tools/dev/fwd_stamps.py, hipcc -DFWD_STAMPS): clock-tick sums per phase of a key tile, all active waves
+__device__ unsigned long long fwd_dbg[16];
+extern "C" void wft_fwd_dbg_read(unsigned long long* host, int reset) {
+  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(fwd_dbg), z, sizeof z); return; }
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(fwd_dbg), 16 * sizeof(unsigned long long));
+}
+// stamp phase I behind the value DEP (a dependent v_mov makes the hardware wait for DEP's producer, e.g. an MFMA chain)
+#define FWD_STAMP(I, DEP)                                                                                  \
+  do {                                                                                                     \
+    unsigned long long now_;                                                                               \
+    asm volatile("v_mov_b32 %1, %1\n s_nop 0\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(now_), "+v"(DEP)); \
+    fst[I] += now_ - flast;                                                                                \
+    flast = now_;                                                                                          \
+  } while (0)
+#else
+#define FWD_STAMP(I, DEP) do {} while (0)
+#endif
+
 // ------------------------------------------------------------------------------ forward
 // K/V tiles travel through a THREE-slot LDS ring, staged two tiles ahead of their use, and the end-of-tile
 // wait is a counted s_waitcnt vmcnt(4) (this wave's 4 LDS-DMA instructions of tile kt+2 may stay in flight).
@@ -317,6 +336,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   // everything else 4).  Same sums as the eager form up to fp32 rounding of l and O.
   float m = 0.f, l = 0.f;
   f32x16 minit = zero16;
+#ifdef FWD_STAMPS
+  unsigned long long fst[8] = {0, 0, 0, 0, 0, 0, 0, 0}, flast = __builtin_amdgcn_s_memtime(), fbegin = flast;
+#endif
 
   att_stage2(stK, kb, p.ldk, smem, stV, vb, p.ldv, smem + 8192, 0, p.Tk, wave, lane);
   if (nkt > 1) {
@@ -346,6 +368,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
     const bool active = qw0 < p.Tq && !(p.causal && key0 > qw0 + 31);
     s16x4 vt[4][2][2];
     bf16x8 pf[4];
+    FWD_STAMP(0, m);  // tile entry -> stage issue done
     if (active) {
       static_for<4>([&](auto ks_tag) {  // the k-step's 2048-byte stride rides in the immediate: no address add per read
         constexpr int ks = decltype(ks_tag)::value;
@@ -370,7 +393,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
           for (int e = 0; e < 16; ++e)
             sacc[kb2][e] = (32 * kb2 + (e & 3) + 8 * (e >> 2)) < lim ? sacc[kb2][e] : ATT_NEG;
       }
-      const float tmax = att_xhalf_max(att_max32(sacc[0], sacc[1]));  // max over the tile of S - m
+      FWD_STAMP(1, sacc[1][15]);  // V^T read issue + S MFMA chains complete
+      float tmax = att_xhalf_max(att_max32(sacc[0], sacc[1]));  // max over the tile of S - m
+      FWD_STAMP(2, tmax);  // maximum (in-lane tree + half exchange)
       if (kt == 0 || __builtin_amdgcn_ballot_w64(tmax * c > ATT_TAU) != 0) {
         // rare path: move the reference maximum (first tile: to the tile's own maximum, whatever its sign)
         const float d = kt == 0 ? tmax : fmaxf(tmax, 0.f);
@@ -403,11 +428,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
       l += att_xhalf_sum(ls0 + ls1);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) pf[ks] = att_pack8(sacc[ks >> 1], ks & 1);
+      FWD_STAMP(3, l);  // (rescale branch,) exponentials, row sums, packs
     }
     __builtin_amdgcn_sched_barrier(0);
     if (more) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    FWD_STAMP(4, m);  // own LDS-DMA pieces of tile kt+1 landed, V^T fragments landed
     __builtin_amdgcn_s_barrier();
+    FWD_STAMP(5, m);  // barrier
     __builtin_amdgcn_sched_barrier(0);
     if (kt + 1 < nkt) {
 #pragma unroll
@@ -421,6 +449,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
 #pragma unroll
         for (int db = 0; db < 2; ++db)
           oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_join(vt[ks][db][0], vt[ks][db][1]), pf[ks], oacc[db], 0, 0, 0);
+      FWD_STAMP(6, oacc[1][15]);  // K fragment reads of tile kt+1 issued + P.V MFMA chains complete
     }
   };
   int kt = 0;
@@ -446,6 +475,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
       }
     if (h == 0 && p.lse) p.lse[((long)b * p.H + hd) * p.Tq + qi] = m * p.scale + __logf(l);
   }
+#ifdef FWD_STAMPS
+  if (lane == 0 && qw0 < p.Tq) {
+    for (int i = 0; i < 7; ++i) atomicAdd(&fwd_dbg[i], fst[i]);
+    atomicAdd(&fwd_dbg[8], 1ull);
+    atomicAdd(&fwd_dbg[9], __builtin_amdgcn_s_memtime() - fbegin);
+    atomicAdd(&fwd_dbg[10], (unsigned long long)nkt);
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------ delta

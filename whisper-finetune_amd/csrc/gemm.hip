@@ -1437,7 +1437,7 @@ __global__ __launch_bounds__(256) void tn_splitk_reduce_pair_kernel(TnReduceP r0
 static int g_diag = 0;
 // dispatch thresholds, measured at M = R = 4096 and 8704 (decoder-sized problems; tests/dev_small_gemm.py): the 256x256 kernels win once
 // they can occupy half of the CUs (NT: >= 128 tiles) / have >= 50 output tiles to split (TN).  Tunable: WFT_NT256_MIN_TILES, WFT_TN256_MIN_STEPS.
-static int g_nt256_min_tiles = 128, g_tn256_min_steps = 64;
+static int g_nt256_min_tiles = 128, g_tn256_min_steps = 64, g_tn256_min_out_tiles = 50;
 static bool g_nt256_persistent = true;
 static int g_nt256_band = 5;
 // which 256x256 NT kernel: 0 = the one-wave-per-SIMD kernel where it applies (gemm_nt4w.hip), 1 = always the ping-pong kernel.
@@ -1454,7 +1454,7 @@ int wft_nt4w_launch(const wft_gemm_args* a, const GemmP& p, bool persistent, voi
 extern "C" int wft_gemm_set_persistent(int v);
 extern "C" int wft_gemm_set_nt_variant(int v) { const int o = g_nt_variant; if (v >= 0) g_nt_variant = v; return o; }
 static bool g_force_128 = false;  // debugging / A-B switch: WFT_GEMM_FORCE_128=1
-static struct EnvInit { EnvInit() { const char* e = wft_dev_getenv("WFT_GEMM_FORCE_128"); g_force_128 = e && e[0] == '1'; const char* d = wft_dev_getenv("WFT_GEMM_DIAG"); g_diag = d ? atoi(d) : 0; const char* t1 = wft_dev_getenv("WFT_NT256_MIN_TILES"); if (t1) g_nt256_min_tiles = atoi(t1); const char* t2 = wft_dev_getenv("WFT_TN256_MIN_STEPS"); if (t2) g_tn256_min_steps = atoi(t2); const char* pe = getenv("WFT_NT256_PERSISTENT"); if (pe) g_nt256_persistent = pe[0] != '0'; const char* bw = wft_dev_getenv("WFT_NT256_BAND"); if (bw && atoi(bw) > 0) g_nt256_band = atoi(bw); const char* nv = wft_dev_getenv("WFT_NT_VARIANT"); if (nv) g_nt_variant = (nv[0] == 'p') ? 1 : 0; const char* tv = wft_dev_getenv("WFT_TN_VARIANT"); if (tv) g_tn_variant = (tv[0] == 'p') ? 1 : 0; } } g_env_init;
+static struct EnvInit { EnvInit() { const char* e = wft_dev_getenv("WFT_GEMM_FORCE_128"); g_force_128 = e && e[0] == '1'; const char* d = wft_dev_getenv("WFT_GEMM_DIAG"); g_diag = d ? atoi(d) : 0; const char* t1 = wft_dev_getenv("WFT_NT256_MIN_TILES"); if (t1) g_nt256_min_tiles = atoi(t1); const char* t2 = wft_dev_getenv("WFT_TN256_MIN_STEPS"); if (t2) g_tn256_min_steps = atoi(t2); const char* t3 = wft_dev_getenv("WFT_TN256_MIN_OUT_TILES"); if (t3) g_tn256_min_out_tiles = atoi(t3); const char* pe = getenv("WFT_NT256_PERSISTENT"); if (pe) g_nt256_persistent = pe[0] != '0'; const char* bw = wft_dev_getenv("WFT_NT256_BAND"); if (bw && atoi(bw) > 0) g_nt256_band = atoi(bw); const char* nv = wft_dev_getenv("WFT_NT_VARIANT"); if (nv) g_nt_variant = (nv[0] == 'p') ? 1 : 0; const char* tv = wft_dev_getenv("WFT_TN_VARIANT"); if (tv) g_tn_variant = (tv[0] == 'p') ? 1 : 0; } } g_env_init;
 
 extern "C" int wft_gemm_set_persistent(int v) { const int o = g_nt256_persistent ? 1 : 0; if (v >= 0) g_nt256_persistent = v != 0; return o; }
 
@@ -1626,7 +1626,7 @@ extern "C" int wft_gemm_nt_bf16(const wft_gemm_args* a, void* stream) {
 static bool tn_uses_256(const wft_gemm_args* a) {
   const long nsteps = ((a->K + 63) / 64) * a->batch;
   return !g_force_128 && a->c_is_f32 && a->M % 256 == 0 && a->N % 256 == 0 && nsteps >= g_tn256_min_steps &&
-         (nsteps >= 256 || (a->M / 256) * (a->N / 256) >= 50);
+         (nsteps >= 256 || (a->M / 256) * (a->N / 256) >= g_tn256_min_out_tiles);
 }
 static int tn256_nsplit(const wft_gemm_args* a) {
   const long t256 = (a->M / 256) * (a->N / 256);
