@@ -293,9 +293,9 @@ int wft_attn_set_dkdv_variant(int variant);
 /* The same switch for the dQ kernel (attn_bwd_dq4w_kernel: non-causal calls with Tq >= 512).  Start value from
  * WFT_DQ_VARIANT=4w|8w.                                                                                                    */
 int wft_attn_set_dq_variant(int variant);
-/* ... and for the forward kernel, where the DEFAULT is 1, the 8-wave kernel (the one-wave-per-SIMD attn_fwd4w_kernel measured no
- * faster; it serves non-causal calls with Tq >= 512 when selected and moves the running maximum per 32-key block where the 8-wave
- * kernel does per 64-key tile, so outputs agree to fp32 rounding, not bit for bit).  Start value from WFT_FWD_VARIANT=4w|8w.  */
+/* ... and for the forward kernel: 0 (default) = attn_fwd_pipe_kernel (software-pipelined, four-slot K/V ring) for non-causal calls
+ * with Tk >= 512 and attn_fwd_kernel for the rest, 1 = attn_fwd_kernel everywhere.  Bit-identical outputs.  Start value from
+ * WFT_FWD_VARIANT=8w (timing builds only).                                                                                  */
 int wft_attn_set_fwd_variant(int variant);
 /* Launch mode of the persistent dK/dV kernel, like wft_gemm_set_persistent (start value from WFT_ATTN_PERSISTENT).      */
 int wft_attn_set_persistent(int v);

@@ -12,7 +12,7 @@
 #define REPT_BODY(body) ".rept 32\n" body ".endr\n"
 
 template <int T>
-__global__ __launch_bounds__(512) void k(unsigned long long* out, float seed) {
+__global__ __launch_bounds__(1024) void k(unsigned long long* out, float seed) {
   float a0 = seed + threadIdx.x, a1 = a0 * 1.1f, a2 = a0 * 1.2f, a3 = a0 * 1.3f, a4 = a0 * 1.4f, a5 = a0 * 1.5f, a6 = a0 * 1.6f, a7 = a0 * 1.7f;
   float b0 = 0.5f, b1 = 0.25f;
   typedef __attribute__((ext_vector_type(2))) float f2;
@@ -77,8 +77,8 @@ int main() {
                          "ds_read_b128 random gather, 4 + wait (per read)", "v_accvgpr_read_b32 x8", "mfma16x16x32 + exp + 2 fma (per group)",
                          "mfma16x16x32 back to back (dependent chain)", "mfma16x16x32 + 3 fma (per group)", "exp|rcp alternating with pk_fma (per pair)"};
   const int per[] = {8, 8, 8, 8, 8, 8, 2, 4, 4, 8, 2, 2, 2, 4};
-  printf("%-52s %12s %12s   (s_memtime ticks per unit; the clock of s_memtime is 100 MHz on gfx950 if ticks look 20x too small)\n", "test", "1 wave/SIMD", "2 waves/SIMD");
-#define R(T) printf("%-52s %12.2f %12.2f\n", names[T], run<T>(256, per[T]), run<T>(512, per[T]));
+  printf("%-52s %12s %12s %12s  (s_memtime ticks per unit; the clock of s_memtime is 100 MHz on gfx950 if ticks look 20x too small)\n", "test", "1 wave/SIMD", "2 waves/SIMD", "4 waves/SIMD");
+#define R(T) printf("%-52s %12.2f %12.2f %12.2f\n", names[T], run<T>(256, per[T]), run<T>(512, per[T]), run<T>(1024, per[T]));
   R(0) R(1) R(2) R(3) R(4) R(5) R(6) R(7) R(8) R(9) R(10) R(11) R(12) R(13)
   return 0;
 }

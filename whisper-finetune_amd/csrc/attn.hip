@@ -268,6 +268,13 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
+// FWD_ABL=n (developer builds, tools/dev/fwd_abl.sh): attn_fwd_kernel with one ingredient REMOVED — results are wrong, only the
+// kernel's duration means anything.  1 no exponentials (P = c S), 2 no softmax vector work at all (P = S), 3 no P.V MFMAs,
+// 4 no S MFMAs, 5 no LDS-DMA staging behind the first two tiles, 6 no per-tile barrier, 7 no V^T LDS reads, 8 no K fragment reads;
+// 9 is not an ablation: __launch_bounds__(256, 3) (results stay right)
+#ifndef FWD_ABL
+#define FWD_ABL 0
+#endif
 #ifdef FWD_STAMPS  // developer build (tools/dev/fwd_stamps.py, hipcc -DFWD_STAMPS): clock-tick sums per phase of a key tile, all active waves
 __device__ unsigned long long fwd_dbg[16];
 extern "C" void wft_fwd_dbg_read(unsigned long long* host, int reset) {
@@ -293,7 +300,11 @@ extern "C" void wft_fwd_dbg_read(unsigned long long* host, int reset) {
 // The transposed V reads are inline asm: with the builtin, hipcc drains every outstanding LDS-DMA
 // (s_waitcnt vmcnt(0)) in front of the first ds_read_b64_tr of each tile, which cut the prefetch distance to
 // half a tile and left the kernel latency-bound (no-load experiment: +27 %).
+#if FWD_ABL == 9  // (occupancy experiment: three workgroups per CU = three waves per SIMD, <= 168 registers)
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnP p) {
+#else
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
+#endif
   __shared__ __attribute__((aligned(16))) char smem[3 * 16384];  // [slot 3][K 8K | V 8K]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: conditions on it are scalar branches, not exec masks
@@ -360,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
     constexpr int CUR = decltype(cur_tag)::value;
     constexpr int NXT = (CUR + 1) % 3, NXT2 = (CUR + 2) % 3;
     const int key0 = kt * 64;
-    const bool more = kt + 2 < nkt;
+    const bool more = FWD_ABL == 5 ? false : kt + 2 < nkt;
     if (more)
       att_stage2(stK, kb, p.ldk, smem + NXT2 * 16384, stV, vb, p.ldv, smem + NXT2 * 16384 + 8192, key0 + 128, p.Tk, wave, lane);
     // (a wave whose 32 queries all lie past the sequence end — T = 1500: the fourth wave of the last 128-query block — only
@@ -375,11 +386,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
-          for (int t = 0; t < 2; ++t) vt[ks][db][t] = att_tr_asm<CUR * 16384 + 8192 + ks * 2048>(tra[db][t]);
+          for (int t = 0; t < 2; ++t) {
+            if constexpr (FWD_ABL == 7) vt[ks][db][t] = s16x4{(short)lane, 1, 2, 3};
+            else vt[ks][db][t] = att_tr_asm<CUR * 16384 + 8192 + ks * 2048>(tra[db][t]);
+          }
       });
       f32x16 sacc[2];
 #pragma unroll
       for (int kb2 = 0; kb2 < 2; ++kb2) {
+        if constexpr (FWD_ABL == 4) {
+          sacc[kb2] = minit;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) sacc[kb2][s] += __builtin_bit_cast(float, (int)kf[kb2][s][0]) * 1e-30f;  // (keeps the K reads alive)
+          continue;
+        }
         sacc[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb2][0], qf[0], minit, 0, 0, 0);
 #pragma unroll
         for (int s = 1; s < 4; ++s) sacc[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb2][s], qf[s], sacc[kb2], 0, 0, 0);
@@ -394,9 +414,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
             sacc[kb2][e] = (32 * kb2 + (e & 3) + 8 * (e >> 2)) < lim ? sacc[kb2][e] : ATT_NEG;
       }
       FWD_STAMP(1, sacc[1][15]);  // V^T read issue + S MFMA chains complete
-      float tmax = att_xhalf_max(att_max32(sacc[0], sacc[1]));  // max over the tile of S - m
+      float tmax = FWD_ABL == 2 ? 0.f : att_xhalf_max(att_max32(sacc[0], sacc[1]));  // max over the tile of S - m
       FWD_STAMP(2, tmax);  // maximum (in-lane tree + half exchange)
-      if (kt == 0 || __builtin_amdgcn_ballot_w64(tmax * c > ATT_TAU) != 0) {
+      if (FWD_ABL != 2 && (kt == 0 || __builtin_amdgcn_ballot_w64(tmax * c > ATT_TAU) != 0)) {
         // rare path: move the reference maximum (first tile: to the tile's own maximum, whatever its sign)
         const float d = kt == 0 ? tmax : fmaxf(tmax, 0.f);
         const float alpha = __builtin_amdgcn_exp2f(-d * c);
@@ -418,8 +438,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
       for (int kb2 = 0; kb2 < 2; ++kb2)
 #pragma unroll
         for (int e = 0; e < 16; e += 2) {
-          const float p0 = __builtin_amdgcn_exp2f(sacc[kb2][e] * c);
-          const float p1 = __builtin_amdgcn_exp2f(sacc[kb2][e + 1] * c);
+          if constexpr (FWD_ABL == 2) continue;
+          const float p0 = FWD_ABL == 1 ? sacc[kb2][e] * c : __builtin_amdgcn_exp2f(sacc[kb2][e] * c);
+          const float p1 = FWD_ABL == 1 ? sacc[kb2][e + 1] * c : __builtin_amdgcn_exp2f(sacc[kb2][e + 1] * c);
           ls0 += p0;
           ls1 += p1;
           sacc[kb2][e] = p0;
@@ -434,10 +455,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
     if (more) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     FWD_STAMP(4, m);  // own LDS-DMA pieces of tile kt+1 landed, V^T fragments landed
-    __builtin_amdgcn_s_barrier();
+    if constexpr (FWD_ABL != 6) __builtin_amdgcn_s_barrier();
     FWD_STAMP(5, m);  // barrier
     __builtin_amdgcn_sched_barrier(0);
-    if (kt + 1 < nkt) {
+    if (FWD_ABL != 8 && kt + 1 < nkt) {
 #pragma unroll
       for (int kb2 = 0; kb2 < 2; ++kb2)
 #pragma unroll
@@ -447,8 +468,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+        for (int db = 0; db < 2; ++db) {
+          if constexpr (FWD_ABL == 3) {  // (keeps the V^T reads and the packs alive)
+            oacc[db][ks] += __builtin_bit_cast(float, (int)vt[ks][db][0][0] | ((int)vt[ks][db][1][1] << 16)) * 1e-30f + __builtin_bit_cast(float, (int)pf[ks][0]) * 1e-30f;
+            continue;
+          }
           oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_join(vt[ks][db][0], vt[ks][db][1]), pf[ks], oacc[db], 0, 0, 0);
+        }
       FWD_STAMP(6, oacc[1][15]);  // K fragment reads of tile kt+1 issued + P.V MFMA chains complete
     }
   };
@@ -483,6 +509,206 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
     atomicAdd(&fwd_dbg[10], (unsigned long long)nkt);
   }
 #endif
+}
+
+
+// ------------------------------------------------------------------------------ forward, software-pipelined (round 5)
+// The ablation builds of attn_fwd_kernel (FWD_ABL, profiles/r05_attn_fwd.md) behave like a SUM of their parts: taking out the S
+// MFMAs saves 29 % of the kernel, the softmax's vector work 24 %, the P.V MFMAs 11 %, the LDS-DMA staging 13 %, the V^T reads
+// 13 % — a wave issues its S chains and then sits on their results, and with the oldest-wave-first arbiter the second wave of the
+// SIMD does not fill that hole reliably.  Here the S chains of tile kt+1 are issued BEHIND the softmax of tile kt and IN FRONT of
+// its P.V chains: they run on the matrix pipe while the wave goes through the end-of-tile wait, the barrier, the next tile's
+// staging and V^T reads, and tile kt+1's softmax finds its scores finished.  That needs tile kt+1's K fragments one barrier
+// earlier, so the K/V ring has FOUR slots and is staged three tiles ahead (64 KiB per workgroup, two workgroups per CU):
+//   iteration kt: stage kt+3 | V^T(kt) reads | softmax(kt) -> P | S(kt+1) MFMAs | wait own pieces of kt+2, barrier |
+//                 K(kt+2) fragment reads | P.V(kt) MFMAs
+// Same arithmetic in the same order as attn_fwd_kernel (the stale maximum that enters S(kt+1) as its initial accumulator is the
+// one softmax(kt) has just settled, exactly what the un-pipelined kernel uses at the head of tile kt+1): bit-identical results.
+__global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(AttnP p) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * 16384];  // [slot 4][K 8K | V 8K]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  int bx, hd, b;
+  att_block_coords((p.Tq + 127) >> 7, p.H, p.B, p.xcd, bx, hd, b);
+  const int q0 = bx * 128;
+  const int qw0 = q0 + wave * 32;
+  const int qi = qw0 + r;
+  const int qc = qi < p.Tq ? qi : p.Tq - 1;
+  const unsigned short* qrow = p.q + (long)b * p.q_bs + (long)qc * p.ldq + hd * 64;
+  const unsigned short* kb = p.k + (long)b * p.k_bs + hd * 64;
+  const unsigned short* vb = p.v + (long)b * p.v_bs + hd * 64;
+  const float c = p.scale * LOG2E;
+  bf16x8 qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) qf[s] = att_load_reg_frag(qrow, s, h);
+  const AttOffs offs = att_offsets(lane);
+  const AttStage stK = att_stage_init(p.ldk, wave, lane), stV = att_stage_init(p.ldv, wave, lane);
+  const unsigned lds0 = lds_addr_of(smem);
+  unsigned tra[2][2];
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) tra[db][t] = lds0 + offs.tr[db][t];
+
+  int nkt = (p.Tk + 63) >> 6;
+  if (p.causal) {
+    const int last = (q0 + 127) / 64 + 1;
+    nkt = nkt < last ? nkt : last;
+  }
+  const f32x16 zero16 = f32x16{0};
+  f32x16 oacc[2];
+  oacc[0] = zero16;
+  oacc[1] = zero16;
+  float m = 0.f, l = 0.f;
+  f32x16 minit = zero16;
+  auto is_active = [&](int kt) { return qw0 < p.Tq && !(p.causal && kt * 64 > qw0 + 31); };
+
+  // prologue: tiles 0, 1, 2 on their way; tiles 0 and 1 certified by the first barrier
+  att_stage2(stK, kb, p.ldk, smem, stV, vb, p.ldv, smem + 8192, 0, p.Tk, wave, lane);
+  if (nkt > 1) att_stage2(stK, kb, p.ldk, smem + 16384, stV, vb, p.ldv, smem + 16384 + 8192, 64, p.Tk, wave, lane);
+  if (nkt > 2) {
+    att_stage2(stK, kb, p.ldk, smem + 2 * 16384, stV, vb, p.ldv, smem + 2 * 16384 + 8192, 128, p.Tk, wave, lane);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  bf16x8 kf[2][4];  // K row fragments of the NEXT tile to be multiplied
+  f32x16 sacc[2];   // scores of the CURRENT tile (S chains issued one tile ahead)
+#pragma unroll
+  for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) kf[kb2][s] = att_row_frag(smem, offs, kb2, s);
+  sacc[0] = sacc[1] = zero16;
+  if (is_active(0)) {
+#pragma unroll
+    for (int kb2 = 0; kb2 < 2; ++kb2) {
+      sacc[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb2][0], qf[0], minit, 0, 0, 0);
+#pragma unroll
+      for (int s = 1; s < 4; ++s) sacc[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb2][s], qf[s], sacc[kb2], 0, 0, 0);
+    }
+  }
+  if (nkt > 1) {
+#pragma unroll
+    for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) kf[kb2][s] = att_row_frag(smem + 16384, offs, kb2, s);
+  }
+
+  auto tile = [&](auto cur_tag, int kt) {
+    constexpr int CUR = decltype(cur_tag)::value;
+    constexpr int NXT2 = (CUR + 2) % 4, NXT3 = (CUR + 3) % 4;
+    const int key0 = kt * 64;
+    const bool more = kt + 3 < nkt;
+    if (more)
+      att_stage2(stK, kb, p.ldk, smem + NXT3 * 16384, stV, vb, p.ldv, smem + NXT3 * 16384 + 8192, key0 + 192, p.Tk, wave, lane);
+    const bool active = is_active(kt);
+    s16x4 vt[4][2][2];
+    bf16x8 pf[4];
+    if (active) {
+      static_for<4>([&](auto ks_tag) {
+        constexpr int ks = decltype(ks_tag)::value;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) vt[ks][db][t] = att_tr_asm<CUR * 16384 + 8192 + ks * 2048>(tra[db][t]);
+      });
+      if ((key0 + 64 > p.Tk) || (p.causal && key0 + 63 > qw0)) {
+        const int lim = (p.causal ? (qi + 1 < p.Tk ? qi + 1 : p.Tk) : p.Tk) - key0 - 4 * h;
+#pragma unroll
+        for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            sacc[kb2][e] = (32 * kb2 + (e & 3) + 8 * (e >> 2)) < lim ? sacc[kb2][e] : ATT_NEG;
+      }
+      const float tmax = att_xhalf_max(att_max32(sacc[0], sacc[1]));
+      if (kt == 0 || __builtin_amdgcn_ballot_w64(tmax * c > ATT_TAU) != 0) {
+        const float d = kt == 0 ? tmax : fmaxf(tmax, 0.f);
+        const float alpha = __builtin_amdgcn_exp2f(-d * c);
+        m += d;
+        l *= alpha;
+#pragma unroll
+        for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) sacc[kb2][e] -= d;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) oacc[db][e] *= alpha;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) minit[e] = -m;
+      }
+      float ls0 = 0.f, ls1 = 0.f;
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+          const f32x2 sc = f32x2{sacc[kb2][e], sacc[kb2][e + 1]} * c;  // (one v_pk_mul_f32 per pair: hipcc leaves the scalar form unpacked)
+          const float p0 = __builtin_amdgcn_exp2f(sc[0]);
+          const float p1 = __builtin_amdgcn_exp2f(sc[1]);
+          ls0 += p0;
+          ls1 += p1;
+          sacc[kb2][e] = p0;
+          sacc[kb2][e + 1] = p1;
+        }
+      l += att_xhalf_sum(ls0 + ls1);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) pf[ks] = att_pack8(sacc[ks >> 1], ks & 1);
+    }
+    // the NEXT tile's scores: on the matrix pipe from here, consumed by the next iteration's softmax
+    if (kt + 1 < nkt && is_active(kt + 1)) {
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; ++kb2) {
+        sacc[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb2][0], qf[0], minit, 0, 0, 0);
+#pragma unroll
+        for (int s = 1; s < 4; ++s) sacc[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb2][s], qf[s], sacc[kb2], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 2 < nkt) {
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) kf[kb2][s] = att_row_frag(smem + NXT2 * 16384, offs, kb2, s);
+    }
+    if (active) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_join(vt[ks][db][0], vt[ks][db][1]), pf[ks], oacc[db], 0, 0, 0);
+    }
+  };
+  int kt = 0;
+  for (; kt + 3 < nkt; kt += 4) {
+    tile(IntC<0>{}, kt);
+    tile(IntC<1>{}, kt + 1);
+    tile(IntC<2>{}, kt + 2);
+    tile(IntC<3>{}, kt + 3);
+  }
+  if (kt < nkt) tile(IntC<0>{}, kt);
+  if (kt + 1 < nkt) tile(IntC<1>{}, kt + 1);
+  if (kt + 2 < nkt) tile(IntC<2>{}, kt + 2);
+
+  if (qi < p.Tq) {
+    const float inv = 1.0f / l;
+    unsigned short* orow = p.o + (long)b * p.o_bs + (long)qi * p.ldo + hd * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int d = 32 * db + 8 * a + 4 * h;
+        u32x2 pk = {pack2bf(oacc[db][4 * a] * inv, oacc[db][4 * a + 1] * inv),
+                    pack2bf(oacc[db][4 * a + 2] * inv, oacc[db][4 * a + 3] * inv)};
+        *(u32x2*)(orow + d) = pk;
+      }
+    if (h == 0 && p.lse) p.lse[((long)b * p.H + hd) * p.Tq + qi] = m * p.scale + __logf(l);
+  }
 }
 
 // ------------------------------------------------------------------------------ delta
@@ -1916,389 +2142,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq4w_kernel(AttnP p) {
 }
 
 
-// ------------------------------------------------------------------------------ forward, one wave per SIMD (round 4)
-// attn_bwd_dq4w_kernel's frame with the softmax of attn_fwd_kernel: a wave owns 64 queries (Q fragments a[64:95], O^T accumulators
-// a[0:63]) and streams 32-key blocks from LDS tiles {K, V}; S^T[key, query] puts one query in a lane, so the running maximum m and
-// the row sum l are per-lane scalars.  Lazy rescaling as in attn_fwd_kernel: -m rides in the C operand of each S chain (16 copies per
-// query block), and only when a block's maximum exceeds it by more than ATT_TAU (log2 units) — always for the first block — does the
-// slow path move m, scale l and the O accumulators and rewrite the copies.  Per iteration: the PV MFMAs of block j-1 beside the
-// maximum of block j, the decision, then the S MFMAs of block j+1 beside the 32 multiplies, exponentials, sums and the 16 packs of
-// block j.  The decision is per 32-key block (the 8-wave kernel decides per 64-key tile), so m moves at different moments: same sums
-// up to fp32 rounding, not the same bits.  l is kept as per-lane partial sums (a query's two lanes meet in the epilogue); forming it
-// on the matrix pipe instead (a ones operand beside V^T) was measured: no faster, and lse loses three digits (sums of bf16 P).
-#define F4_TAU_BITS 0x41000000u  // 8.0f = ATT_TAU
-#define F4_ASM_MACROS R"ASM(
-; registers: S(g,qb) v[g+16qb..+15], g = 128 / 160; PF(qb) v[32+8qb..+7]; TV(ks,db) v[48+8ks+4db..+3]; -m copies MI(qb) v[64+16qb..+15];
-; m v[96+qb], l v[98+qb] (per-lane partial sums), floor v100 (first block: -3e38, then 0), threshold v101 (first block: -3e38, then tau), block maxima
-; v[102+qb], scratch v104..v107, v112..v114; O^T(qb,db) a[32qb+16db..+15]; QF(qb,s) a[64+16qb+4s..+3]; K row fragments AK(s) a[96+4s..+3]
-.macro F4_M2 n
-  v_mfma_f32_32x32x16_bf16 a[32*((\n)/4)+16*((\n)%%2):32*((\n)/4)+16*((\n)%%2)+15], v[48+8*(((\n)/2)%%2)+4*((\n)%%2):48+8*(((\n)/2)%%2)+4*((\n)%%2)+3], v[32+8*((\n)/4)+4*(((\n)/2)%%2):32+8*((\n)/4)+4*(((\n)/2)%%2)+3], a[32*((\n)/4)+16*((\n)%%2):32*((\n)/4)+16*((\n)%%2)+15]
-.endm
-.macro F4_M1 n, g
-  .if ((\n) %% 4) == 0
-    v_mfma_f32_32x32x16_bf16 v[\g+16*((\n)/4):\g+16*((\n)/4)+15], a[96:99], a[64+16*((\n)/4):64+16*((\n)/4)+3], v[64+16*((\n)/4):64+16*((\n)/4)+15]
-  .else
-    v_mfma_f32_32x32x16_bf16 v[\g+16*((\n)/4):\g+16*((\n)/4)+15], a[96+4*((\n)%%4):96+4*((\n)%%4)+3], a[64+16*((\n)/4)+4*((\n)%%4):64+16*((\n)/4)+4*((\n)%%4)+3], v[\g+16*((\n)/4):\g+16*((\n)/4)+15]
-  .endif
-.endm
-.macro F4_RD1 i, rb, hf
-  ds_read_b128 a[96+4*(\i):96+4*(\i)+3], \rb offset:512*\hf+32*(\i)
-.endm
-; transposed V read m (0..7) in the order the PV MFMAs consume them: (ks, db) = (m/4, (m/2)%%2), t = m%%2
-.macro F4_RD2 m, tb, hf
-  ds_read_b64_tr_b16 v[48+8*((\m)/4)+4*(((\m)/2)%%2)+2*((\m)%%2):48+8*((\m)/4)+4*(((\m)/2)%%2)+2*((\m)%%2)+1], \tb offset:10240+5152*((\m)%%2)+128*(4*\hf+2*((\m)/4))+64*(((\m)/2)%%2)
-.endm
-; maximum over the 32 keys of a block for query block \qb -> v[102+\qb] (16 registers in the lane, then the partner lane)
-; the slow path of one query block: d = max(block maximum, floor); m += d; alpha = 2^(-d c); l, O *= alpha; S' -= d; -m copies rewritten
-.macro F4_RESCALE qb, g
-  v_max_f32 v104, v[102+\qb], v100
-  v_mul_f32 v105, %[c], v104
-  v_exp_f32 v105, -v105
-  v_add_f32 v[96+\qb], v[96+\qb], v104
-  v_mul_f32 v[98+\qb], v[98+\qb], v105
-  .set f4_i, 0
-  .rept 16
-    v_sub_f32 v[\g+16*\qb+f4_i], v[\g+16*\qb+f4_i], v104
-    .set f4_i, f4_i+1
-  .endr
-  .set f4_i, 0
-  .rept 32
-    v_accvgpr_read_b32 v106, a[32*\qb+f4_i]
-    s_nop 1
-    v_mul_f32 v106, v105, v106
-    s_nop 1
-    v_accvgpr_write_b32 a[32*\qb+f4_i], v106
-    .set f4_i, f4_i+1
-  .endr
-  v_sub_f32 v106, 0, v[96+\qb]
-  .set f4_i, 0
-  .rept 16
-    v_mov_b32 v[64+16*\qb+f4_i], v106
-    .set f4_i, f4_i+1
-  .endr
-.endm
-; one iteration.  gV: generation of block j (softmax here), gM: of block j+1 (S MFMAs); rb1, hf1 / tb2, hf2 as in Q4_ITER; dma: LDS-DMA of
-; the tile two ahead; mask: keys at or past \lim + (8 a + e) are switched off (x -> -1e30) before the maximum
-.macro F4_ITER gV, gM, rb1, hf1, tb2, hf2, dma, mask, lim
-  ; ---- PV of block j-1 beside the maximum of block j
-  .if \mask
-    .set f4_i, 0
-    .rept 16
-      v_cmp_gt_i32 vcc, \lim, 8*(f4_i/4)+(f4_i%%4)
-      v_cndmask_b32 v[\gV+f4_i], v31, v[\gV+f4_i], vcc
-      v_cndmask_b32 v[\gV+16+f4_i], v31, v[\gV+16+f4_i], vcc
-      .set f4_i, f4_i+1
-    .endr
-  .endif
-  s_waitcnt lgkmcnt(6)
-  F4_M2 0
-  F4_RD1 0, \rb1, \hf1
-  v_max3_f32 v104, v[\gV], v[\gV+1], v[\gV+2]
-  v_max3_f32 v105, v[\gV+3], v[\gV+4], v[\gV+5]
-  v_max3_f32 v106, v[\gV+6], v[\gV+7], v[\gV+8]
-  s_waitcnt lgkmcnt(5)
-  F4_M2 1
-  F4_RD1 1, \rb1, \hf1
-  v_max3_f32 v107, v[\gV+9], v[\gV+10], v[\gV+11]
-  v_max3_f32 v112, v[\gV+12], v[\gV+13], v[\gV+14]
-  v_max3_f32 v104, v104, v105, v[\gV+15]
-  s_waitcnt lgkmcnt(4)
-  F4_M2 2
-  F4_RD1 2, \rb1, \hf1
-  v_max3_f32 v106, v106, v107, v112
-  v_max_f32 v104, v104, v106
-  v_mov_b32 v105, v104
-  s_waitcnt lgkmcnt(3)
-  F4_M2 3
-  F4_RD1 3, \rb1, \hf1
-  v_permlane32_swap_b32 v104, v105
-  v_max3_f32 v113, v[\gV+16], v[\gV+17], v[\gV+18]
-  v_max3_f32 v114, v[\gV+19], v[\gV+20], v[\gV+21]
-  F4_M2 4
-  v_max_f32 v102, v104, v105
-  v_max3_f32 v106, v[\gV+22], v[\gV+23], v[\gV+24]
-  v_max3_f32 v107, v[\gV+25], v[\gV+26], v[\gV+27]
-  F4_M2 5
-  v_max3_f32 v112, v[\gV+28], v[\gV+29], v[\gV+30]
-  v_max3_f32 v113, v113, v114, v[\gV+31]
-  v_max3_f32 v106, v106, v107, v112
-  F4_M2 6
-  v_max_f32 v113, v113, v106
-  v_mov_b32 v114, v113
-  v_mul_f32 v104, %[c], v102
-  F4_M2 7
-  v_permlane32_swap_b32 v113, v114
-  s_nop 1
-  v_max_f32 v103, v113, v114
-  v_mul_f32 v105, %[c], v103
-  v_max_f32 v104, v104, v105
-  v_cmp_gt_f32 vcc, v104, v101
-  s_cbranch_vccz 7f
-  ; ---- slow path (rare; always for the first block): the PV MFMAs above must have written the accumulators
-  s_nop 15
-  s_nop 15
-  F4_RESCALE 0, \gV
-  F4_RESCALE 1, \gV
-  v_mov_b32 v100, 0
-  v_mov_b32 v101, )ASM" D4_STR(F4_TAU_BITS) R"ASM(
-7:
-  s_waitcnt lgkmcnt(0)
-  ; ---- S of block j+1 beside p = 2^(c S'), the row sums and the packs of block j
-  .set f4_s, 0
-  .rept 8
-    F4_M1 f4_s, \gM
-    v_mul_f32 v[\gV+2*f4_s], %[c], v[\gV+2*f4_s]
-    v_mul_f32 v[\gV+16+2*f4_s], %[c], v[\gV+16+2*f4_s]
-    v_exp_f32 v[\gV+2*f4_s], v[\gV+2*f4_s]
-    F4_RD2 f4_s, \tb2, \hf2
-    v_mul_f32 v[\gV+2*f4_s+1], %[c], v[\gV+2*f4_s+1]
-    v_exp_f32 v[\gV+16+2*f4_s], v[\gV+16+2*f4_s]
-    v_mul_f32 v[\gV+16+2*f4_s+1], %[c], v[\gV+16+2*f4_s+1]
-    v_exp_f32 v[\gV+2*f4_s+1], v[\gV+2*f4_s+1]
-    v_add_f32 v98, v98, v[\gV+2*f4_s]
-    v_exp_f32 v[\gV+16+2*f4_s+1], v[\gV+16+2*f4_s+1]
-    v_add_f32 v99, v99, v[\gV+16+2*f4_s]
-    .if \dma && f4_s < 4
-      Q4_DMA f4_s, s65
-    .endif
-    .if \dma && f4_s == 4
-      Q4_ADVANCE
-    .endif
-    v_add_f32 v98, v98, v[\gV+2*f4_s+1]
-    v_cvt_pk_bf16_f32 v[32+f4_s], v[\gV+2*f4_s], v[\gV+2*f4_s+1]
-    v_add_f32 v99, v99, v[\gV+16+2*f4_s+1]
-    v_cvt_pk_bf16_f32 v[40+f4_s], v[\gV+16+2*f4_s], v[\gV+16+2*f4_s+1]
-    .set f4_s, f4_s+1
-  .endr
-.endm
-.macro F4_PAIR mask
-    s_waitcnt vmcnt(0)
-    s_barrier
-    F4_ITER 128, 160, v24, 1, v25, 0, 1, \mask, v29
-    F4_ITER 160, 128, v27, 0, v25, 1, 0, \mask, v30
-    s_mov_b32 s67, s63
-    s_mov_b32 s63, s64
-    s_mov_b32 s64, s65
-    s_mov_b32 s65, s67
-    v_add_u32 v24, s63, %[rb]
-    v_add_u32 v25, s63, %[tb]
-    v_add_u32 v27, s64, %[rb]
-.endm
-)ASM"
-#define F4_ASM_PURGE R"ASM(
-.purgem F4_M2
-.purgem F4_M1
-.purgem F4_RD1
-.purgem F4_RD2
-.purgem F4_RESCALE
-.purgem F4_ITER
-.purgem F4_PAIR
-)ASM"
-
-__global__ __launch_bounds__(256) void attn_fwd4w_kernel(AttnP p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 31, h = lane >> 5;
-  int bx, hd, b;
-  att_block_coords((p.Tq + 255) >> 8, p.H, p.B, p.xcd, bx, hd, b);
-  const int qw0 = bx * 256 + wave * 64;
-  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
-  const int c = r & 15, pidr = (c & 1) | ((c >> 2) << 1);
-  const unsigned rb = lds0 + pidr * D4_PIECE + 64 * (pidr & 1) + 16 * (pidr >> 1) + (2 * (r >> 4) + ((c >> 1) & 1)) * 128 + h * 16;
-  const int g4 = lane >> 4, i16 = lane & 15, pidt = ((i16 >> 2) & 1) | ((g4 >> 1) << 1);
-  const unsigned tb = lds0 + pidt * D4_PIECE + 64 * (pidt & 1) + 16 * (pidt >> 1) + ((i16 >> 3) & 1) * 128 + 32 * (g4 & 1) + 8 * (i16 & 3);
-  const int slot = lane >> 3, ch = lane & 7;
-  auto krow = [&](int pid) { return (pid & 1) + 4 * (pid >> 1) + 2 * (slot & 1) + 16 * (slot >> 1); };
-  const unsigned voK0 = (unsigned)(krow(2 * wave) * (int)p.ldk + ch * 8) * 2u, voK1 = (unsigned)(krow(2 * wave + 1) * (int)p.ldk + ch * 8) * 2u;
-  const unsigned voV0 = (unsigned)(krow(2 * wave) * (int)p.ldv + ch * 8) * 2u, voV1 = (unsigned)(krow(2 * wave + 1) * (int)p.ldv + ch * 8) * 2u;
-  auto sg64 = [](unsigned long long x) {
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)x), hi = __builtin_amdgcn_readfirstlane((unsigned)(x >> 32));
-    return ((unsigned long long)hi << 32) | lo;
-  };
-  const unsigned long long bQ = sg64((unsigned long long)(p.q + (long)b * p.q_bs + hd * 64));
-  const unsigned long long bK = sg64((unsigned long long)(p.k + (long)b * p.k_bs + hd * 64));
-  const unsigned long long bV = sg64((unsigned long long)(p.v + (long)b * p.v_bs + hd * 64));
-  const unsigned voQ = (unsigned)((qw0 + 2 * (slot & 1) + 16 * (slot >> 1)) * (int)p.ldq + ch * 8) * 2u;
-  const unsigned tq = __builtin_amdgcn_readfirstlane((unsigned)p.Tq), tk = __builtin_amdgcn_readfirstlane((unsigned)p.Tk);
-  const unsigned ldq2 = __builtin_amdgcn_readfirstlane((unsigned)p.ldq * 2u);
-  const unsigned stK = __builtin_amdgcn_readfirstlane((unsigned)p.ldk * 128u), stV = __builtin_amdgcn_readfirstlane((unsigned)p.ldv * 128u);
-  const unsigned npair = __builtin_amdgcn_readfirstlane((unsigned)((p.Tk + 63) >> 6));
-  const int lim0 = p.Tk - 64 * ((p.Tk + 63) / 64 - 1) - 4 * h;
-  const float cscale = p.scale * LOG2E;
-  const unsigned cbits = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, cscale));
-  const unsigned wv = (unsigned)wave;
-  float m0, m1, l0, l1;
-
-  asm volatile(Q4_ASM_MACROS F4_ASM_MACROS R"ASM(
-    ; ---- descriptors: K s[40:43], V s[44:47] (tile strides s56, s57), Q s[68:71]
-    s_mov_b64 s[40:41], %[bK]
-    s_lshr_b32 s61, %[stK], 6
-    s_sub_u32 s62, %[tk], 1
-    s_mul_i32 s42, s62, s61
-    s_add_u32 s42, s42, 128
-    s_mov_b32 s43, 0x20000
-    s_mov_b64 s[44:45], %[bV]
-    s_lshr_b32 s61, %[stV], 6
-    s_mul_i32 s46, s62, s61
-    s_add_u32 s46, s46, 128
-    s_mov_b32 s47, 0x20000
-    s_mov_b32 s56, %[stK]
-    s_mov_b32 s57, %[stV]
-    s_mov_b64 s[68:69], %[bQ]
-    s_sub_u32 s62, %[tq], 1
-    s_mul_i32 s70, s62, %[ldq2]
-    s_add_u32 s70, s70, 128
-    s_mov_b32 s71, 0x20000
-    ; Q rows of this wave's 64 queries -> its transit area (s53) as one tile in the piece layout, from there into a[64:95] below
-    s_mul_i32 s53, %[wave], 10240
-    s_add_u32 s53, s53, 3*)ASM" D4_STR(Q4_BUF) R"ASM(
-    s_add_u32 s53, s53, %[lds0]
-    .set f4_i, 0
-    .rept 8
-      s_mul_i32 s61, %[ldq2], (f4_i%%2)+4*(f4_i/2)
-      v_add_u32 v29, s61, %[voQ]
-      s_add_u32 m0, s53, f4_i*1280+64*(f4_i%%2)+16*(f4_i/2)
-      s_nop 0
-      buffer_load_dwordx4 v29, s[68:71], 0 offen lds
-      .set f4_i, f4_i+1
-    .endr
-    s_lshl_b32 s61, %[wave], 1
-    s_mul_i32 s58, s61, 1280
-    s_lshr_b32 s62, s61, 1
-    s_lshl_b32 s62, s62, 4
-    s_add_u32 s58, s58, s62
-    s_add_u32 s58, s58, %[lds0]
-    s_add_u32 s59, s58, 1344
-    s_mov_b32 s63, 0
-    s_mov_b32 s64, )ASM" D4_STR(Q4_BUF) R"ASM(
-    s_mov_b32 s65, 2*)ASM" D4_STR(Q4_BUF) R"ASM(
-    s_sub_u32 s66, %[npair], 1
-    Q4_STAGE s63
-    Q4_ADVANCE
-    s_nop 4
-    Q4_STAGE s64
-    Q4_ADVANCE
-    ; ---- (under the loads) accumulators, packed P, transposed fragments, -m copies, m and l start from zero
-    .set f4_i, 0
-    .rept 64
-      v_accvgpr_write_b32 a[f4_i], 0
-      .set f4_i, f4_i+1
-    .endr
-    .set f4_i, 32
-    .rept 68
-      v_mov_b32 v[f4_i], 0
-      .set f4_i, f4_i+1
-    .endr
-    v_mov_b32 v100, 0xff61b1e6     ; -3e38: the first block always takes the slow path with d = its own maximum
-    v_mov_b32 v101, 0xff61b1e6
-    v_mov_b32 v31, 0xf149f2ca      ; -1e30
-    v_mov_b32 v29, %[lim0]
-    v_add_u32 v30, -32, v29
-    v_mov_b32 v24, %[rb]
-    v_mov_b32 v25, %[tb]
-    v_add_u32 v27, s64, v24
-    s_waitcnt vmcnt(4)             ; Q rows and tile 0
-    s_barrier
-    s_sub_u32 s61, s53, %[lds0]
-    v_add_u32 v26, s61, %[rb]
-    .set f4_i, 0
-    .rept 8
-      ds_read_b128 a[64+16*(f4_i/4)+4*(f4_i%%4):64+16*(f4_i/4)+4*(f4_i%%4)+3], v26 offset:512*(f4_i/4)+32*(f4_i%%4)
-      .set f4_i, f4_i+1
-    .endr
-    ; ---- block 0: K row fragments, S -> generation 128 (from C = 0)
-    .set f4_i, 0
-    .rept 4
-      F4_RD1 f4_i, v24, 0
-      .set f4_i, f4_i+1
-    .endr
-    s_waitcnt lgkmcnt(0)
-    .set f4_i, 0
-    .rept 8
-      F4_M1 f4_i, 128
-      .set f4_i, f4_i+1
-    .endr
-    s_nop 15
-    s_nop 15
-    s_cmp_eq_u32 s66, 0
-    s_cbranch_scc1 5f
-1:
-    F4_PAIR 0
-    s_sub_u32 s66, s66, 1
-    s_cmp_eq_u32 s66, 0
-    s_cbranch_scc0 1b
-5:
-    F4_PAIR 1
-    ; ---- PV of the last block
-    s_waitcnt lgkmcnt(0)
-    s_nop 1
-    .set f4_i, 0
-    .rept 8
-      F4_M2 f4_i
-      .set f4_i, f4_i+1
-    .endr
-    v_mov_b32 %[m0], v96
-    v_mov_b32 %[m1], v97
-    v_mov_b32 %[l0], v98
-    v_mov_b32 %[l1], v99
-    s_waitcnt vmcnt(0)
-    s_nop 15
-  )ASM" F4_ASM_PURGE Q4_ASM_PURGE
-               : [m0] "=&v"(m0), [m1] "=&v"(m1), [l0] "=&v"(l0), [l1] "=&v"(l1)
-               : [rb] "v"(rb), [tb] "v"(tb), [voK0] "v"(voK0), [voK1] "v"(voK1), [voV0] "v"(voV0), [voV1] "v"(voV1), [voQ] "v"(voQ),
-                 [lim0] "v"(lim0), [bK] "s"(bK), [bV] "s"(bV), [bQ] "s"(bQ), [tq] "s"(tq), [tk] "s"(tk), [ldq2] "s"(ldq2), [stK] "s"(stK),
-                 [stV] "s"(stV), [npair] "s"(npair), [c] "s"(cbits), [lds0] "s"(lds0), [wave] "s"(wv)
-               : "memory", "vcc", "scc", Q4_CLOBBER_A, D4_CLOBBER_V, D4_CLOBBER_S);
-
-  // ---- epilogue: O = acc / l (lane (r, h) holds O [query qw0 + 32 qb + r][d = 32 db + 8 a + 4 h + e]), lse = m scale + ln l
-  auto row16 = [&](const f32x16& acc, int m, float mul) {
-    const unsigned x0 = pack2bf(acc[8 * m] * mul, acc[8 * m + 1] * mul), x1 = pack2bf(acc[8 * m + 2] * mul, acc[8 * m + 3] * mul);
-    const unsigned y0 = pack2bf(acc[8 * m + 4] * mul, acc[8 * m + 5] * mul), y1 = pack2bf(acc[8 * m + 6] * mul, acc[8 * m + 7] * mul);
-    const auto s0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false), s1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
-    u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
-    return o;
-  };
-  auto store = [&](auto qbc, float mq, float lpart) {
-    constexpr int qb = decltype(qbc)::value;
-    const int qi = qw0 + 32 * qb + r;
-    const float l = lpart + __shfl_xor(lpart, 32, 64);
-    const float inv = 1.0f / l;
-    f32x16 o[2];
-    o[0] = d4_get16<32 * qb>(); o[1] = d4_get16<32 * qb + 16>();
-    unsigned short* orow = p.o + (long)b * p.o_bs + (long)qi * p.ldo + hd * 64;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const u32x4 pk = row16(o[db], m, inv);
-        if (qi < p.Tq) *(u32x4*)(orow + 32 * db + 8 * (2 * m + h)) = pk;
-      }
-    if (h == 0 && qi < p.Tq && p.lse) p.lse[((long)b * p.H + hd) * p.Tq + qi] = mq * p.scale + __logf(l);
-  };
-  store(IntC<0>{}, m0, l0);
-  store(IntC<1>{}, m1, l1);
-}
-
-
 #define ATT_ALIGNED(ptr, ld, bs) ((((uintptr_t)(ptr)) & 15) == 0 && ((ld) % 8) == 0 && ((bs) % 8) == 0)
 
-#define F4_LDS (3 * Q4_BUF + 4 * 10240)  // three {K, V} tile buffers + one Q transit area per wave
-// Which forward kernel: 1 (default) the 8-wave kernel, 0 the one-wave-per-SIMD kernel for non-causal calls with Tq >= 512.
-// WFT_FWD_VARIANT=8w|4w sets the start value.  The forward is bound by vector issue (per MFMA: 8 vector instructions, against 4 in
-// the backward kernels) and gains nothing from the 4-wave frame: 505-546 us against 541-547 us per encoder call at B = 32, whole
-// step 626 against 623-626 ms (profiles/README.md, round 4).  The kernel stays as the measured alternative.
-static int g_fwd_variant = [] { const char* e = wft_dev_getenv("WFT_FWD_VARIANT"); return (e && !strcmp(e, "4w")) ? 0 : 1; }();
+// Forward kernel choice: 0 (default) = attn_fwd_pipe_kernel (software-pipelined: S of tile kt+1 behind the softmax of tile kt) for
+// non-causal calls with Tk >= 512 — the encoder — and attn_fwd_kernel for the rest (the short key ranges of the decoder: the
+// four-slot ring's longer prologue costs 2-5 % there); 1 = attn_fwd_kernel everywhere.  Bit-identical results either way.
+// (Round 4's one-wave-per-SIMD forward kernel measured equal to attn_fwd_kernel and was removed in round 5.)
+static int g_fwd_variant = [] { const char* e = wft_dev_getenv("WFT_FWD_VARIANT"); return (e && !strcmp(e, "8w")) ? 1 : 0; }();
 extern "C" int wft_attn_set_fwd_variant(int v) {
   const int old = g_fwd_variant;
   if (v >= 0) g_fwd_variant = v ? 1 : 0;
   return old;
 }
-static bool wft_fwd4w_eligible(const wft_attn_args* a) {
-  static const int min_tq = [] { const char* e = wft_dev_getenv("WFT_FWD4W_MIN_TQ"); return e ? atoi(e) : 512; }();
-  if (g_fwd_variant != 0 || a->causal || a->Tq < min_tq) return false;
-  const long lim = 0x7fffffffL;
-  return (long)(a->Tq + 256) * a->ldq * 2 < lim && (long)(a->Tk + 256) * a->ldk * 2 < lim && (long)(a->Tk + 256) * a->ldv * 2 < lim;
+static bool wft_fwd_pipe_eligible(const wft_attn_args* a) {
+  static const int min_tk = [] { const char* e = wft_dev_getenv("WFT_FWDPIPE_MIN_TK"); return e ? atoi(e) : 512; }();
+  return g_fwd_variant == 0 && !a->causal && a->Tk >= min_tk;
 }
 
 extern "C" int wft_attn_fwd_bf16(const wft_attn_args* a, void* stream) {
@@ -2310,23 +2168,9 @@ extern "C" int wft_attn_fwd_bf16(const wft_attn_args* a, void* stream) {
   WFT_CHECK_ARG(!a->causal || a->Tq == a->Tk, "causal attention needs Tq == Tk");
   AttnP p;
   attn_fill(a, p);
-  if (wft_fwd4w_eligible(a)) {
-    static bool ldsf_set[64] = {false};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (!ldsf_set[dev]) {
-      const hipError_t e = hipFuncSetAttribute((const void*)attn_fwd4w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F4_LDS);
-      if (e != hipSuccess) {
-        wft_set_error("wft_attn_fwd_bf16: the kernel needs %d bytes of dynamic LDS, hipFuncSetAttribute: %s", F4_LDS, hipGetErrorString(e));
-        return WFT_ERR_LAUNCH;
-      }
-      ldsf_set[dev] = true;
-    }
-    hipLaunchKernelGGL(attn_fwd4w_kernel, dim3((unsigned)(((a->Tq + 255) / 256) * a->H * a->B)), dim3(256), F4_LDS, (hipStream_t)stream, p);
-  } else {
-    dim3 grid((unsigned)(((a->Tq + 127) / 128) * a->H * a->B)), block(256);  // 1-D: see att_block_coords
-    hipLaunchKernelGGL(attn_fwd_kernel, grid, block, 0, (hipStream_t)stream, p);
-  }
+  dim3 grid((unsigned)(((a->Tq + 127) / 128) * a->H * a->B)), block(256);  // 1-D: see att_block_coords
+  if (wft_fwd_pipe_eligible(a)) hipLaunchKernelGGL(attn_fwd_pipe_kernel, grid, block, 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(attn_fwd_kernel, grid, block, 0, (hipStream_t)stream, p);
   WFT_CHECK_LAUNCH();
   return WFT_OK;
 }

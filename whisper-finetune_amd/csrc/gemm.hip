@@ -1625,8 +1625,11 @@ extern "C" int wft_gemm_nt_bf16(const wft_gemm_args* a, void* stream) {
 
 static bool tn_uses_256(const wft_gemm_args* a) {
   const long nsteps = ((a->K + 63) / 64) * a->batch;
+  // (round 5: 25 output tiles — a decoder block's 1280 x 1280 gradients — take the 256 x 256 kernel from 8 192 reduction rows on:
+  // 59 -> 57 us at R = 8 704, 66 -> 56 us at R = 11 136, but 35 -> 53 us at R = 4 096; tools/dev/tn_small.py)
+  const long t256 = (a->M / 256) * (a->N / 256);
   return !g_force_128 && a->c_is_f32 && a->M % 256 == 0 && a->N % 256 == 0 && nsteps >= g_tn256_min_steps &&
-         (nsteps >= 256 || (a->M / 256) * (a->N / 256) >= g_tn256_min_out_tiles);
+         (nsteps >= 256 || t256 >= g_tn256_min_out_tiles || (t256 >= g_tn256_min_out_tiles / 2 && nsteps >= 128));
 }
 static int tn256_nsplit(const wft_gemm_args* a) {
   const long t256 = (a->M / 256) * (a->N / 256);

@@ -86,7 +86,7 @@
 .endm
 ; the 256 bias values of a tile's columns -> LDS (one 1 KiB piece, issued by wave 0 only; \go = 0: no bias / not wave 0)
 .macro NT4W_BIAS_DMA go, base, dst, voff
-  s_bitcmp0_b32 \go, 2
+  s_cmp_eq_u32 \go, 0
   s_cbranch_scc1 9f
   s_mov_b64 s[56:57], \base
   s_mov_b32 s58, 1024
@@ -98,12 +98,8 @@
 .endm
 ; one k-step.  z: first k-step of a tile (accumulators start from 0); ld: issue the loads of k-step t+2; nx: read k-step t+1's
 ; fragments (with vmA / vmB = vmcnt before its W / X reads); rdXc.. : address VGPRs of this / the other buffer; mX, mW: SGPRs with
-; this wave's LDS-DMA destination in this buffer; ax: epilogue-operand prefetch (the residual / aux rows of this lane, 16 groups
-; of 16 bytes each, descriptor s[56:59], running offset v63, row step s55): 1 = batch A, walking-order groups 0-11 -> v[64:111]
-; (issued in the second-to-last k-step), 2 = batch B, groups 16-31 -> v[128:191] (the last k-step: fragment set 0 is dead after
-; slot 63); 0 = none.  (Groups 12-15 are loaded behind the loop: a 16-group batch A leaves the compiler 47 registers across the
-; loop and the column-sum variant spills.)
-.macro NT4W_KSTEP z, ld, nx, vmA, vmB, rdXc, rdWc, rdXn, rdWn, mX, mW, ax=0
+; this wave's LDS-DMA destination in this buffer
+.macro NT4W_KSTEP z, ld, nx, vmA, vmB, rdXc, rdWc, rdXn, rdWn, mX, mW
   .set nt4w_s, 0
   .rept 128
     .if nt4w_s < 64
@@ -168,20 +164,6 @@
         ds_read_b128 v[160+4*((nt4w_s-NT4W_T4-2)/2):160+4*((nt4w_s-NT4W_T4-2)/2)+3], \rdXn offset:128*((nt4w_s-NT4W_T4-2)/2)
       .endif
     .endif
-    .if \ax
-      .if (nt4w_s >= 65) && (((nt4w_s-65) %% 4) == 0)
-        .if \ax == 1
-          .if nt4w_s < 65+48
-            buffer_load_dwordx4 v[64+(nt4w_s-65):64+(nt4w_s-65)+3], v63, s[56:59], 0 offen offset:64*(((nt4w_s-65)/4) %% 2)
-          .endif
-        .else
-          buffer_load_dwordx4 v[128+(nt4w_s-65):128+(nt4w_s-65)+3], v63, s[56:59], 0 offen offset:128+64*(((nt4w_s-65)/4) %% 2)
-        .endif
-      .endif
-      .if (nt4w_s >= 67) && (((nt4w_s-67) %% 8) == 4)
-        v_add_u32 v63, s55, v63
-      .endif
-    .endif
     .set nt4w_s, nt4w_s+1
   .endr
   s_waitcnt lgkmcnt(0)
@@ -209,67 +191,143 @@
   "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", NT4W_V8(12), NT4W_V8(13), NT4W_V8(14), NT4W_V8(15),         \
       NT4W_V8(16), NT4W_V8(17), NT4W_V8(18), NT4W_V8(19), NT4W_V8(20), NT4W_V8(21), NT4W_V8(22), NT4W_V8(23), NT4W_V8(24),    \
       "v250", "v251", "v252", "v253", "v254", "v255"
-#define NT4W_CLOBBER_S NT4W_S8(4), "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59"
+#define NT4W_CLOBBER_S NT4W_S8(4), "s50", "s51", "s52", "s53", "s56", "s57", "s58", "s59"
 
 // Everything the K loop of one tile needs.  Wave-uniform members are SGPR operands (the caller pins them with readfirstlane).
 struct Nt4wTile {
   unsigned long long baseX, baseW;  // first row of the tile's A rows / B rows, k = 0
   unsigned nrX, nrW;                // buffer bounds in bytes from the base: rows beyond M read as zero
 };
-// The epilogue operand of a tile (residual rows, or the aux rows of MUL_AUX) when it is prefetched inside the K loop
-struct Nt4wPf {
-  unsigned long long base;  // first row of the tile in the operand
-  unsigned nr;              // descriptor bound: valid rows * ld * 2
-  unsigned step;            // bytes between 16-row bands (32 * ld)
-  unsigned voff;            // this lane's byte offset of group 0 (per-lane: VGPR)
-};
 
-// flags: bit 0 = first tile of this workgroup, bit 1 = another tile follows, bit 2 = this wave issues the bias slice DMA.
-// The statement exists twice (gemm_nt4w_kloop.inc, included below): PF = 0 as in round 4; PF = 1 additionally issues the 32 epilogue-operand loads of
-// this lane in the last two k-steps (NT4W_KSTEP ax = 1 / 2) and clobbers their landing registers v[63:111] (v[128:191] are
-// fragment registers anyway).
-// (descriptor and running offset of the operand prefetch; re-armed in front of each of the two k-steps that issue a batch)
-#define NT4W_PF_SETUP R"ASM(
-    s_mov_b64 s[56:57], %[pfb]
-    s_mov_b32 s58, %[pfn]
-    s_mov_b32 s59, 0x20000
-    s_mov_b32 s55, %[pfs]
-    v_mov_b32 v63, %[pfv]
-)ASM"
-#define NT4W_CLOBBER_PF                                                                                                          \
-  "v63", "v64", "v65", "v66", "v67", "v68", "v69", NT4W_V8(7), NT4W_V8(8), NT4W_V8(9), NT4W_V8(10), "v110", "v111"
-
-template <bool PF>
+template <bool DUMMY = false>
 __device__ __forceinline__ void nt4w_kloop(unsigned rdX0, unsigned rdX1, unsigned rdW0, unsigned rdW1, unsigned voX, unsigned voW,
                                            const Nt4wTile& cur, const Nt4wTile& nxt, unsigned lda2, unsigned ldb2, unsigned mdst,
-                                           unsigned nblk, unsigned flags, unsigned nops, unsigned lane16,
-                                           unsigned long long cbias, unsigned long long nbias, unsigned cbdst, unsigned nbdst,
-                                           const Nt4wPf& pf) {
-  if constexpr (PF) {
-#define NT4W_AXA 1
-#define NT4W_AXB 2
-#define NT4W_PFSETUP NT4W_PF_SETUP
-#define NT4W_PF_OPERANDS , [pfb] "s"(pf.base), [pfn] "s"(pf.nr), [pfs] "s"(pf.step), [pfv] "v"(pf.voff)
-#define NT4W_EXTRA_CLOBBERS , NT4W_CLOBBER_PF
-#include "gemm_nt4w_kloop.inc"
-#undef NT4W_AXA
-#undef NT4W_AXB
-#undef NT4W_PFSETUP
-#undef NT4W_PF_OPERANDS
-#undef NT4W_EXTRA_CLOBBERS
-  } else {
-#define NT4W_AXA 0
-#define NT4W_AXB 0
-#define NT4W_PFSETUP ""
-#define NT4W_PF_OPERANDS
-#define NT4W_EXTRA_CLOBBERS
-#include "gemm_nt4w_kloop.inc"
-#undef NT4W_AXA
-#undef NT4W_AXB
-#undef NT4W_PFSETUP
-#undef NT4W_PF_OPERANDS
-#undef NT4W_EXTRA_CLOBBERS
-  }
+                                           unsigned nblk, unsigned first, unsigned more, unsigned nops, unsigned lane16, unsigned bgo,
+                                           unsigned long long cbias, unsigned long long nbias, unsigned cbdst, unsigned nbdst) {
+  asm volatile(NT4W_ASM_MACROS R"ASM(
+    ; ---- per-lane source offsets of this wave's 8 X blocks and 8 W blocks (row step of block j: j rows of A; {0,1,2,3,8,9,10,11} rows of B)
+    v_mov_b32 v112, %[voX]
+    v_add_u32 v113, %[lda2], v112
+    v_add_u32 v114, %[lda2], v113
+    v_add_u32 v115, %[lda2], v114
+    v_add_u32 v116, %[lda2], v115
+    v_add_u32 v117, %[lda2], v116
+    v_add_u32 v118, %[lda2], v117
+    v_add_u32 v119, %[lda2], v118
+    s_lshl_b32 s49, %[ldb2], 3
+    v_mov_b32 v120, %[voW]
+    v_add_u32 v121, %[ldb2], v120
+    v_add_u32 v122, %[ldb2], v121
+    v_add_u32 v123, %[ldb2], v122
+    v_add_u32 v124, s49, v120
+    v_add_u32 v125, s49, v121
+    v_add_u32 v126, s49, v122
+    v_add_u32 v127, s49, v123
+    ; ---- LDS-DMA destinations of this wave: X / W part of buffer 0 / 1
+    s_mov_b32 s50, %[mdst]
+    s_add_u32 s51, s50, )ASM" NT4W_STR(NT4W_BUF) R"ASM(
+    s_add_u32 s52, s50, )ASM" NT4W_STR(NT4W_OP) R"ASM(
+    s_add_u32 s53, s51, )ASM" NT4W_STR(NT4W_OP) R"ASM(
+    ; ---- buffer descriptors of the current tile
+    s_mov_b64 s[40:41], %[cbX]
+    s_mov_b32 s42, %[cnX]
+    s_mov_b32 s43, 0x20000
+    s_mov_b64 s[44:45], %[cbW]
+    s_mov_b32 s46, %[cnW]
+    s_mov_b32 s47, 0x20000
+    s_mov_b32 s48, %[nblk]
+    s_cmp_eq_u32 %[first], 0
+    s_cbranch_scc1 1f
+    ; first tile of this workgroup: nobody staged its bias slice and its k-steps 0 and 1
+    NT4W_BIAS_DMA %[bgo], %[cbias], %[cbdst], %[lane16]
+    .irp j,0,1,2,3,4,5,6,7
+      NT4W_DMA \j, 120, 44, s52
+    .endr
+    .irp j,0,1,2,3,4,5,6,7
+      NT4W_DMA \j, 112, 40, s50
+    .endr
+    s_add_u32 s40, s40, 128
+    s_addc_u32 s41, s41, 0
+    s_add_u32 s44, s44, 128
+    s_addc_u32 s45, s45, 0
+    .irp j,0,1,2,3,4,5,6,7
+      NT4W_DMA \j, 120, 44, s53
+    .endr
+    .irp j,0,1,2,3,4,5,6,7
+      NT4W_DMA \j, 112, 40, s51
+    .endr
+    s_add_u32 s40, s40, 128
+    s_addc_u32 s41, s41, 0
+    s_add_u32 s44, s44, 128
+    s_addc_u32 s45, s45, 0
+    s_waitcnt vmcnt(16)   ; k-step 0 complete, k-step 1's 16 pieces are the youngest operations
+    s_branch 7f
+1:
+    ; k-steps 0 and 1 were staged by the previous tile's last two k-steps
+    s_add_u32 s40, s40, 256
+    s_addc_u32 s41, s41, 0
+    s_add_u32 s44, s44, 256
+    s_addc_u32 s45, s45, 0
+2:
+    ; k-step 0 complete.  vmcnt retires in issue order: younger than k-step 0's pieces are k-step 1's 16 pieces and the
+    ; %[nops] vector-memory operations the previous tile's epilogue issued behind them (a LOWER bound is safe)
+    s_cmp_ge_u32 %[nops], 47
+    s_cbranch_scc1 5f
+    s_cmp_ge_u32 %[nops], 32
+    s_cbranch_scc1 6f
+    s_waitcnt vmcnt(16)
+    s_branch 7f
+5:
+    s_waitcnt vmcnt(63)
+    s_branch 7f
+6:
+    s_waitcnt vmcnt(48)
+7:
+    s_barrier
+    .irp f,0,1,2,3,4,5,6,7
+      ds_read_b128 v[128+4*\f:128+4*\f+3], %[rdW0] offset:128*\f
+    .endr
+    .irp f,0,1,2,3,4,5,6,7
+      ds_read_b128 v[160+4*\f:160+4*\f+3], %[rdX0] offset:128*\f
+    .endr
+    s_waitcnt lgkmcnt(0)
+    ; ---- k-steps 0, 1 (accumulators start from zero in k-step 0)
+    NT4W_KSTEP 1, 1, 1, 24, 16, %[rdX0], %[rdW0], %[rdX1], %[rdW1], s50, s52
+    NT4W_KSTEP 0, 1, 1, 24, 16, %[rdX1], %[rdW1], %[rdX0], %[rdW0], s51, s53
+    s_cmp_eq_u32 s48, 0
+    s_cbranch_scc1 4f
+3:
+    NT4W_KSTEP 0, 1, 1, 24, 16, %[rdX0], %[rdW0], %[rdX1], %[rdW1], s50, s52
+    NT4W_KSTEP 0, 1, 1, 24, 16, %[rdX1], %[rdW1], %[rdX0], %[rdW0], s51, s53
+    s_sub_u32 s48, s48, 1
+    s_cmp_eq_u32 s48, 0
+    s_cbranch_scc0 3b
+4:
+    s_cmp_eq_u32 %[more], 0
+    s_cbranch_scc1 8f
+    ; ---- last two k-steps: their loads are the NEXT tile's k-steps 0 and 1
+    s_mov_b64 s[40:41], %[nbX]
+    s_mov_b32 s42, %[nnX]
+    s_mov_b64 s[44:45], %[nbW]
+    s_mov_b32 s46, %[nnW]
+    NT4W_KSTEP 0, 1, 1, 24, 16, %[rdX0], %[rdW0], %[rdX1], %[rdW1], s50, s52
+    NT4W_KSTEP 0, 1, 0, 0, 0, %[rdX1], %[rdW1], %[rdX0], %[rdW0], s51, s53
+    NT4W_BIAS_DMA %[bgo], %[nbias], %[nbdst], %[lane16]
+    s_branch 10f
+8:
+    ; ---- last tile of this workgroup: nothing to load; k-step nk-1's 16 pieces are the youngest operations (exact waits 8 / 0)
+    NT4W_KSTEP 0, 0, 1, 8, 0, %[rdX0], %[rdW0], %[rdX1], %[rdW1], s50, s52
+    NT4W_KSTEP 0, 0, 0, 0, 0, %[rdX1], %[rdW1], %[rdX0], %[rdW0], s51, s53
+10:
+    s_nop 15
+  )ASM" NT4W_ASM_PURGE
+               :
+               : [rdX0] "v"(rdX0), [rdX1] "v"(rdX1), [rdW0] "v"(rdW0), [rdW1] "v"(rdW1), [voX] "v"(voX), [voW] "v"(voW),
+                 [cbX] "s"(cur.baseX), [cbW] "s"(cur.baseW), [cnX] "s"(cur.nrX), [cnW] "s"(cur.nrW), [nbX] "s"(nxt.baseX),
+                 [nbW] "s"(nxt.baseW), [nnX] "s"(nxt.nrX), [nnW] "s"(nxt.nrW), [lda2] "s"(lda2), [ldb2] "s"(ldb2),
+                 [mdst] "s"(mdst), [nblk] "s"(nblk), [first] "s"(first), [more] "s"(more), [nops] "s"(nops), [lane16] "v"(lane16), [bgo] "s"(bgo), [cbias] "s"(cbias), [nbias] "s"(nbias),
+                 [cbdst] "s"(cbdst), [nbdst] "s"(nbdst)
+               : "memory", "vcc", "scc", NT4W_CLOBBER_A, NT4W_CLOBBER_V, NT4W_CLOBBER_S);
 }
 
 template <int N>
@@ -336,7 +394,6 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmP p) {
   unsigned first = 1;
   constexpr bool RD_AUX = (EPI == WFT_EPI_MUL_AUX), WR_AUX = (EPI == WFT_EPI_GELU_GRAD);
   constexpr bool has_res = RES;  // (a residual operand; MUL_AUX reads aux instead)
-  constexpr bool PF = RD_AUX || has_res;  // epilogue operand prefetched inside the K loop
   // vector-memory operations every wave issues per tile AFTER the K loop (a lower bound: the column-sum stores are not counted):
   // 32 stores of C, 32 of aux (GELU_GRAD), 32 loads of aux (MUL_AUX), 32 loads of the residual.  They are buffer operations
   // bounded by the tile's valid rows: no row masks, no branches, so the count holds on ragged tiles too.
@@ -379,172 +436,7 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmP p) {
     const int r0 = (wave & 1) * 8;
     const unsigned voX = (unsigned)(((wm * 128 + 16 * ldf + r0) * (int)p.lda + ldc8 * 8) * 2);
     const unsigned voW = (unsigned)(((wm * 128 + 32 * (ldf >> 1) + 4 * (ldf & 1) + 8 * (r0 >> 2)) * (int)p.ldb + ldc8 * 8) * 2);
-    // epilogue operand (residual rows / MUL_AUX's aux rows) of THIS tile, prefetched by the K loop's last two k-steps: descriptor that
-    // ends at the tile's last valid row, this lane's offset of walking-order group 0
-    Nt4wPf pf{0, 0, 0, 0};
-    if constexpr (PF) {
-      const int rows_p = p.M - m0 < 256 ? p.M - m0 : 256;
-      const unsigned short* const ob_p = RD_AUX ? p.aux + (long)bz * p.sAux + (long)m0 * p.ldaux : p.res + (long)bz * p.sR + (long)m0 * p.ldr;
-      const unsigned ldo_p = (unsigned)(RD_AUX ? p.ldaux : p.ldr);
-      pf.base = nt4w_sgpr64((unsigned long long)ob_p);
-      pf.nr = (unsigned)rows_p * ldo_p * 2u;  // (uniform by construction: kernel arguments and the tile index)
-      pf.step = 32u * ldo_p;
-      pf.voff = ((unsigned)(wm * 128 + (lane_o & 15)) * ldo_p + (unsigned)(n0 + wn * 128 + 8 * (lane_o >> 4))) * 2u;
-    }
-    const unsigned flags = nt4w_sgpr(first | (t + (int)gridDim.x < total ? 2u : 0u) | (bgo ? 4u : 0u));
-    nt4w_kloop<PF>(rdX0, rdX1, rdW0, rdW1, voX, voW, cur, nxt, lda2, ldb2, mdst, nblk, flags, nops, lane_o * 16, cbias, nbias, cbdst, nbdst, pf);
-    u32x4 opq[PF ? 32 : 16];
-    if constexpr (PF) {
-      // 28 of the 32 operand groups of this lane were loaded by the K loop's last two k-steps: walking-order groups 0-11 into
-      // v[64:111], 16-31 into v[128:191].  They become compiler-visible values HERE: register-bound outputs of statements that first
-      // wait for the loads (vmcnt retires in order: the next tile's LDS-DMA pieces were issued before them, only wave 0's bias piece
-      // after).  Nothing may sit between the K loop and these statements that writes those registers (tools/dev/nt4w_pf_check.sh
-      // greps that window of the ISA).  Groups 12-15 (consumed after twelve groups' worth of epilogue work) are loaded below.
-      register unsigned pfr64 asm("v64");
-      register unsigned pfr65 asm("v65");
-      register unsigned pfr66 asm("v66");
-      register unsigned pfr67 asm("v67");
-      register unsigned pfr68 asm("v68");
-      register unsigned pfr69 asm("v69");
-      register unsigned pfr70 asm("v70");
-      register unsigned pfr71 asm("v71");
-      register unsigned pfr72 asm("v72");
-      register unsigned pfr73 asm("v73");
-      register unsigned pfr74 asm("v74");
-      register unsigned pfr75 asm("v75");
-      register unsigned pfr76 asm("v76");
-      register unsigned pfr77 asm("v77");
-      register unsigned pfr78 asm("v78");
-      register unsigned pfr79 asm("v79");
-      register unsigned pfr80 asm("v80");
-      register unsigned pfr81 asm("v81");
-      register unsigned pfr82 asm("v82");
-      register unsigned pfr83 asm("v83");
-      register unsigned pfr84 asm("v84");
-      register unsigned pfr85 asm("v85");
-      register unsigned pfr86 asm("v86");
-      register unsigned pfr87 asm("v87");
-      register unsigned pfr88 asm("v88");
-      register unsigned pfr89 asm("v89");
-      register unsigned pfr90 asm("v90");
-      register unsigned pfr91 asm("v91");
-      register unsigned pfr92 asm("v92");
-      register unsigned pfr93 asm("v93");
-      register unsigned pfr94 asm("v94");
-      register unsigned pfr95 asm("v95");
-      register unsigned pfr96 asm("v96");
-      register unsigned pfr97 asm("v97");
-      register unsigned pfr98 asm("v98");
-      register unsigned pfr99 asm("v99");
-      register unsigned pfr100 asm("v100");
-      register unsigned pfr101 asm("v101");
-      register unsigned pfr102 asm("v102");
-      register unsigned pfr103 asm("v103");
-      register unsigned pfr104 asm("v104");
-      register unsigned pfr105 asm("v105");
-      register unsigned pfr106 asm("v106");
-      register unsigned pfr107 asm("v107");
-      register unsigned pfr108 asm("v108");
-      register unsigned pfr109 asm("v109");
-      register unsigned pfr110 asm("v110");
-      register unsigned pfr111 asm("v111");
-      register unsigned pfr128 asm("v128");
-      register unsigned pfr129 asm("v129");
-      register unsigned pfr130 asm("v130");
-      register unsigned pfr131 asm("v131");
-      register unsigned pfr132 asm("v132");
-      register unsigned pfr133 asm("v133");
-      register unsigned pfr134 asm("v134");
-      register unsigned pfr135 asm("v135");
-      register unsigned pfr136 asm("v136");
-      register unsigned pfr137 asm("v137");
-      register unsigned pfr138 asm("v138");
-      register unsigned pfr139 asm("v139");
-      register unsigned pfr140 asm("v140");
-      register unsigned pfr141 asm("v141");
-      register unsigned pfr142 asm("v142");
-      register unsigned pfr143 asm("v143");
-      register unsigned pfr144 asm("v144");
-      register unsigned pfr145 asm("v145");
-      register unsigned pfr146 asm("v146");
-      register unsigned pfr147 asm("v147");
-      register unsigned pfr148 asm("v148");
-      register unsigned pfr149 asm("v149");
-      register unsigned pfr150 asm("v150");
-      register unsigned pfr151 asm("v151");
-      register unsigned pfr152 asm("v152");
-      register unsigned pfr153 asm("v153");
-      register unsigned pfr154 asm("v154");
-      register unsigned pfr155 asm("v155");
-      register unsigned pfr156 asm("v156");
-      register unsigned pfr157 asm("v157");
-      register unsigned pfr158 asm("v158");
-      register unsigned pfr159 asm("v159");
-      register unsigned pfr160 asm("v160");
-      register unsigned pfr161 asm("v161");
-      register unsigned pfr162 asm("v162");
-      register unsigned pfr163 asm("v163");
-      register unsigned pfr164 asm("v164");
-      register unsigned pfr165 asm("v165");
-      register unsigned pfr166 asm("v166");
-      register unsigned pfr167 asm("v167");
-      register unsigned pfr168 asm("v168");
-      register unsigned pfr169 asm("v169");
-      register unsigned pfr170 asm("v170");
-      register unsigned pfr171 asm("v171");
-      register unsigned pfr172 asm("v172");
-      register unsigned pfr173 asm("v173");
-      register unsigned pfr174 asm("v174");
-      register unsigned pfr175 asm("v175");
-      register unsigned pfr176 asm("v176");
-      register unsigned pfr177 asm("v177");
-      register unsigned pfr178 asm("v178");
-      register unsigned pfr179 asm("v179");
-      register unsigned pfr180 asm("v180");
-      register unsigned pfr181 asm("v181");
-      register unsigned pfr182 asm("v182");
-      register unsigned pfr183 asm("v183");
-      register unsigned pfr184 asm("v184");
-      register unsigned pfr185 asm("v185");
-      register unsigned pfr186 asm("v186");
-      register unsigned pfr187 asm("v187");
-      register unsigned pfr188 asm("v188");
-      register unsigned pfr189 asm("v189");
-      register unsigned pfr190 asm("v190");
-      register unsigned pfr191 asm("v191");
-      asm volatile("s_waitcnt vmcnt(0)" : "=v"(pfr64), "=v"(pfr65), "=v"(pfr66), "=v"(pfr67), "=v"(pfr68), "=v"(pfr69), "=v"(pfr70), "=v"(pfr71), "=v"(pfr72), "=v"(pfr73), "=v"(pfr74), "=v"(pfr75), "=v"(pfr76), "=v"(pfr77), "=v"(pfr78), "=v"(pfr79), "=v"(pfr80), "=v"(pfr81), "=v"(pfr82), "=v"(pfr83), "=v"(pfr84), "=v"(pfr85), "=v"(pfr86), "=v"(pfr87), "=v"(pfr88), "=v"(pfr89), "=v"(pfr90), "=v"(pfr91), "=v"(pfr92), "=v"(pfr93));
-      asm volatile("s_waitcnt vmcnt(0)" : "=v"(pfr94), "=v"(pfr95), "=v"(pfr96), "=v"(pfr97), "=v"(pfr98), "=v"(pfr99), "=v"(pfr100), "=v"(pfr101), "=v"(pfr102), "=v"(pfr103), "=v"(pfr104), "=v"(pfr105), "=v"(pfr106), "=v"(pfr107), "=v"(pfr108), "=v"(pfr109), "=v"(pfr110), "=v"(pfr111), "=v"(pfr128), "=v"(pfr129), "=v"(pfr130), "=v"(pfr131), "=v"(pfr132), "=v"(pfr133), "=v"(pfr134), "=v"(pfr135), "=v"(pfr136), "=v"(pfr137), "=v"(pfr138), "=v"(pfr139));
-      asm volatile("s_waitcnt vmcnt(0)" : "=v"(pfr140), "=v"(pfr141), "=v"(pfr142), "=v"(pfr143), "=v"(pfr144), "=v"(pfr145), "=v"(pfr146), "=v"(pfr147), "=v"(pfr148), "=v"(pfr149), "=v"(pfr150), "=v"(pfr151), "=v"(pfr152), "=v"(pfr153), "=v"(pfr154), "=v"(pfr155), "=v"(pfr156), "=v"(pfr157), "=v"(pfr158), "=v"(pfr159), "=v"(pfr160), "=v"(pfr161), "=v"(pfr162), "=v"(pfr163), "=v"(pfr164), "=v"(pfr165), "=v"(pfr166), "=v"(pfr167), "=v"(pfr168), "=v"(pfr169));
-      asm volatile("s_waitcnt vmcnt(0)" : "=v"(pfr170), "=v"(pfr171), "=v"(pfr172), "=v"(pfr173), "=v"(pfr174), "=v"(pfr175), "=v"(pfr176), "=v"(pfr177), "=v"(pfr178), "=v"(pfr179), "=v"(pfr180), "=v"(pfr181), "=v"(pfr182), "=v"(pfr183), "=v"(pfr184), "=v"(pfr185), "=v"(pfr186), "=v"(pfr187), "=v"(pfr188), "=v"(pfr189), "=v"(pfr190), "=v"(pfr191));
-      opq[0] = u32x4{pfr64, pfr65, pfr66, pfr67};
-      opq[1] = u32x4{pfr68, pfr69, pfr70, pfr71};
-      opq[2] = u32x4{pfr72, pfr73, pfr74, pfr75};
-      opq[3] = u32x4{pfr76, pfr77, pfr78, pfr79};
-      opq[4] = u32x4{pfr80, pfr81, pfr82, pfr83};
-      opq[5] = u32x4{pfr84, pfr85, pfr86, pfr87};
-      opq[6] = u32x4{pfr88, pfr89, pfr90, pfr91};
-      opq[7] = u32x4{pfr92, pfr93, pfr94, pfr95};
-      opq[8] = u32x4{pfr96, pfr97, pfr98, pfr99};
-      opq[9] = u32x4{pfr100, pfr101, pfr102, pfr103};
-      opq[10] = u32x4{pfr104, pfr105, pfr106, pfr107};
-      opq[11] = u32x4{pfr108, pfr109, pfr110, pfr111};
-      opq[16] = u32x4{pfr128, pfr129, pfr130, pfr131};
-      opq[17] = u32x4{pfr132, pfr133, pfr134, pfr135};
-      opq[18] = u32x4{pfr136, pfr137, pfr138, pfr139};
-      opq[19] = u32x4{pfr140, pfr141, pfr142, pfr143};
-      opq[20] = u32x4{pfr144, pfr145, pfr146, pfr147};
-      opq[21] = u32x4{pfr148, pfr149, pfr150, pfr151};
-      opq[22] = u32x4{pfr152, pfr153, pfr154, pfr155};
-      opq[23] = u32x4{pfr156, pfr157, pfr158, pfr159};
-      opq[24] = u32x4{pfr160, pfr161, pfr162, pfr163};
-      opq[25] = u32x4{pfr164, pfr165, pfr166, pfr167};
-      opq[26] = u32x4{pfr168, pfr169, pfr170, pfr171};
-      opq[27] = u32x4{pfr172, pfr173, pfr174, pfr175};
-      opq[28] = u32x4{pfr176, pfr177, pfr178, pfr179};
-      opq[29] = u32x4{pfr180, pfr181, pfr182, pfr183};
-      opq[30] = u32x4{pfr184, pfr185, pfr186, pfr187};
-      opq[31] = u32x4{pfr188, pfr189, pfr190, pfr191};
-    }
+    nt4w_kloop(rdX0, rdX1, rdW0, rdW1, voX, voW, cur, nxt, lda2, ldb2, mdst, nblk, first, nt4w_sgpr(t + (int)gridDim.x < total ? 1u : 0u), nops, lane_o * 16, nt4w_sgpr(bgo), cbias, nbias, cbdst, nbdst);
     first = 0;
     cur = nxt;
 
@@ -580,17 +472,18 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmP p) {
     const unsigned offC = (row_l * (unsigned)p.ldc + (unsigned)ncol) * 2u, stepC = 32u * (unsigned)p.ldc;
     // The 32 groups (fx, u) of a lane are walked in column-chunk PAIRS: order o = 16 up + 2 fx + (u & 1), u = 2 up + (u & 1): both
     // chunks of a row band are converted, then stored together as whole 128-byte lines (store_pair below).
-    // Residual / aux rows of this lane: 28 groups arrive from the K loop's prefetch (opq above), groups 12-15 are fetched here
-    if constexpr (PF) {
-      const unsigned short* const ob = RD_AUX ? p.aux + (long)bz * p.sAux + (long)m0 * p.ldaux : p.res + (long)bz * p.sR + (long)m0 * p.ldr;
-      const long ldo = RD_AUX ? p.ldaux : p.ldr;
-      const auto srdO = srd_of(ob, ldo);
-      const unsigned offO = (row_l * (unsigned)ldo + (unsigned)ncol) * 2u, stepO = 32u * (unsigned)ldo;
-      nt4w_for<12, 16>([&](auto oc) {  // group number oc in walking order: fx = (o >> 1) & 7, u = 2 (o >> 4) + (o & 1)
-        constexpr int o = decltype(oc)::value, fx = (o >> 1) & 7, u = 2 * (o >> 4) + (o & 1);
-        opq[o] = __builtin_amdgcn_raw_buffer_load_b128(srdO, offO + fx * stepO + 64u * u, 0, 0);
-      });
-    }
+    // Residual / aux rows of this lane: a ring of 16 groups (64 registers; all 32 would leave the lane constants no room beside
+    // them): the first 16 in walking order are fetched up front, group o + 16 as soon as o has been consumed.
+    u32x4 opq[16];
+    const unsigned short* const ob = RD_AUX ? p.aux + (long)bz * p.sAux + (long)m0 * p.ldaux : p.res + (long)bz * p.sR + (long)m0 * p.ldr;
+    const long ldo = RD_AUX ? p.ldaux : p.ldr;
+    const auto srdO = srd_of((RD_AUX || has_res) ? (const void*)ob : (const void*)p.C, (RD_AUX || has_res) ? ldo : 0);
+    const unsigned offO = (row_l * (unsigned)ldo + (unsigned)ncol) * 2u, stepO = 32u * (unsigned)ldo;
+    auto load_o = [&](auto oc) {  // group number oc in walking order
+      constexpr int o = decltype(oc)::value, fx = (o >> 1) & 7, u = 2 * (o >> 4) + (o & 1);
+      opq[o & 15] = __builtin_amdgcn_raw_buffer_load_b128(srdO, offO + fx * stepO + 64u * u, 0, 0);
+    };
+    if constexpr (RD_AUX || has_res) nt4w_for<0, 16>(load_o);
     const auto srdA = srd_of(WR_AUX ? p.aux + (long)bz * p.sAux + (long)m0 * p.ldaux : (const unsigned short*)p.C, (WR_AUX && p.diag != 23 && p.diag != 24) ? p.ldaux : 0);  // (DIAG 23: C and aux stores dropped, 24: aux only — timing)
     const unsigned stepA = 32u * (unsigned)p.ldaux;  // (wave-uniform by construction: no readfirstlane — it would cost a vector register across the K loop)
     // Whole-line stores.  As they leave the MFMA a lane (q, mr) holds 16 bytes of row mr in each column chunk, so one store
@@ -634,7 +527,7 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmP p) {
             for (int e = 0; e < 8; ++e) gelu_both_f(v[e], v[e], dv[e]);
             dpk[hh] = u32x4{pack2bf(dv[0], dv[1]), pack2bf(dv[2], dv[3]), pack2bf(dv[4], dv[5]), pack2bf(dv[6], dv[7])};
           } else if constexpr (EPI == WFT_EPI_MUL_AUX) {
-            const u32x4 a4 = opq[o];
+            const u32x4 a4 = opq[o & 15];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               v[2 * e] *= __builtin_bit_cast(float, a4[e] << 16);
@@ -642,13 +535,14 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmP p) {
             }
           }
           if constexpr (!RD_AUX && has_res) {
-            const u32x4 r4 = opq[o];
+            const u32x4 r4 = opq[o & 15];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               v[2 * e] += p.beta * __builtin_bit_cast(float, r4[e] << 16);
               v[2 * e + 1] += p.beta * __builtin_bit_cast(float, r4[e] & 0xffff0000u);
             }
           }
+          if constexpr ((RD_AUX || has_res) && o < 16) load_o(std::integral_constant<int, o + 16>{});
           pk[hh] = u32x4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
           if constexpr (CS) {
             // rows >= M add exact zeros: CS is only instantiated with MUL_AUX (no bias), their accumulators are products of the
