@@ -78,7 +78,7 @@ def lora_flops_per_clip(d, S: int, r: int) -> float:
 
 def pmc_traffic_per_launch(batch: int, lora: bool = False, kname: str = "gemm_nt256_kernel"):
     """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes of THIS command
-    (profiles/collect_r04.sh: --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, the only tracing next to them
+    (profiles/collect_r05.sh: --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, the only tracing next to them
     being --kernel-trace).  FETCH_SIZE is in KiB and counts 64 B per 128-B request on gfx950 for 16-B/lane streaming
     reads, so it is doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE (KiB) is exact.  Counters cannot be
     collected inside the timed run, so the value is only reported when the committed pass used the same batch."""
@@ -430,6 +430,16 @@ def ddp_mode_1gpu(case, B, S, plain_ms):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29534")
         dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    # a DDP job from its first step: no gradient homes left over from the plain run (they would keep the plain run's gradient
+    # tensors alive beside the buckets), peak-memory statistics from here on
+    for prm in case.model.parameters():
+        prm.__dict__.pop("_wft_grad_home", None)
+        prm.grad = None
+    case.opt.__dict__["_wft_steps"] = 0
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
     scratch = torch.empty(2, 256 << 20, dtype=torch.uint8, device=dev)
     side = torch.cuda.Stream(device=dev)
     moved = [0]
@@ -460,20 +470,23 @@ def ddp_mode_1gpu(case, B, S, plain_ms):
             case.ddp = True
             if thief:
                 case.net.register_comm_hook(None, thief_hook)
-            for mode, flag in (("per_tile", 0), ("persistent", 1)):
+            for mode, flag in (("persistent", 1), ("per_tile", 0)):
                 lib.wft_gemm_set_persistent(flag)
                 lib.wft_attn_set_persistent(flag)
                 moved[0] = 0
-                r = case.measure(B, S, 3, 1, roofline=False, ddp_twin=(not thief and mode == "per_tile"))
+                r = case.measure(B, S, 3, 2 if (not thief and mode == "persistent") else 1, roofline=False,
+                                 ddp_twin=(not thief and mode == "persistent"))
                 key = f"ddp_{mode}" + ("_thief" if thief else "")
                 out[key + "_ms_per_step"] = r["ms_per_step"]
                 if thief:
                     out["thief_gb_per_step"] = round(moved[0] / 4 / 1e9, 2)  # (3 timed + 1 warm-up step)
+                if not thief and mode == "persistent":  # (two warm-up steps: DDP rebuilt its buckets, the optimizer noted the new views)
+                    out["hbm_peak_gib_under_ddp"] = round(torch.cuda.max_memory_allocated() / 2**30, 1)
                 if "ddp" in r:
                     out["exposed_exchange_ms_1rank"] = r["ddp"]["exposed_exchange_ms"]
             case.net = None
-        out["hbm_peak_gib_under_ddp"] = round(torch.cuda.max_memory_allocated() / 2**30, 1)
-        out["ddp_mode_overhead_pct"] = round((out["ddp_per_tile_ms_per_step"] / plain_ms - 1.0) * 100.0, 2)
+        out["ddp_persistent_overhead_pct"] = round((out["ddp_persistent_ms_per_step"] / plain_ms - 1.0) * 100.0, 2)  # the default launch mode
+        out["ddp_per_tile_overhead_pct"] = round((out["ddp_per_tile_ms_per_step"] / plain_ms - 1.0) * 100.0, 2)
         out["per_tile_vs_persistent_under_thief_pct"] = round((out["ddp_per_tile_thief_ms_per_step"] / out["ddp_persistent_thief_ms_per_step"] - 1.0) * 100.0, 2)
     finally:
         lib.wft_gemm_set_persistent(old[0])

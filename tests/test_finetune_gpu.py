@@ -39,7 +39,7 @@ def test_gpu_data_path_yields_reference_batch_layout():
     assert (mel == 0).any()        # SpecAugment masks are zero-valued
 
 
-@pytest.mark.parametrize("variant", ["lora_muon_sd_recompute", "decoder_only_lora"])
+@pytest.mark.parametrize("variant", ["lora_muon_sd_recompute", "decoder_only_lora", "lora_adamw_8bit"])
 def test_finetune_entrypoint_lora_variants(tmp_path, variant):
     """The entrypoint with the reference's other switches on the synthetic provider: LoRA (dropout 0.1) + Muon/AuxAdam +
     gradient-checkpointing flags (-> the CheckpointedStochastic classes, stochastic depth 0.1) + block recompute + deep
@@ -59,6 +59,10 @@ def test_finetune_entrypoint_lora_variants(tmp_path, variant):
                             "muon_params": {"lr": 2e-4, "momentum": 0.95, "weight_decay": 0.01},
                             "params": {"lr": 2e-4, "weight_decay": 0.01, "betas": [0.9, 0.98], "eps": 1e-6, "amsgrad": False}}
         cfg["lr_scheduler"] = {"type": "cosine_with_warmup_restarts", "warmup_steps": 1, "lr_num_cycles": 2, "lr_gamma": 0.8}
+    elif variant == "lora_adamw_8bit":
+        # the optimizer block of configs/config_turbo_best.yaml:62-72 (`8bit: True`): bnb.optim.AdamW8bit in the reference,
+        # WftAdamW8bit here — block-wise 8-bit moments for the adapter matrices of >= 4 096 elements, fp32 for the small ones
+        cfg["optimizer"] = {"type": "adamw", "8bit": True, "params": {"lr": 2e-4, "weight_decay": 0.1, "betas": [0.9, 0.98], "eps": 1e-6, "amsgrad": False}}
     else:
         t["train_only_decoder"] = True
     losses = finetune.main(cfg)
