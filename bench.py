@@ -480,8 +480,14 @@ def ddp_mode_1gpu(case, B, S, plain_ms):
                 out[key + "_ms_per_step"] = r["ms_per_step"]
                 if thief:
                     out["thief_gb_per_step"] = round(moved[0] / 4 / 1e9, 2)  # (3 timed + 1 warm-up step)
-                if not thief and mode == "persistent":  # (two warm-up steps: DDP rebuilt its buckets, the optimizer noted the new views)
+                if not thief and mode == "persistent":
+                    # peak over a DDP job's first steps (torch DDP allocates its rebuilt buckets beside the first iteration's at the
+                    # start of its second iteration: +6 GB of its own) ...
                     out["hbm_peak_gib_under_ddp"] = round(torch.cuda.max_memory_allocated() / 2**30, 1)
+                    torch.cuda.reset_peak_memory_stats()
+                if not thief and mode == "per_tile":
+                    # ... and in the steady state behind it (buckets rebuilt, gradient homes = the bucket views)
+                    out["hbm_peak_gib_under_ddp_steady_state"] = round(torch.cuda.max_memory_allocated() / 2**30, 1)
                 if "ddp" in r:
                     out["exposed_exchange_ms_1rank"] = r["ddp"]["exposed_exchange_ms"]
             case.net = None
