@@ -23,7 +23,8 @@ and, on the default (headline) invocation, extra keys measured in the same proce
   "reference_yaml_shapes":   the reference YAML's batch 32 at S = 128 and at the S = 448 stress length,
   "configs2_lora_muon":      BASELINE configs[2] (LoRA r16 + Muon + stochastic depth + deep SpecAugment, B = 32) with
                              its own roofline object,
-  "configs1_base":           BASELINE configs[1] (whisper-base full fine-tune, B = 8, S = 128),
+  "configs1_base":           BASELINE configs[1] (whisper-base full fine-tune, B = 8, S = 128) with training.wft_hip_graph (the micro-batch
+                             as one captured HIP graph); the eager step time is in the same object,
   "configs4_turbo_lora":     BASELINE configs[4]'s per-GPU workload (large-v3-turbo, LoRA r16, 64-token prompt with -100 targets +
                              timestamp tokens every 16th position, B = 64 — SURVEY.md §8d config 5),
   "entrypoint_loop":         scripts/finetune.py's real loop (SyntheticDataset -> DataLoader workers -> GpuMelLoader ->
@@ -366,7 +367,10 @@ class Case:
             # gradient all-reduce is a collective); only rank 0 records.
             if rank == 0:
                 K.PROFILE_NT = []
+            graph_mode = self.t_cfg.get("wft_hip_graph", False)
+            self.t_cfg["wft_hip_graph"] = False  # (the HIP events are recorded by Python around each launch: an eager step)
             step()
+            self.t_cfg["wft_hip_graph"] = graph_mode
             torch.cuda.synchronize()
             if rank == 0:
                 recs, K.PROFILE_NT = K.PROFILE_NT, None
@@ -516,6 +520,7 @@ def main():
     ap.add_argument("--muon", action="store_true", help="Muon + auxiliary Adam param groups (config_large_v3_best_muon.yaml)")
     ap.add_argument("--stochastic-depth", type=float, default=0.0)
     ap.add_argument("--deep-spec-augment", action="store_true")
+    ap.add_argument("--hip-graph", action="store_true", help="training.wft_hip_graph: the micro-batch as one captured HIP graph (small models)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -552,6 +557,8 @@ def main():
     extras = headline_default and not args.no_extras and world == 1
     case = Case(args, device, rank, local_rank, world, ddp, lora=args.lora, muon=args.muon, sd=args.stochastic_depth,
                 dsa=args.deep_spec_augment)
+    if args.hip_graph:
+        case.t_cfg["wft_hip_graph"] = True
     head = case.measure(B, S, args.steps, args.warmup, roofline=not args.no_roofline, hand_rolled_steps=3 if extras else 0)
     hbm_peak = round(torch.cuda.max_memory_allocated() / 2**30, 1)
     other = []
@@ -574,9 +581,17 @@ def main():
         lora_line["workload"] = f"whisper-large-v3 {c2.mode()}, 32 clips per GPU per step, S=128 (BASELINE configs[2] shape)"
         c2.release()
         # BASELINE configs[1]: whisper-base full fine-tune, 8 clips (host-bound: 810 launches of 13 ms of kernels per step)
+        # Launch-bound eagerly; `training.wft_hip_graph: true` runs each micro-batch (forward + fused loss + backward) as one captured
+        # HIP graph (engine/graph.py; bit-identical to the eager path) — the line is the graph mode, the eager step time is beside it
         c1 = Case(args, device, rank, local_rank, world, ddp, model_name="base")
-        base_line = c1.measure(8, 128, 20, 5, roofline=not args.no_roofline)
-        base_line["workload"] = f"whisper-base {c1.mode()}, 8 clips per GPU per step, S=128 (BASELINE configs[1])"
+        eager = c1.measure(8, 128, 20, 5, roofline=False)
+        c1.t_cfg["wft_hip_graph"] = True
+        base_line = c1.measure(8, 128, 30, 8, roofline=not args.no_roofline)
+        base_line["eager_ms_per_step"], base_line["eager_ms_per_step_median"] = eager["ms_per_step"], eager["ms_per_step_median"]
+        gm = c1.model.__dict__.get("_wft_graph")
+        base_line["hip_graph"] = {"micro_batch_graphs": len(gm[1].graphs) if gm else 0, "disabled": gm[1].disabled if gm else "not built"}
+        base_line["workload"] = (f"whisper-base {c1.mode()}, 8 clips per GPU per step, S=128 (BASELINE configs[1]), training.wft_hip_graph: "
+                                 "forward + loss + backward of the micro-batch as one HIP graph; front end, clip, optimizer, scheduler eager")
         c1.release()
         # BASELINE configs[4]'s per-GPU workload: large-v3-turbo (4-layer decoder), LoRA r16, prompt + timestamp targets, B = 64
         c4 = Case(args, device, rank, local_rank, world, ddp, lora=True, model_name="large-v3-turbo", prompt_ts=True)

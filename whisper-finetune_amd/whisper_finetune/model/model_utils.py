@@ -67,6 +67,7 @@ def train_step(
         scaler = None
 
     device = next(model.parameters()).device
+    graphed = _graphed_micro_batch(model, t_config, mixed, amp_dtype, label_smoothing, accum, scaler)
     total_loss = 0.0
     for micro in range(accum):
         last = micro == accum - 1
@@ -76,6 +77,9 @@ def train_step(
                 x = x.to(device, non_blocking=True)
                 y_in = y_in.to(device, non_blocking=True)
                 y_out = y_out.to(device, non_blocking=True)
+                if graphed is not None:  # training.wft_hip_graph: forward + loss + backward as ONE graph launch (engine/graph.py)
+                    total_loss += graphed(x, y_in, y_out).item()
+                    break
                 with rt.maybe_no_sync(model, enabled=rt.IS_DISTRIBUTED and not last):
                     with torch.autocast(device_type=device.type, enabled=mixed, dtype=amp_dtype):
                         loss = _micro_batch_loss(model, x, y_in, y_out, label_smoothing) / accum
@@ -122,8 +126,37 @@ def train_step(
     else:
         optimizer.step()
         lr_scheduler.step()
-    optimizer.zero_grad(set_to_none=True)
+    # (graph mode: the captured backward adds into persistent gradient buffers — zeroed in place, never dropped; this holds for
+    # every later step of a model that has captured graphs, also one that runs eagerly)
+    optimizer.zero_grad(set_to_none=graphed is None and "_wft_graph" not in rt.unwrap_model(model).__dict__)
     return total_loss
+
+
+def _graphed_micro_batch(model, t_config, mixed, amp_dtype, label_smoothing, accum, scaler):
+    """The model's GraphedMicroBatch if `training.wft_hip_graph` asks for one and the configuration can be captured, else None
+    (with one loud message saying why).  Cached on the model object; rebuilt if label smoothing or the accumulation factor change."""
+    if not t_config.get("wft_hip_graph", False):
+        return None
+    from whisper_finetune.engine import graph as G
+
+    m = rt.unwrap_model(model)
+    reason = None
+    if m is not model:
+        reason = "the model is wrapped (DDP): its reducer hooks are Python"
+    elif not mixed or amp_dtype != torch.bfloat16 or scaler is not None:
+        reason = "only bf16 mixed precision is captured"
+    else:
+        reason = G.why_not(m)
+    if reason is not None:
+        if not m.__dict__.get("_wft_graph_refused"):
+            m.__dict__["_wft_graph_refused"] = True
+            print(f"WARNING: training.wft_hip_graph is set but this run stays on the eager path: {reason}.")
+        return None
+    key = (float(label_smoothing), int(accum))
+    ent = m.__dict__.get("_wft_graph")
+    if ent is None or ent[0] != key:
+        ent = m.__dict__["_wft_graph"] = (key, G.GraphedMicroBatch(m, label_smoothing, accum, amp_dtype))
+    return ent[1]
 
 
 def save_model(model, save_path: str) -> None:
