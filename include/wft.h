@@ -229,8 +229,8 @@ int wft_gemm_set_nt_variant(int v);
 int wft_gemm_set_tn_variant(int v);
 /* Launch mode of the 256x256 NT kernels: 1 (default) = persistent, one workgroup per CU walks the tiles; 0 = one workgroup per
  * tile (the mode of a multi-GPU job, where RCCL's collective kernels hold CUs during the backward pass: engine/lib.py sets
- * WFT_NT256_PERSISTENT=0 when WORLD_SIZE > 1, the reference's DDP wrap at scripts/finetune.py:694-710).  Same results either
- * way.  Returns the previous setting; v < 0 only queries.                                                          */
+ * WFT_NT256_PERSISTENT=0 when WORLD_SIZE > 1, the reference's DDP wrap at scripts/finetune.py:694-710; measured under a CU thief in
+ * bench.py's ddp_mode_1gpu block).  Same results either way.  Returns the previous setting; v < 0 only queries.                                                          */
 int wft_gemm_set_persistent(int v);
 /* Which kernel wft_gemm_nt_bf16 dispatches these arguments to: 4 (gemm_nt4w_kernel: 256x256 tiles, four waves with 128x128
  * accumulators each), 256 (gemm_nt256_kernel, the 8-wave ping-pong 256x256 kernel) or 128 (gemm_nt_kernel).  Pure host

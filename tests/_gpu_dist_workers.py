@@ -77,7 +77,7 @@ def ddp_engine_worker(rank, world, port, out):
     find_unused_parameters=True, gradient_as_bucket_view=True, local accumulation 2 (no_sync on the first micro-batch),
     the libwft optimizer reading the bucket views, per-tile GEMM launches — against the same steps without DDP."""
     _setup(rank, world, port, "nccl")
-    os.environ["WFT_NT256_PERSISTENT"] = "0"  # the per-tile launch mode stays covered (default since round 5: persistent everywhere)
+    os.environ["WFT_NT256_PERSISTENT"] = "0"  # what engine/lib.py selects when WORLD_SIZE > 1 (RCCL kernels hold CUs; measured: bench.py ddp_mode_1gpu)
     import torch
     import torch.distributed as dist
     from torch.nn.parallel import DistributedDataParallel as DDP

@@ -67,7 +67,9 @@ def test_configurations_with_host_drawn_kernel_arguments_are_refused(capsys):
     assert G.why_not(m) is None
     m.decoder = CheckpointedStochasticTextDecoder(dims.n_vocab, dims.n_text_ctx, dims.n_text_state, dims.n_text_head, dims.n_text_layer, 0.1).to(DEV)
     assert "stochastic depth" in G.why_not(m)
-    m2 = Whisper(ModelDimensions(**vars(dims))).to(DEV)
+    m2 = Whisper(ModelDimensions(**vars(dims)))
+    m2.load_state_dict(O.init_params(dims, seed=4))
+    m2.to(DEV)
     lora.apply_lora(m2, {"rank": 4, "lora_alpha": 8, "lora_dropout": 0.1})
     assert "LoRA dropout" in G.why_not(m2)
     m3 = Whisper(ModelDimensions(**vars(dims))).to(DEV)

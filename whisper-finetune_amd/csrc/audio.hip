@@ -1,9 +1,9 @@
 // audio.hip — log-mel front end and SpecAugment on the GPU.
 //
 // logmel: one 256-thread workgroup per (clip, 16 frames): the 2800-sample reflect-padded
-// audio span is staged once in LDS, Hann-windowed frames are written to LDS, the 400-point
-// DFT is evaluated directly in fp32 from a 400-entry twiddle table in LDS (exact periodic
-// index k*n mod 400, no trig in the loop), then the [16 x 201] power tile is multiplied by
+// audio span is staged once in LDS, Hann-windowed frames are written to LDS and folded on the DFT's
+// symmetry (x[n] +- x[400 - n]: half the multiply-adds), the 400-point DFT is evaluated directly in fp32
+// from a 400-entry twiddle table in LDS (exact periodic index k*n mod 400, no trig in the loop), then the [16 x 201] power tile is multiplied by
 // the mel filterbank and log10'd.  Algorithmic HBM bytes per clip: 1.92 MB read +
 // n_mels*3000*4 B written twice (the clip-max floor needs a second pass).
 // specaug: one pass, bilinear time-warp gather + time/frequency/extremes masks.
@@ -46,16 +46,45 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* audio, const f
     frames[f][n] = w * span[f * HOP + n];
   }
   __syncthreads();
-  // DFT, register-blocked: thread = one bin k for all FPB frames.  Per 4 samples: 4 twiddle pairs (ds_read_b64) + FPB
-  // broadcast float4 frame reads feed 8*FPB FMAs, so the loop is VALU-bound (the per-(frame, bin) form read 3 LDS words
-  // per 2 FMAs).  Summation order over n is unchanged: results are bit-identical to that form.
+  // Fold every windowed frame on the DFT's symmetry (round 5: half the multiply-adds).  cos(2 pi k (400 - n) / 400) =
+  // cos(2 pi k n / 400) and sin(...) = -sin(...), so with s[n] = x[n] + x[400 - n], d[n] = x[n] - x[400 - n] (n = 1..199):
+  //   Re X[k] = x[0] + (-1)^k x[200] + sum_n s[n] cos(2 pi k n / 400),   Im X[k] = -sum_n d[n] sin(2 pi k n / 400)
+  // In place: [f][0] = x[0], [f][1..199] = s, [f][200] = x[200], [f][201..399] = d[1..199] (so that both 4-sample reads of the loop
+  // below are 16-byte aligned); two phases around a barrier because d[n] lands in another pair's input.
+  {
+    constexpr int PAIRS = FPB * 199, PER = (PAIRS + 255) / 256;
+    float pa[PER], pb[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int i = tid + j * 256;
+      if (i < PAIRS) {
+        const int f = i / 199, n = 1 + (i - f * 199);
+        pa[j] = frames[f][n];
+        pb[j] = frames[f][NFFT - n];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int i = tid + j * 256;
+      if (i < PAIRS) {
+        const int f = i / 199, n = 1 + (i - f * 199);
+        frames[f][n] = pa[j] + pb[j];
+        frames[f][200 + n] = pa[j] - pb[j];
+      }
+    }
+    __syncthreads();
+  }
+  // DFT, register-blocked: thread = one bin k for all FPB frames.  Per 4 samples: 4 twiddle pairs (ds_read_b64) + 2 FPB
+  // broadcast float4 frame reads feed 8*FPB FMAs: VALU-bound.  (The sample at offset 200 of the first d read is x[200], multiplied
+  // by sin(0) = 0: an exact zero.)
   if (tid < NBIN) {
     const int k = tid;
     float re[FPB], im[FPB];
 #pragma unroll
     for (int f = 0; f < FPB; ++f) { re[f] = 0.f; im[f] = 0.f; }
     int idx = 0;
-    for (int n = 0; n < NFFT; n += 4) {
+    for (int n = 0; n < 200; n += 4) {
       f32x2 t[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -65,16 +94,21 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* audio, const f
       }
 #pragma unroll
       for (int f = 0; f < FPB; ++f) {
-        const f32x4 x = *(const f32x4*)&frames[f][n];
+        const f32x4 xs = *(const f32x4*)&frames[f][n];
+        const f32x4 xd = *(const f32x4*)&frames[f][200 + n];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          re[f] = fmaf(x[j], t[j][0], re[f]);
-          im[f] = fmaf(x[j], t[j][1], im[f]);
+          re[f] = fmaf(xs[j], t[j][0], re[f]);
+          im[f] = fmaf(xd[j], t[j][1], im[f]);
         }
       }
     }
+    const float sgn = (k & 1) ? -1.f : 1.f;  // cos(pi k)
 #pragma unroll
-    for (int f = 0; f < FPB; ++f) power[f][k] = re[f] * re[f] + im[f] * im[f];
+    for (int f = 0; f < FPB; ++f) {
+      re[f] = fmaf(frames[f][200], sgn, re[f]);
+      power[f][k] = re[f] * re[f] + im[f] * im[f];
+    }
   }
   __syncthreads();
   float lmax = -1.0e30f;

@@ -168,12 +168,15 @@ def load():
             f"HIP extension {LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(make -C whisper-finetune_amd/csrc). There is no CPU fallback for the product path."
         )
-    # Launch modes of a multi-GPU job.  Rounds 3-4 switched the persistent NT / dK/dV grids to one workgroup per tile when
-    # WORLD_SIZE > 1, on the argument that RCCL's collective kernels hold CUs.  Round 5 measured it on one GPU (bench.py
-    # `ddp_mode_1gpu`: DDP wrapper, a side-stream kernel per gradient bucket that holds 24 CUs and moves the ring's bytes):
-    # per-tile 642.7 ms vs persistent 639.3 ms per step under the CU thief, 634.1 vs 628.8 without — persistent wins both, so
-    # it stays the default everywhere.  WFT_NT256_PERSISTENT=0 / WFT_ATTN_PERSISTENT=0 (or wft_gemm_set_persistent /
-    # wft_attn_set_persistent) still select per-tile launches.
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # Launch modes of a multi-GPU job: one workgroup per tile / item instead of the persistent grids.  RCCL's collective kernels
+        # hold CUs while the backward pass runs; measured on one GPU with a side-stream kernel per gradient bucket that holds 24 CUs
+        # and moves the ring's bytes (bench.py `ddp_mode_1gpu`, four boxes): without it the per-tile modes cost 0.5-0.9 % of the
+        # step, with it they are 0.6-1.1 % FASTER than the persistent ones in three runs of four (persistent grids wait for the
+        # stolen CUs' share of the tiles: +16 ms for 43 ms of thief against +3 ms per-tile).  The library reads the variables once,
+        # when it is loaded; wft_gemm_set_persistent / wft_attn_set_persistent switch inside a process.
+        os.environ.setdefault("WFT_NT256_PERSISTENT", "0")
+        os.environ.setdefault("WFT_ATTN_PERSISTENT", "0")
     lib = C.CDLL(str(LIB_PATH))
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
