@@ -288,7 +288,7 @@ class Case:
                 yield frontend(audio, training=True), y_in, y_out
 
         it = batches()
-        rt.IS_DISTRIBUTED = self.world > 1
+        rt.IS_DISTRIBUTED = self.world > 1 or getattr(self, "force_distributed", False)
 
         def step():
             return train_step(net, it, opt, sched, self.t_cfg)
@@ -463,7 +463,8 @@ def ddp_mode_1gpu(case, B, S, plain_ms):
 
     out = {"batch": B, "seq_len": S, "plain_ms_per_step": plain_ms, "thief_cus": thief_cus, "thief_gbps": thief_gbps,
            "what": "headline workload under DDP (1-rank RCCL group, gradient_as_bucket_view, 64 MB buckets); per_tile = "
-                   "wft_gemm_set_persistent(0) + wft_attn_set_persistent(0), the launch modes of a WORLD_SIZE > 1 job; thief = a "
+                   "wft_gemm_set_persistent(0) + wft_attn_set_persistent(0) everywhere; product = train_step's multi-process mode: "
+                   "persistent grids, per-tile launches only for the backward pass beside the gradient exchange; thief = a "
                    "side-stream kernel per gradient bucket holding thief_cus CUs and copying 2*7/8 of the bucket at thief_gbps"}
     old = (lib.wft_gemm_set_persistent(-1), lib.wft_attn_set_persistent(-1))
     saved = (case.net, case.ddp)
@@ -474,9 +475,12 @@ def ddp_mode_1gpu(case, B, S, plain_ms):
             case.ddp = True
             if thief:
                 case.net.register_comm_hook(None, thief_hook)
-            for mode, flag in (("persistent", 1), ("per_tile", 0)):
+            # product = what model_utils.train_step does in a multi-process job: persistent grids, per-tile launches only for the
+            # backward pass that runs beside the gradient exchange (runtime.exchange_launch_mode)
+            for mode, flag in (("persistent", 1), ("per_tile", 0), ("product", 1)):
                 lib.wft_gemm_set_persistent(flag)
                 lib.wft_attn_set_persistent(flag)
+                case.force_distributed = mode == "product"
                 moved[0] = 0
                 r = case.measure(B, S, 3, 2 if (not thief and mode == "persistent") else 1, roofline=False,
                                  ddp_twin=(not thief and mode == "persistent"))
@@ -497,10 +501,12 @@ def ddp_mode_1gpu(case, B, S, plain_ms):
             case.net = None
         out["ddp_persistent_overhead_pct"] = round((out["ddp_persistent_ms_per_step"] / plain_ms - 1.0) * 100.0, 2)  # the default launch mode
         out["ddp_per_tile_overhead_pct"] = round((out["ddp_per_tile_ms_per_step"] / plain_ms - 1.0) * 100.0, 2)
+        out["ddp_product_overhead_pct"] = round((out["ddp_product_ms_per_step"] / plain_ms - 1.0) * 100.0, 2)  # what a multi-GPU job runs
         out["per_tile_vs_persistent_under_thief_pct"] = round((out["ddp_per_tile_thief_ms_per_step"] / out["ddp_persistent_thief_ms_per_step"] - 1.0) * 100.0, 2)
     finally:
         lib.wft_gemm_set_persistent(old[0])
         lib.wft_attn_set_persistent(old[1])
+        case.force_distributed = False
         case.net, case.ddp = saved
         del scratch
         if own_pg:

@@ -110,13 +110,25 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* audio, const f
       power[f][k] = re[f] * re[f] + im[f] * im[f];
     }
   }
+  // The mel filters are triangles: 2-30 non-zero bins out of 201 per filter.  Each filter's non-zero range is found once per
+  // workgroup (one thread per filter; skipping exact zeros leaves every sum bit-identical to the dense loop).
+  __shared__ short mlo[256], mhi[256];
+  if (tid < n_mels && tid < 256) {
+    const float* fl = filters + (long)tid * NBIN;
+    int lo = NBIN, hi = 0;
+    for (int k = 0; k < NBIN; ++k)
+      if (fl[k] != 0.f) { lo = lo < k ? lo : k; hi = k + 1; }
+    mlo[tid] = (short)(lo < hi ? lo : 0);
+    mhi[tid] = (short)hi;
+  }
   __syncthreads();
   float lmax = -1.0e30f;
   for (int o = tid; o < n_mels * FPB; o += 256) {
     const int mI = o / FPB, f = o - mI * FPB;
     const float* fl = filters + (long)mI * NBIN;
     float acc = 0.f;
-    for (int k = 0; k < NBIN; ++k) acc = fmaf(fl[k], power[f][k], acc);
+    const int k0 = mI < 256 ? mlo[mI] : 0, k1 = mI < 256 ? mhi[mI] : NBIN;
+    for (int k = k0; k < k1; ++k) acc = fmaf(fl[k], power[f][k], acc);
     const float lg = log10f(fmaxf(acc, 1.0e-10f));
     const int fr = f0 + f;
     if (fr < n_frames) {

@@ -168,15 +168,10 @@ def load():
             f"HIP extension {LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(make -C whisper-finetune_amd/csrc). There is no CPU fallback for the product path."
         )
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        # Launch modes of a multi-GPU job: one workgroup per tile / item instead of the persistent grids.  RCCL's collective kernels
-        # hold CUs while the backward pass runs; measured on one GPU with a side-stream kernel per gradient bucket that holds 24 CUs
-        # and moves the ring's bytes (bench.py `ddp_mode_1gpu`, four boxes): without it the per-tile modes cost 0.5-0.9 % of the
-        # step, with it they are 0.6-1.1 % FASTER than the persistent ones in three runs of four (persistent grids wait for the
-        # stolen CUs' share of the tiles: +16 ms for 43 ms of thief against +3 ms per-tile).  The library reads the variables once,
-        # when it is loaded; wft_gemm_set_persistent / wft_attn_set_persistent switch inside a process.
-        os.environ.setdefault("WFT_NT256_PERSISTENT", "0")
-        os.environ.setdefault("WFT_ATTN_PERSISTENT", "0")
+    # Launch modes of a multi-GPU job: persistent grids by default; model_utils.train_step switches the 256x256 NT GEMMs and the
+    # dK/dV kernel to one workgroup per tile / item for the backward pass that runs beside the gradient all-reduce
+    # (runtime.exchange_launch_mode, wft_gemm_set_persistent / wft_attn_set_persistent; measured in bench.py's ddp_mode_1gpu block).
+    # WFT_NT256_PERSISTENT=0 / WFT_ATTN_PERSISTENT=0 (read when the library is loaded) force per-tile launches everywhere.
     lib = C.CDLL(str(LIB_PATH))
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing

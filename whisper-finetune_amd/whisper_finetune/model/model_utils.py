@@ -83,7 +83,9 @@ def train_step(
                 with rt.maybe_no_sync(model, enabled=rt.IS_DISTRIBUTED and not last):
                     with torch.autocast(device_type=device.type, enabled=mixed, dtype=amp_dtype):
                         loss = _micro_batch_loss(model, x, y_in, y_out, label_smoothing) / accum
-                    (scaler.scale(loss) if scaler else loss).backward()
+                    # the backward pass that runs beside the bucketed all-reduce: per-tile launches (runtime.exchange_launch_mode)
+                    with rt.exchange_launch_mode(rt.IS_DISTRIBUTED and last and device.type == "cuda"):
+                        (scaler.scale(loss) if scaler else loss).backward()
                 total_loss += loss.item()
                 break
             except RuntimeError as err:

@@ -92,6 +92,28 @@ def maybe_no_sync(model: torch.nn.Module, enabled: bool):
     return contextlib.nullcontext()
 
 
+@contextlib.contextmanager
+def exchange_launch_mode(active: bool):
+    """Launch modes while a gradient exchange is in flight: inside this context (the backward pass of the LAST micro-batch of an
+    accumulation window in a multi-process job — the only kernels that run beside RCCL's collective kernels; the reference's
+    `no_sync()` window, model/model_utils.py:63-72) the 256x256 NT GEMMs and the dK/dV attention kernel are launched one workgroup
+    per tile / item, everywhere else on their persistent grids.  Measured on one GPU with a side-stream kernel that holds CUs the
+    way the collectives do (bench.py `ddp_mode_1gpu`): per-tile launches cost 0.5-0.9 % of a step while nothing holds CUs and
+    are 0.6-1.1 % faster than persistent grids while 24 CUs are held."""
+    if not active:
+        yield
+        return
+    from whisper_finetune.engine import lib as L
+
+    lib = L.load()
+    old = (lib.wft_gemm_set_persistent(0), lib.wft_attn_set_persistent(0))
+    try:
+        yield
+    finally:
+        lib.wft_gemm_set_persistent(old[0])
+        lib.wft_attn_set_persistent(old[1])
+
+
 # ---------------------------------------------------------------- wandb (rank 0 only)
 def setup_wandb(**kwargs) -> None:
     global _wandb
