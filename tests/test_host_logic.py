@@ -461,6 +461,24 @@ def test_grad_fork_sums_like_autograd_in_partial_repeated_and_aborted_passes():
     assert torch.equal(x.grad, torch.full((4,), 2.0 * (1 + 2 + 3 + 4)))
 
 
+def test_hip_graph_request_is_refused_loudly_where_it_cannot_be_honoured(capsys, monkeypatch):
+    """`training.wft_hip_graph: true` (engine/graph.py): train_step captures the micro-batch only for an un-wrapped engine model on
+    a HIP device in bf16 mixed precision without host-drawn kernel arguments; anything else says why, once, and runs eagerly."""
+    from whisper_finetune.engine import graph as G
+
+    m = _tiny()
+    assert "HIP device" in G.why_not(m)
+    assert "not an engine Whisper" in G.why_not(torch.nn.Linear(2, 2))
+    monkeypatch.setattr(rt, "IS_DISTRIBUTED", False)
+    toy = _TinyDDPModel()
+    cfg = {**T_CFG, "wft_hip_graph": True}
+    for _ in range(2):
+        model_utils.train_step(toy, _batches(4), torch.optim.SGD(toy.parameters(), lr=0.1), _Sched(), dict(cfg))
+    out = capsys.readouterr().out
+    assert out.count("stays on the eager path") == 1 and "bf16 mixed precision" in out
+    assert all(p.grad is None for p in toy.parameters())  # the eager path's zero_grad(set_to_none=True) is untouched
+
+
 def test_optimizer_post_hook_only_counts_optimizers_that_own_shadowed_parameters():
     """engine/ops.py: torch's fused optimizers do not bump tensor._version, so an optimizer step invalidates the bf16 weight
     shadows through a global post-hook — scoped to optimizers that own a parameter the engine has shadowed: an
