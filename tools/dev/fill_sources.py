@@ -1,8 +1,9 @@
-"""Developer script (GPU box): who launches the ~830 FillFunctor kernels per headline step (2.7 ms in profiles/r04_d)?  One train_step
-of large-v3 at a small batch under torch.profiler with Python stacks; aten::zero_ / aten::fill_ / aten::zeros calls grouped by the
-innermost frame inside this repository."""
+"""Developer script (GPU box): who launches the fill kernels of one training step?  Python-level: torch.zeros / zeros_like / new_zeros /
+Tensor.zero_ / fill_ are wrapped and counted by calling line for ONE train_step of the chosen configuration (large-v3 at a small batch).
+    python tools/dev/fill_sources.py [lora]"""
 import collections
 import sys
+import traceback
 from pathlib import Path
 
 import torch
@@ -17,23 +18,29 @@ class A:
     model = "large-v3"
 
 
+lora = len(sys.argv) > 1 and sys.argv[1] == "lora"
 dev = torch.device("cuda:0")
-case = bench.Case(A, dev, 0, 0, 1, False)
-case.measure(4, 128, 1, 2, roofline=False)  # warm-up: shadows, homes, tables
-
-
-def one():
-    case.measure(4, 128, 1, 0, roofline=False)
-
-
-from torch.profiler import ProfilerActivity, profile  # noqa: E402
-
-with profile(activities=[ProfilerActivity.CPU], with_stack=True) as prof:
-    one()
+case = bench.Case(A, dev, 0, 0, 1, False, lora=lora, muon=lora, sd=0.1 if lora else 0.0, dsa=lora)
+case.measure(4, 128, 1, 2, roofline=False)
 cnt = collections.Counter()
-for ev in prof.events():
-    if ev.name in ("aten::zero_", "aten::fill_", "aten::zeros", "aten::zeros_like", "aten::new_zeros", "aten::full"):
-        frame = next((s for s in ev.stack if "/whisper" in s or "bench.py" in s or "torch/nn/parallel" in s or "optim" in s), ev.stack[0] if ev.stack else "?")
-        cnt[(ev.name, frame)] += 1
-for (name, frame), n in cnt.most_common(30):
-    print(f"{n:6d}  {name:18s} {frame}")
+
+
+def wrap(owner, name):
+    real = getattr(owner, name)
+
+    def f(*a, **k):
+        fr = [x for x in traceback.extract_stack()[:-1] if "whisper" in x.filename or "bench.py" in x.filename]
+        key = f"{Path(fr[-1].filename).name}:{fr[-1].lineno}" if fr else "torch-internal"
+        cnt[(name, key)] += 1
+        return real(*a, **k)
+
+    setattr(owner, name, f)
+
+
+for n in ("zeros", "zeros_like", "full", "ones"):
+    wrap(torch, n)
+for n in ("zero_", "fill_", "new_zeros"):
+    wrap(torch.Tensor, n)
+case.measure(4, 128, 1, 0, roofline=False)
+for (name, key), n in cnt.most_common(30):
+    print(f"{n:6d}  {name:12s} {key}")
