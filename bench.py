@@ -216,6 +216,7 @@ class Case:
 
     def __init__(self, args, device, rank, local_rank, world, ddp, lora=False, muon=False, sd=0.0, dsa=False, model_name=None,
                  prompt_ts=False):
+        import whisper_finetune.runtime as rt
         from whisper_finetune.data.gpu_frontend import GpuFrontend
         from whisper_finetune.model.optimizer import WftAdamW, get_optimizer
 
@@ -249,7 +250,7 @@ class Case:
             from torch.nn.parallel import DistributedDataParallel as DDP
 
             self.net = DDP(self.model, device_ids=[local_rank], output_device=local_rank, broadcast_buffers=False,
-                           gradient_as_bucket_view=True, bucket_cap_mb=64, find_unused_parameters=sd > 0)
+                           gradient_as_bucket_view=True, bucket_cap_mb=rt.ddp_bucket_cap_mb(self.model), find_unused_parameters=sd > 0)
         self.t_cfg = {"mixed_precision_training": True, "mp_dtype": "bf16", "accum_grad_steps": 1, "max_grad_norm": 1.0,
                       "label_smoothing": 0.1, "is_lora_run": False}
 
@@ -350,7 +351,7 @@ class Case:
                 twin[sync] = t.item() * 1e3
             from whisper_finetune.engine import lib as L_
 
-            res["ddp"] = {"rccl_ranks": self.world, "bucket_cap_mb": 64, "gradient_as_bucket_view": True,
+            res["ddp"] = {"rccl_ranks": self.world, "bucket_cap_mb": rt.ddp_bucket_cap_mb(self.model), "gradient_as_bucket_view": True,
                           "nt_persistent_launches": bool(L_.load().wft_gemm_set_persistent(-1)),
                           "attn_persistent_launches": bool(L_.load().wft_attn_set_persistent(-1)),
                           "fwd_bwd_ms_all_reduce": round(twin[True], 2), "fwd_bwd_ms_no_sync": round(twin[False], 2),
@@ -594,7 +595,8 @@ def main():
         c1.t_cfg["wft_hip_graph"] = True
         base_line = c1.measure(8, 128, 30, 8, roofline=not args.no_roofline)
         base_line["eager_ms_per_step"], base_line["eager_ms_per_step_median"] = eager["ms_per_step"], eager["ms_per_step_median"]
-        gm = c1.model.__dict__.get("_wft_graph")
+        from whisper_finetune.engine import graph as _G
+        gm = _G.graphed_for(c1.model)
         base_line["hip_graph"] = {"micro_batch_graphs": len(gm[1].graphs) if gm else 0, "disabled": gm[1].disabled if gm else "not built"}
         base_line["workload"] = (f"whisper-base {c1.mode()}, 8 clips per GPU per step, S=128 (BASELINE configs[1]), training.wft_hip_graph: "
                                  "forward + loss + backward of the micro-batch as one HIP graph; front end, clip, optimizer, scheduler eager")

@@ -93,6 +93,33 @@ def test_get_optimizer_8bit_on_cpu_keeps_the_references_import_error():
         wopt.get_optimizer(m, {"type": "adamw", "8bit": True, "params": {"lr": 1e-3}})
 
 
+def test_state_dict_round_trip_keeps_uint8_codes_and_shared_maps():
+    """torch's Optimizer.load_state_dict casts state tensors to the parameter dtype — the code bytes came back float32 and the
+    next step refused them.  (State built by hand: the update itself is a HIP kernel.)"""
+    p = torch.nn.Parameter(torch.randn(8192))
+    small = torch.nn.Parameter(torch.randn(16))
+    opt = wopt.WftAdamW8bit([p, small], lr=1e-3)
+    g = torch.Generator().manual_seed(0)
+    q1, q2 = opt._maps(p.device)
+    opt.state[p] = {"step": 3, "state1": torch.randint(0, 256, (8192,), dtype=torch.uint8, generator=g),
+                    "state2": torch.randint(0, 256, (8192,), dtype=torch.uint8, generator=g),
+                    "absmax1": torch.rand(4, generator=g), "absmax2": torch.rand(4, generator=g), "qmap1": q1, "qmap2": q2}
+    opt.state[small] = {"step": 3, "exp_avg": torch.randn(16, generator=g), "exp_avg_sq": torch.rand(16, generator=g)}
+    import copy
+
+    sd = copy.deepcopy(opt.state_dict())
+    opt2 = wopt.WftAdamW8bit([torch.nn.Parameter(p.detach().clone()), torch.nn.Parameter(small.detach().clone())], lr=1e-3)
+    opt2.load_state_dict(sd)
+    p2, s2 = opt2.param_groups[0]["params"]
+    st = opt2.state[p2]
+    assert st["state1"].dtype == torch.uint8 and st["state2"].dtype == torch.uint8 and st["state1"].is_contiguous()
+    assert torch.equal(st["state1"], opt.state[p]["state1"]) and torch.equal(st["state2"], opt.state[p]["state2"])
+    assert torch.equal(st["absmax1"], opt.state[p]["absmax1"]) and st["absmax1"].dtype == torch.float32
+    assert st["qmap1"] is opt2._maps(p2.device)[0] and st["qmap2"] is opt2._maps(p2.device)[1]
+    assert st["step"] == 3 and isinstance(st["step"], int)
+    assert torch.equal(opt2.state[s2]["exp_avg"], opt.state[small]["exp_avg"])
+
+
 # ------------------------------------------------------------------------------------------------------------------ GPU
 def _gpu_case(n, seed):
     g = torch.Generator().manual_seed(seed)

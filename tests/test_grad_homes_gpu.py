@@ -97,3 +97,49 @@ def test_training_with_gradient_homes_matches_fresh_gradient_tensors():
         # (relative to the parameter's size, or — the biases start at zero and have moved by 4 steps of lr = 1e-4 — to that distance)
         err = ((p0[n] - p1[n]).norm() / (p0[n].norm() + 4e-4 * p0[n].numel() ** 0.5)).item()
         assert err < 1e-3, (n, err)
+
+
+def test_two_forwards_one_backward_sum_their_weight_gradients_with_homes_on():
+    """one weight feeding two LinearFn nodes of the same backward pass (the model called twice before a single backward —
+    the case `ops.grad_fork` documents as supported).  Both nodes see `w.grad is None`; only the first writer of a graph task may take
+    the home in overwrite mode, otherwise the result is 2 * dW_second.  Checked from the second optimizer step on (homes exist then)
+    against WFT_GRAD_HOMES=0."""
+    from oracle import whisper_oracle as O
+    from whisper_finetune.engine import ops
+    from whisper_finetune.engine.whisper_model import ModelDimensions, Whisper
+    from whisper_finetune.model.optimizer import WftAdamW
+
+    dims = O.DIMS["base"]
+    params = O.init_params(dims, seed=5)
+    batches = []
+    for seed in (0, 1):
+        audio, y_in, y_out = O.synthetic_batch(dims, 6, 16, seed=1234 + 100 * seed)
+        mel = K.logmel(audio.to(DEV), O.mel_filters(dims.n_mels).to(DEV))
+        batches.append((mel, y_in.to(DEV), y_out.to(DEV)))
+
+    def run(homes: bool):
+        old = ops._GRAD_HOMES
+        ops._GRAD_HOMES = homes
+        try:
+            m = Whisper(ModelDimensions(**vars(dims)))
+            m.load_state_dict(params)
+            m.to(DEV).train()
+            opt = WftAdamW(m.parameters(), lr=1e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.0)
+            grads = None
+            for step in range(3):
+                with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+                    loss = sum(m(x, yi, targets=yo, label_smoothing=0.0) for x, yi, yo in batches)
+                loss.backward()
+                grads = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+                opt.step()
+                opt.zero_grad(set_to_none=True)
+            return grads, sum(1 for p in m.parameters() if "_wft_grad_home" in p.__dict__)
+        finally:
+            ops._GRAD_HOMES = old
+
+    g0, h0 = run(False)
+    g1, h1 = run(True)
+    assert h0 == 0 and h1 > 30
+    for n in g0:
+        err = ((g0[n] - g1[n]).norm() / (g0[n].norm() + 1e-12)).item()
+        assert err < 1e-3, (n, err)

@@ -18,9 +18,28 @@ hooks are Python), the fp32 compute mode's host-side paths are fine but untested
 Results are the eager path's bit for bit (same kernels, same order): tests/test_hip_graph_gpu.py."""
 from __future__ import annotations
 
+import weakref
 from typing import Optional
 
 import torch
+
+# model -> (key, GraphedMicroBatch).  Kept OFF the module: a captured graph holds torch.cuda.CUDAGraph objects, which neither pickle nor
+# deep-copy, and `save_model` deep-copies the model (reference model/model_utils.py:130-135).  Weak keys: a dropped model drops its graphs.
+_GRAPHS: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+MAX_SHAPES = 8  # captured input shapes per model; further shapes run eagerly (each graph pins its static inputs and pool memory)
+
+
+def graphed_for(model):
+    """The (key, GraphedMicroBatch) entry of `model`, or None."""
+    return _GRAPHS.get(model)
+
+
+def has_graphs(model) -> bool:
+    return model in _GRAPHS
+
+
+def set_graphed(model, key, gm) -> None:
+    _GRAPHS[model] = (key, gm)
 
 
 def why_not(model) -> Optional[str]:
@@ -51,7 +70,8 @@ def why_not(model) -> Optional[str]:
 
 class GraphedMicroBatch:
     def __init__(self, model, label_smoothing: float, accum: int, amp_dtype=torch.bfloat16, warmup: int = 2):
-        self.model, self.ls, self.accum, self.amp_dtype, self.warmup = model, float(label_smoothing), int(accum), amp_dtype, warmup
+        self._model = weakref.ref(model)  # (the registry's key must not be kept alive by its value)
+        self.ls, self.accum, self.amp_dtype, self.warmup = float(label_smoothing), int(accum), amp_dtype, warmup
         self.graphs = {}  # input shapes -> (graph, x, y_in, y_out, loss)
         self.pool = None
         self.eager_calls = 0
@@ -65,6 +85,13 @@ class GraphedMicroBatch:
         for p in model.parameters():  # persistent gradient buffers (see the module docstring)
             if p.requires_grad and p.grad is None:
                 p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+
+    @property
+    def model(self):
+        m = self._model()
+        if m is None:
+            raise RuntimeError("the model of this GraphedMicroBatch no longer exists")
+        return m
 
     def _eager(self, x, y_in, y_out):
         with torch.autocast(device_type="cuda", dtype=self.amp_dtype):
@@ -80,6 +107,12 @@ class GraphedMicroBatch:
         key = (tuple(x.shape), x.dtype, tuple(y_in.shape), tuple(y_out.shape))
         ent = self.graphs.get(key)
         if ent is None:
+            if len(self.graphs) >= MAX_SHAPES and self.disabled is None:
+                self.shapes_refused = getattr(self, "shapes_refused", 0) + 1
+                if self.shapes_refused == 1:
+                    print(f"WARNING: {MAX_SHAPES} input shapes are captured already; further shapes run eagerly "
+                          "(pad decoder lengths to a small set to keep them on the graph path).")
+                return self._eager(x, y_in, y_out)
             if self.disabled is not None or self.eager_calls < self.warmup or self.eager_after_step < 1:
                 # the first calls run eagerly: lazy one-time work (kernel attributes, workspaces, bf16 shadows, pointer tables) must
                 # not happen under capture — at least two micro-batches, one of them behind an optimizer step

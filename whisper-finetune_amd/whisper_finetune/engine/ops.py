@@ -533,19 +533,31 @@ def _weight_grad_homes(weights, w_need):
     if not _GRAD_HOMES or not all(w_need):
         return None
     homes, modes = [], set()
+    task = torch._C._current_graph_task_id()
     for w in weights:
         h = w.__dict__.get("_wft_grad_home")
         if h is None or h.shape != w.shape or h.device != w.device or w._backward_hooks:
             return None
         g = w.grad
         if g is None:
+            # overwrite mode hands autograd an ALIAS of the home.  A second LinearFn node of the same weight in the same backward pass
+            # (the model called twice before one backward, a Linear reused) still sees w.grad None — AccumulateGrad runs after both —
+            # and would overwrite the first product: only the first writer of a graph task gets the home
+            if w.__dict__.get("_wft_home_task") == task:
+                return None
             modes.add(False)
         elif g.data_ptr() == h.data_ptr() and g.dtype == F32 and g.shape == h.shape and g.is_contiguous():
             modes.add(True)
         else:
             return None
         homes.append(h)
-    return (homes, modes.pop()) if len(modes) == 1 else None
+    if len(modes) != 1:
+        return None
+    mode = modes.pop()
+    if not mode and task != -1:
+        for w in weights:
+            w.__dict__["_wft_home_task"] = task
+    return homes, mode
 
 
 class _LinearCfg:

@@ -29,7 +29,8 @@ import whisper_finetune.runtime as rt
 from whisper_finetune.data import transforms as T  # the reference's `import torchaudio.transforms as T` (model_utils.py:10)
 from whisper_finetune.engine.whisper_model import AudioEncoder, LayerNorm, TextDecoder, Whisper, check_amp_request
 
-_ILLEGAL = "CUDA error: an illegal memory"
+# PyTorch-ROCm words it "HIP error: an illegal memory access ..."; the CUDA spelling is the reference's (model_utils.py:76)
+_ILLEGAL = ("HIP error: an illegal memory", "CUDA error: an illegal memory")
 
 
 def _micro_batch_loss(model, x, y_in, y_out, label_smoothing: float) -> Tensor:
@@ -91,7 +92,7 @@ def train_step(
             except RuntimeError as err:
                 # the reference retries sporadic illegal-memory-access errors 3x on one GPU and
                 # aborts immediately under DDP (a retry would desynchronise the ranks)
-                if _ILLEGAL not in str(err):
+                if not any(s in str(err) for s in _ILLEGAL):
                     raise
                 if rt.IS_DISTRIBUTED:
                     print("Caught illegal memory access under DDP; aborting instead of retrying.")
@@ -130,8 +131,14 @@ def train_step(
         lr_scheduler.step()
     # (graph mode: the captured backward adds into persistent gradient buffers — zeroed in place, never dropped; this holds for
     # every later step of a model that has captured graphs, also one that runs eagerly)
-    optimizer.zero_grad(set_to_none=graphed is None and "_wft_graph" not in rt.unwrap_model(model).__dict__)
+    optimizer.zero_grad(set_to_none=graphed is None and not _has_graphs(model))
     return total_loss
+
+
+def _has_graphs(model) -> bool:
+    from whisper_finetune.engine import graph as G
+
+    return G.has_graphs(rt.unwrap_model(model))
 
 
 def _graphed_micro_batch(model, t_config, mixed, amp_dtype, label_smoothing, accum, scaler):
@@ -155,9 +162,10 @@ def _graphed_micro_batch(model, t_config, mixed, amp_dtype, label_smoothing, acc
             print(f"WARNING: training.wft_hip_graph is set but this run stays on the eager path: {reason}.")
         return None
     key = (float(label_smoothing), int(accum))
-    ent = m.__dict__.get("_wft_graph")
+    ent = G.graphed_for(m)  # (kept off the module: save_model deep-copies it, CUDAGraph objects do not copy)
     if ent is None or ent[0] != key:
-        ent = m.__dict__["_wft_graph"] = (key, G.GraphedMicroBatch(m, label_smoothing, accum, amp_dtype))
+        G.set_graphed(m, key, G.GraphedMicroBatch(m, label_smoothing, accum, amp_dtype))
+        ent = G.graphed_for(m)
     return ent[1]
 
 

@@ -153,6 +153,23 @@ class WftAdamW8bit(_FusedClipMixin, torch.optim.Optimizer):
             ent = self._qmaps[device] = (create_dynamic_map(True).to(device), create_dynamic_map(False).to(device))
         return ent
 
+    def load_state_dict(self, state_dict):
+        """torch.optim.Optimizer.load_state_dict casts every state tensor except `step` to the parameter's dtype: the code bytes come
+        back as float32 (values 0..255, exact).  Restore uint8 codes, re-share the two maps, keep `step` a Python int (bitsandbytes
+        overrides load_state_dict for the same reason)."""
+        super().load_state_dict(state_dict)
+        for p, st in self.state.items():
+            for k in ("state1", "state2"):
+                if k in st and st[k].dtype != torch.uint8:
+                    st[k] = st[k].round().to(torch.uint8).contiguous()
+            for k in ("absmax1", "absmax2", "exp_avg", "exp_avg_sq"):
+                if k in st and st[k].dtype != torch.float32:
+                    st[k] = st[k].float()
+            if "state1" in st:
+                st["qmap1"], st["qmap2"] = self._maps(p.device)
+            if torch.is_tensor(st.get("step")):
+                st["step"] = int(st["step"].item())
+
     @torch.no_grad()
     def step(self, closure=None):
         from whisper_finetune.engine import kernels as K

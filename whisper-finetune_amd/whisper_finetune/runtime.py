@@ -92,6 +92,15 @@ def maybe_no_sync(model: torch.nn.Module, enabled: bool):
     return contextlib.nullcontext()
 
 
+def ddp_bucket_cap_mb(model, default_mb: int = 64, one_bucket_below_mb: int = 256) -> int:
+    """`bucket_cap_mb` for the DDP wrap (reference: scripts/finetune.py:694-705 takes torch's default).  Full fine-tuning moves
+    gigabytes of fp32 gradients: 64 MB buckets (xGMI is point-to-point — few, large messages — and the first buckets leave while the
+    backward pass still runs).  A LoRA / frozen run moves 56-115 MB in total: latency-bound, ONE bucket — the cap is the
+    trainable bytes rounded up."""
+    mb = sum(p.numel() * p.element_size() for p in model.parameters() if p.requires_grad) / 2**20
+    return int(mb) + 1 if mb <= one_bucket_below_mb else default_mb
+
+
 @contextlib.contextmanager
 def exchange_launch_mode(active: bool):
     """Launch modes while a gradient exchange is in flight: inside this context (the backward pass of the LAST micro-batch of an

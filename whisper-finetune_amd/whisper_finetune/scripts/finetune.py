@@ -283,7 +283,7 @@ def main(config: dict):
         unused = t_cfg.get("ddp_find_unused_parameters", float(t_cfg.get("stochastic_depth", 0.0)) > 0)
         kw = dict(device_ids=[rt.LOCAL_RANK], output_device=rt.LOCAL_RANK) if device.type == "cuda" else {}
         model = DDP(model, find_unused_parameters=unused, broadcast_buffers=False, gradient_as_bucket_view=True,
-                    bucket_cap_mb=64, **kw)
+                    bucket_cap_mb=rt.ddp_bucket_cap_mb(model), **kw)
 
     w_cfg = dict(config.get("wandb", {}))
     if w_cfg.pop("enabled", False):
