@@ -349,11 +349,9 @@ class Case:
                 t = torch.tensor([(time.perf_counter() - t0) / min(3, steps)], device=dev, dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 twin[sync] = t.item() * 1e3
-            from whisper_finetune.engine import lib as L_
-
             res["ddp"] = {"rccl_ranks": self.world, "bucket_cap_mb": rt.ddp_bucket_cap_mb(self.model), "gradient_as_bucket_view": True,
-                          "nt_persistent_launches": bool(L_.load().wft_gemm_set_persistent(-1)),
-                          "attn_persistent_launches": bool(L_.load().wft_attn_set_persistent(-1)),
+                          "launch_mode": "persistent grids; per-tile launches (wft_gemm_args / wft_attn_args launch_mode = 1) for the backward "
+                                         "pass of the last micro-batch of a window, beside the gradient exchange (runtime.exchange_launch_mode)",
                           "fwd_bwd_ms_all_reduce": round(twin[True], 2), "fwd_bwd_ms_no_sync": round(twin[False], 2),
                           "exposed_exchange_ms": round(twin[True] - twin[False], 2)}
         if hand_rolled_steps > 0:
@@ -464,10 +462,11 @@ def ddp_mode_1gpu(case, B, S, plain_ms):
 
     out = {"batch": B, "seq_len": S, "plain_ms_per_step": plain_ms, "thief_cus": thief_cus, "thief_gbps": thief_gbps,
            "what": "headline workload under DDP (1-rank RCCL group, gradient_as_bucket_view, 64 MB buckets); per_tile = "
-                   "wft_gemm_set_persistent(0) + wft_attn_set_persistent(0) everywhere; product = train_step's multi-process mode: "
+                   "launch_mode = 1 in every wft_gemm_args / wft_attn_args (kernels.LAUNCH_OVERRIDE); product = train_step's multi-process mode: "
                    "persistent grids, per-tile launches only for the backward pass beside the gradient exchange; thief = a "
                    "side-stream kernel per gradient bucket holding thief_cus CUs and copying 2*7/8 of the bucket at thief_gbps"}
-    old = (lib.wft_gemm_set_persistent(-1), lib.wft_attn_set_persistent(-1))
+    from whisper_finetune.engine import kernels as K_
+
     saved = (case.net, case.ddp)
     try:
         for thief in (False, True):
@@ -478,9 +477,8 @@ def ddp_mode_1gpu(case, B, S, plain_ms):
                 case.net.register_comm_hook(None, thief_hook)
             # product = what model_utils.train_step does in a multi-process job: persistent grids, per-tile launches only for the
             # backward pass that runs beside the gradient exchange (runtime.exchange_launch_mode)
-            for mode, flag in (("persistent", 1), ("per_tile", 0), ("product", 1)):
-                lib.wft_gemm_set_persistent(flag)
-                lib.wft_attn_set_persistent(flag)
+            for mode, force in (("persistent", 0), ("per_tile", 1), ("product", None)):
+                K_.LAUNCH_OVERRIDE[0] = force  # None: the per-call argument train_step's launch mode sets decides
                 case.force_distributed = mode == "product"
                 moved[0] = 0
                 r = case.measure(B, S, 3, 2 if (not thief and mode == "persistent") else 1, roofline=False,
@@ -505,8 +503,7 @@ def ddp_mode_1gpu(case, B, S, plain_ms):
         out["ddp_product_overhead_pct"] = round((out["ddp_product_ms_per_step"] / plain_ms - 1.0) * 100.0, 2)  # what a multi-GPU job runs
         out["per_tile_vs_persistent_under_thief_pct"] = round((out["ddp_per_tile_thief_ms_per_step"] / out["ddp_persistent_thief_ms_per_step"] - 1.0) * 100.0, 2)
     finally:
-        lib.wft_gemm_set_persistent(old[0])
-        lib.wft_attn_set_persistent(old[1])
+        K_.LAUNCH_OVERRIDE[0] = None
         case.force_distributed = False
         case.net, case.ddp = saved
         del scratch

@@ -14,8 +14,14 @@
  *    the name ends in _host; the caller (PyTorch's allocator) owns every buffer
  *    including workspaces;
  *  - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*):
- *    no host sync, no allocation, no default-stream use, no device state kept
- *    in the library — re-entrant across streams and threads;
+ *    no host sync, no allocation, no default-stream use, no device state and no
+ *    mutable host state kept in the library — re-entrant across streams and
+ *    threads.  Everything that selects a launch mode or a kernel variant is a
+ *    FIELD of the call's argument struct (wft_gemm_args / wft_attn_args:
+ *    launch_mode, variant, q_prescaled); the only process-wide inputs are read
+ *    ONCE when the library is loaded: WFT_NT256_PERSISTENT / WFT_ATTN_PERSISTENT
+ *    (=0: one workgroup per tile everywhere) and, in libwft_timing.so only, the
+ *    developer switches of DESIGN.md §3;
  *  - return value: WFT_OK (0) or a negative wft_status; wft_last_error() gives
  *    a thread-local message for the last failure on the calling thread;
  *  - matrices are row-major; `ld*` are leading dimensions in ELEMENTS;
@@ -53,19 +59,24 @@ int wft_cast_bf16_f32(const wft_bf16* src, float* dst, int64_t n, void* stream);
 /* src f32 [rows, cols] -> dst bf16 [rows_pad, cols_pad] (zero padded, row
  * stride ld_dst) and, if dst_t != NULL, dst_t bf16 [cols_pad, rows_pad] (row
  * stride ld_dst_t: the transposed shadow the backward-data GEMM consumes).
- * The strides let several weights (q/k/v) share one concatenated shadow.     */
+ * The strides let several weights (q/k/v) share one concatenated shadow.
+ * fwd_scale (0 is read as 1): dst = bf16(fwd_scale * src) — one rounding of the
+ * scaled value — while dst_t stays bf16(src): the softmax scale * log2(e) of a
+ * self-attention q projection folded into its FORWARD shadow
+ * (wft_attn_args.q_prescaled; whisper's `q * scale`, App. A.1).               */
 int wft_cast_pad_transpose_f32_bf16(const float* src, int64_t rows, int64_t cols,
                                     wft_bf16* dst, wft_bf16* dst_t,
                                     int64_t rows_pad, int64_t cols_pad,
-                                    int64_t ld_dst, int64_t ld_dst_t, void* stream);
+                                    int64_t ld_dst, int64_t ld_dst_t, float fwd_scale, void* stream);
 /* W_eff = W + scaling * B @ (A * mask): the weight minLoRA's parametrization produces for every adapted Linear
  * (reference call sites model/lora.py:30-71 apply, :83-89 merge).  W f32 [rows, cols], B f32
  * [rows, rank], A f32 [rank, cols], mask f32 [cols] or NULL (the already-drawn dropout mask), rank <= 64.
  * Outputs (any subset): dst bf16 [rows_pad, cols_pad] (ld_dst) and dst_t bf16 [cols_pad, rows_pad] (ld_dst_t), zero
- * padded — the GEMM shadows of the training forward/backward; dst_f32 f32 [rows, cols] (may alias W) — merge_lora. */
+ * padded — the GEMM shadows of the training forward/backward; dst_f32 f32 [rows, cols] (may alias W) — merge_lora.
+ * fwd_scale: as in wft_cast_pad_transpose_f32_bf16 (dst only; dst_t and dst_f32 are never scaled).                  */
 int wft_lora_merge(const float* W, int64_t rows, int64_t cols, const float* B, const float* A, const float* mask,
                    int rank, float scaling, wft_bf16* dst, wft_bf16* dst_t, int64_t rows_pad, int64_t cols_pad,
-                   int64_t ld_dst, int64_t ld_dst_t, float* dst_f32, void* stream);
+                   int64_t ld_dst, int64_t ld_dst_t, float* dst_f32, float fwd_scale, void* stream);
 /* Operands of the rank-r adapter-gradient GEMMs (du = dy (sB), u = x (s A*mask)^T; minLoRA parametrization, model/lora.py:30-71)
  * of ONE adapter, written into its Linear group's zero-initialised padded bf16 buffers: Am [rpad, K] rows ro..ro+rank (and
  * AmT [K, rpad]) = scaling * A * mask; Bb [npad, rpad] block (no..no+n, ro..ro+rank) (and BbT [rpad, npad]) = scaling * B.
@@ -76,14 +87,16 @@ int wft_lora_pack(const float* A, const float* mask, const float* B, int rank, i
 /* wft_lora_merge (dst + dst_t) and wft_lora_pack of EVERY adapter of a model in one launch — issued once per training forward,
  * right after the dropout masks are drawn, instead of two launches per Linear (2 x 512 for large-v3).  tab: device array of n
  * rows x 20 int64:
- *   0 W, 1 rows, 2 cols, 3 B, 4 A, 5 mask (or 0), 6 rank, 7 scaling (the float's bits), 8 dst, 9 dst_t (or 0), 10 ld_dst,
+ *   0 W, 1 rows, 2 cols, 3 B, 4 A, 5 mask (or 0), 6 rank, 7 scaling (the float's bits in bits 0..31; bits 32..63: fwd_scale as float bits, 0 = 1 —
+ *   dst = bf16(fwd_scale * w), dst_t unscaled, as in wft_cast_pad_transpose_f32_bf16), 8 dst, 9 dst_t (or 0), 10 ld_dst,
  *   11 ld_dst_t, 12 Am, 13 AmT, 14 Bb, 15 BbT (12-15 all 0: no pack), 16 rpad, 17 npad, 18 ro, 19 no
  * with the meanings of the two per-adapter entry points; rows % 64 == 0, cols % 64 == 0, rank <= 64, W 16-byte and dst / dst_t
  * 8-byte aligned, ld_dst % 4 == 0, ld_dst_t % 4 == 0 (the caller checks: a model that does not fit keeps the per-adapter calls).
  * tile_start: device int32 [n + 1], prefix sums of (rows / 64) * (cols / 64); total_tiles = tile_start[n].  Values are
  * bit-identical to the per-adapter entry points. */
 int wft_lora_refresh_mt(const void* tab, const int32_t* tile_start, int n, int total_tiles, void* stream);
-/* n small f32 vector copies in one launch.  tab: DEVICE int64 [n][3] = source address, destination address, element count
+/* n small f32 vector copies in one launch.  tab: DEVICE int64 [n][3] = source address, destination address, element count (bits 0..31;
+ * bits 32..63: a scale as float bits, 0 = plain copy — the q slice of a fused q/k/v bias under wft_attn_args.q_prescaled)
  * (disjoint ranges).  The host mirror uses it to restack the bias vectors of every fused q/k/v group after an optimizer step
  * (whisper.model.Linear biases: the GEMM epilogue reads ONE bias vector per fused group). */
 int wft_mt_copy_f32(const void* tab, int n, void* stream);
@@ -216,22 +229,14 @@ typedef struct {
    * Always through the workspace (wft_gemm_tn_workspace_bytes with these fields set), summed by the reduce kernel in the same
    * fixed order as the unsegmented call: bit-identical values.  C must still be a valid pointer (it is not written).           */
   int tn_seg_count; int tn_seg_end[4]; float* tn_seg_ptr[4];
+  /* Per-call launch state (zero = defaults; nothing is kept in the library):
+   *  launch_mode: 0 = persistent grids for the 256x256 NT kernels (one workgroup per CU walks the tiles), 1 = one workgroup per tile
+   *    (the backward pass beside RCCL's collective kernels: runtime.exchange_launch_mode; scripts/finetune.py:694-710).
+   *  variant: != 0 forces the 8-wave ping-pong kernels (gemm_nt256_kernel / gemm_tn256_kernel) where the one-wave-per-SIMD kernels
+   *    would apply (bit-identity tests, A/B runs; NT: same k order, bit-identical C).                                            */
+  int launch_mode; int variant;
 } wft_gemm_args;
 int wft_gemm_nt_bf16(const wft_gemm_args* args, void* stream);
-/* Which 256x256 NT kernel serves the encoder-sized problems: 0 (default) = the one-wave-per-SIMD kernel (csrc/gemm_nt4w.hip)
- * wherever it applies, 1 = always the 8-wave ping-pong kernel (csrc/gemm.hip).  Environment (libwft_timing.so only, `make TIMING=1`): WFT_NT_VARIANT=4w|pp, read once at
- * load time.  Returns the previous setting; v < 0 only queries.  A/B tool and test hook: the two kernels accumulate in the same
- * k order and give bit-identical C.                                                                        */
-int wft_gemm_set_nt_variant(int v);
-/* The same switch for the weight-gradient GEMM: 0 (default) = gemm_tn4w_kernel (csrc/gemm_tn4w.hip) where it applies, 1 = always
- * gemm_tn256_kernel.  WFT_TN_VARIANT=4w|pp at load time (timing builds only).  Both sum the reduction in ascending 32-row MFMA steps inside a split;
- * their split-K plans may differ (different partial sums, same fixed order from run to run).                          */
-int wft_gemm_set_tn_variant(int v);
-/* Launch mode of the 256x256 NT kernels: 1 (default) = persistent, one workgroup per CU walks the tiles; 0 = one workgroup per
- * tile (the mode of a multi-GPU job, where RCCL's collective kernels hold CUs during the backward pass: engine/lib.py sets
- * WFT_NT256_PERSISTENT=0 when WORLD_SIZE > 1, the reference's DDP wrap at scripts/finetune.py:694-710; measured under a CU thief in
- * bench.py's ddp_mode_1gpu block).  Same results either way.  Returns the previous setting; v < 0 only queries.                                                          */
-int wft_gemm_set_persistent(int v);
 /* Which kernel wft_gemm_nt_bf16 dispatches these arguments to: 4 (gemm_nt4w_kernel: 256x256 tiles, four waves with 128x128
  * accumulators each), 256 (gemm_nt256_kernel, the 8-wave ping-pong 256x256 kernel) or 128 (gemm_nt_kernel).  Pure host
  * function (used by bench.py to attribute HIP-event timings to the kernel names rocprofv3 reports).        */
@@ -281,24 +286,26 @@ typedef struct {
    * second pass over dq / dv.  dq_colsum / dv_colsum: f32 [H*64] outputs (sum over batch and time of the bf16 values
    * written); colsum_ws: f32 scratch of wft_attn_bwd_colsum_workspace_bytes(args) bytes.  All three or none.      */
   float* dq_colsum; float* dv_colsum; float* colsum_ws;
+  /* Per-call launch state (zero-initialised structs get the defaults; nothing here is kept in the library):
+   *  launch_mode: 0 = the kernel's default grid (the dK/dV kernel: persistent, one workgroup per CU), 1 = one work item per workgroup
+   *    (the backward pass that runs beside RCCL's collective kernels in a multi-process job: runtime.exchange_launch_mode; the
+   *    reference's DDP wrap, scripts/finetune.py:694-710).  Same results either way.
+   *  variant: bit 0 forward on attn_fwd_kernel, bit 1 dQ on the 8-wave kernel, bit 2 dK/dV on the 8-wave kernel even where the
+   *    pipelined / one-wave-per-SIMD kernels apply (bit-identity tests, A/B runs).
+   *  q_prescaled != 0: q (forward and backward) already holds (x Wq^T + bq) * scale * log2(e) — the factor folded into the bf16
+   *    forward shadow of the q projection (wft_cast_pad_transpose_f32_bf16 / wft_lora_merge `fwd_scale`), ONE bf16 rounding of the
+   *    scaled value, what `q * scale` costs upstream (whisper.model.MultiHeadAttention.qkv_attention) — so no kernel multiplies the
+   *    scores.  `scale` must still be the softmax scale: dq is returned w.r.t. the UNSCALED projection output (dq = scale dS K),
+   *    dk = dS^T q_prescaled * ln 2, lse stays the natural-log lse of the scaled scores.                                          */
+  int launch_mode; int variant; int q_prescaled;
 } wft_attn_args;
 int wft_attn_fwd_bf16(const wft_attn_args* args, void* stream);
 int wft_attn_bwd_bf16(const wft_attn_args* args, void* stream);
 int64_t wft_attn_bwd_colsum_workspace_bytes(const wft_attn_args* args);
-/* Which dK/dV kernel wft_attn_bwd_bf16 launches: 0 (default) the one-wave-per-SIMD kernel (csrc/attn.hip, attn_bwd_dkdv4w_kernel)
- * for non-causal calls with Tq >= 128, the 8-wave kernel otherwise; 1 always the 8-wave kernel.  Same results up to the
- * rounding of a different summation order over queries.  Returns the previous value; a negative argument only reads.
- * Start value from WFT_DKDV_VARIANT=4w|8w (read by timing builds only, like the two below).  (A/B measurements and tests; not part of the reference's interface.)          */
-int wft_attn_set_dkdv_variant(int variant);
-/* The same switch for the dQ kernel (attn_bwd_dq4w_kernel: non-causal calls with Tq >= 512).  Start value from
- * WFT_DQ_VARIANT=4w|8w.                                                                                                    */
-int wft_attn_set_dq_variant(int variant);
-/* ... and for the forward kernel: 0 (default) = attn_fwd_pipe_kernel (software-pipelined, four-slot K/V ring) for non-causal calls
- * with Tk >= 512 and attn_fwd_kernel for the rest, 1 = attn_fwd_kernel everywhere.  Bit-identical outputs.  Start value from
- * WFT_FWD_VARIANT=8w (timing builds only).                                                                                  */
-int wft_attn_set_fwd_variant(int variant);
-/* Launch mode of the persistent dK/dV kernel, like wft_gemm_set_persistent (start value from WFT_ATTN_PERSISTENT).      */
-int wft_attn_set_persistent(int v);
+/* Which kernel wft_attn_fwd_bf16 / wft_attn_bwd_bf16 dispatch these arguments to (pure host function, like wft_gemm_nt_variant):
+ * which = 0 forward: 2 attn_fwd_pipe_kernel, 1 attn_fwd_kernel; which = 1 dQ: 4 attn_bwd_dq4w_kernel, 8 attn_bwd_dq_kernel;
+ * which = 2 dK/dV: 4 attn_bwd_dkdv4w_kernel, 8 attn_bwd_dkdv_kernel.  Only the shape / stride / causal fields are read.            */
+int wft_attn_variant(const wft_attn_args* args, int which);
 
 /* -------------------------------------------------------------- Embedding */
 /* TextDecoder: x = token_embedding(tokens) + positional_embedding[:S]

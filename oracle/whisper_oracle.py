@@ -65,6 +65,7 @@ DIMS = {
     "tiny": ModelDimensions(80, 1500, 384, 6, 4, 51865, 448, 384, 6, 4),
     "base": ModelDimensions(80, 1500, 512, 8, 6, 51865, 448, 512, 8, 6),
     "small": ModelDimensions(80, 1500, 768, 12, 12, 51865, 448, 768, 12, 12),
+    "medium": ModelDimensions(80, 1500, 1024, 16, 24, 51865, 448, 1024, 16, 24),
     "large-v3": ModelDimensions(128, 1500, 1280, 20, 32, 51866, 448, 1280, 20, 32),
     "large-v3-turbo": ModelDimensions(128, 1500, 1280, 20, 32, 51866, 448, 1280, 20, 4),
 }

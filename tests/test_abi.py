@@ -72,10 +72,28 @@ def test_shipped_library_cannot_read_timing_switches():
     assert L.load().wft_version().decode() == "wft 0.1 gfx950"
 
 
-def test_launch_mode_setters_round_trip():
+def test_library_holds_no_mutable_launch_state():
+    """launch mode and kernel variants are per-call fields of the argument structs; no setter is exported."""
     handle = L.load()
-    for fn in (handle.wft_gemm_set_persistent, handle.wft_attn_set_persistent):
-        before = fn(-1)
-        assert fn(0) == before and fn(-1) == 0
-        assert fn(1) == 0 and fn(-1) == 1
-        fn(before)
+    for name in ("wft_gemm_set_persistent", "wft_attn_set_persistent", "wft_gemm_set_nt_variant", "wft_gemm_set_tn_variant",
+                 "wft_attn_set_dkdv_variant", "wft_attn_set_dq_variant", "wft_attn_set_fwd_variant"):
+        assert not hasattr(handle, name), name
+    for st in (L.GemmArgs, L.AttnArgs):
+        assert st.launch_mode.size == 4 and st.variant.size == 4
+    assert L.AttnArgs.q_prescaled.offset == L.AttnArgs.variant.offset + 4 == L.AttnArgs.launch_mode.offset + 8
+    assert L.AttnArgs.launch_mode.offset == L.AttnArgs.colsum_ws.offset + 8
+    assert L.GemmArgs.launch_mode.offset == L.GemmArgs.tn_seg_ptr.offset + 32 and L.GemmArgs.variant.offset == L.GemmArgs.launch_mode.offset + 4
+    # the dispatch queries read the per-call fields: the headline fc1 GEMM goes to the 4-wave kernel unless `variant` says otherwise
+    a = L.GemmArgs()
+    a.M, a.N, a.K, a.batch, a.lda, a.ldb, a.ldc, a.alpha = 130500, 5120, 1280, 1, 1280, 1280, 5120, 1.0
+    a.A = a.B = a.C = 1 << 20
+    assert handle.wft_gemm_nt_variant(ctypes.byref(a)) == 4
+    a.variant = 1
+    assert handle.wft_gemm_nt_variant(ctypes.byref(a)) == 256
+    b = L.AttnArgs()
+    b.B, b.H, b.Tq, b.Tk, b.causal, b.scale = 87, 20, 1500, 1500, 0, 0.125
+    b.ldq = b.ldk = b.ldv = 3840
+    b.lddo = 1280
+    assert [handle.wft_attn_variant(ctypes.byref(b), w) for w in (0, 1, 2)] == [2, 4, 4]
+    b.variant = 7
+    assert [handle.wft_attn_variant(ctypes.byref(b), w) for w in (0, 1, 2)] == [1, 8, 8]

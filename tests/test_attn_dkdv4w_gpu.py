@@ -21,9 +21,9 @@ DEV = "cuda:0"
 
 @pytest.fixture(autouse=True)
 def _restore_variant():
-    old = L.load().wft_attn_set_dkdv_variant(-1)
+    old = K.set_variant("dkdv", -1)
     yield
-    L.load().wft_attn_set_dkdv_variant(old)
+    K.set_variant("dkdv", old)
 
 
 def _ref_bwd(q, k, v, do, H, scale):
@@ -61,7 +61,7 @@ def test_dkdv4w_matches_the_8_wave_kernel_bit_for_bit_and_fp32_math(B, H, Tq, Tk
         o, lse = K.attn_fwd(q, k, v, H, False, 0.125)
         outs = []
         for var in (1, 0):
-            lib.wft_attn_set_dkdv_variant(var)
+            K.set_variant("dkdv", var)
             cs = (torch.full((D,), float("nan"), device=DEV), torch.full((D,), float("nan"), device=DEV))
             dk = torch.full((B, Tk, D), float("nan"), dtype=torch.bfloat16, device=DEV)
             dv = torch.full((B, Tk, D), float("nan"), dtype=torch.bfloat16, device=DEV)
@@ -85,7 +85,7 @@ def test_dkdv4w_dispatch_rules():
         o, lse = K.attn_fwd(q, k, v, 4, causal, 0.125)
         res = []
         for var in (1, 0):
-            lib.wft_attn_set_dkdv_variant(var)
+            K.set_variant("dkdv", var)
             res.append(K.attn_bwd(q, k, v, o, lse, do, 4, causal, 0.125))
         for a, b in zip(*res):
             assert torch.equal(a, b)
@@ -93,7 +93,7 @@ def test_dkdv4w_dispatch_rules():
 
 def test_dkdv4w_is_bitwise_reproducible_under_load():
     lib = L.load()
-    lib.wft_attn_set_dkdv_variant(0)
+    K.set_variant("dkdv", 0)
     g = torch.Generator(device=DEV).manual_seed(5)
     B, H, T = 4, 20, 1500
     D = H * 64

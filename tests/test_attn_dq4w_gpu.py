@@ -21,9 +21,9 @@ DEV = "cuda:0"
 
 @pytest.fixture(autouse=True)
 def _restore_variant():
-    old = L.load().wft_attn_set_dq_variant(-1)
+    old = K.set_variant("dq", -1)
     yield
-    L.load().wft_attn_set_dq_variant(old)
+    K.set_variant("dq", old)
 
 
 def _ref_dq(q, k, v, do, H, scale):
@@ -55,7 +55,7 @@ def test_dq4w_matches_the_8_wave_kernel_bit_for_bit_and_fp32_math(B, H, Tq, Tk):
         o, lse = K.attn_fwd(q, k, v, H, False, 0.125)
         outs = []
         for var in (1, 0):
-            lib.wft_attn_set_dq_variant(var)
+            K.set_variant("dq", var)
             cs = (torch.full((D,), float("nan"), device=DEV), torch.full((D,), float("nan"), device=DEV))
             dq = torch.full((B, Tq, D), float("nan"), dtype=torch.bfloat16, device=DEV)
             _, dk, dv = K.attn_bwd(q, k, v, o, lse, do, H, False, 0.125, dq=dq, colsums=cs)
@@ -77,7 +77,7 @@ def test_dq4w_dispatch_rules():
         o, lse = K.attn_fwd(q, k, v, 4, causal, 0.125)
         res = []
         for var in (1, 0):
-            lib.wft_attn_set_dq_variant(var)
+            K.set_variant("dq", var)
             res.append(K.attn_bwd(q, k, v, o, lse, do, 4, causal, 0.125))
         for a, b in zip(*res):
             assert torch.equal(a, b)
@@ -85,7 +85,7 @@ def test_dq4w_dispatch_rules():
 
 def test_dq4w_is_bitwise_reproducible_under_load():
     lib = L.load()
-    lib.wft_attn_set_dq_variant(0)
+    K.set_variant("dq", 0)
     g = torch.Generator(device=DEV).manual_seed(5)
     B, H, T = 4, 20, 1500
     D = H * 64

@@ -22,9 +22,9 @@ DEV = "cuda:0"
 
 @pytest.fixture(autouse=True)
 def _restore_variant():
-    old = L.load().wft_attn_set_fwd_variant(-1)
+    old = K.set_variant("fwd", -1)
     yield
-    L.load().wft_attn_set_fwd_variant(old)
+    K.set_variant("fwd", old)
 
 
 def _ref(q, k, v, H, scale):
@@ -51,7 +51,7 @@ def test_pipelined_forward_equals_the_unpipelined_kernel_bit_for_bit_and_fp32_ma
         k, v = kv[..., :D], kv[..., D:]
         outs = []
         for var in (1, 0):
-            lib.wft_attn_set_fwd_variant(var)
+            K.set_variant("fwd", var)
             o, lse = K.attn_fwd(q, k, v, H, False, 0.125)
             outs.append((o.clone(), lse.clone()))
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (rep, "pipelined != unpipelined")
@@ -70,6 +70,6 @@ def test_short_and_causal_calls_keep_the_unpipelined_kernel():
         q, k, v = qkv.chunk(3, dim=-1)
         res = []
         for var in (1, 0):
-            lib.wft_attn_set_fwd_variant(var)
+            K.set_variant("fwd", var)
             res.append(K.attn_fwd(q, k, v, H, causal, 0.125))
         assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])

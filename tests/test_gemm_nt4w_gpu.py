@@ -23,7 +23,7 @@ def bf(x):
 
 
 def _variant(v):
-    return L.load().wft_gemm_set_nt_variant(v)
+    return K.set_variant("nt", v)
 
 
 @pytest.fixture(autouse=True)
@@ -35,8 +35,8 @@ def _restore_variant():
 
 def _is_4w(a, b, **kw):
     """the dispatcher's own answer for these arguments under variant 0 (4 = gemm_nt4w_kernel)"""
+    _variant(0)  # (the variant is a field of the argument struct now: set before the arguments are built)
     args, _ = K.gemm_nt(a, b, _args_only=True, **{k: v for k, v in kw.items() if k != "colsum"})
-    _variant(0)
     return L.load().wft_gemm_nt_variant(__import__("ctypes").byref(args)) == 4
 
 

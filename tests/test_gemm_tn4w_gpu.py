@@ -23,7 +23,7 @@ def bf(x):
 
 
 def _variant(v):
-    return L.load().wft_gemm_set_tn_variant(v)
+    return K.set_variant("tn", v)
 
 
 @pytest.fixture(autouse=True)

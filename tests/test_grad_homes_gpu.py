@@ -16,7 +16,7 @@ DEV = torch.device("cuda:0")
 @pytest.mark.parametrize("R", [20000, 16500])         # two split-K plans; 16500: a ragged last reduction step
 def test_segmented_weight_gradient_equals_the_sliced_one_bit_for_bit(variant, R):
     lib = L.load()
-    old = lib.wft_gemm_set_tn_variant(variant)
+    old = K.set_variant("tn", variant)
     try:
         torch.manual_seed(R + variant)
         dy = torch.randn(R, 1536, device=DEV).bfloat16()
@@ -35,7 +35,7 @@ def test_segmented_weight_gradient_equals_the_sliced_one_bit_for_bit(variant, R)
         assert K.gemm_tn(dy, x, seg_out=segs, accumulate=True) is not None
         assert torch.equal(torch.cat(segs), want)
     finally:
-        lib.wft_gemm_set_tn_variant(old)
+        K.set_variant("tn", old)
 
 
 def test_unsegmentable_calls_are_refused_by_the_query_not_by_an_error():

@@ -75,40 +75,44 @@ def test_train_step_enters_no_sync_on_all_but_last_microbatch(monkeypatch):
 
 
 def test_train_step_switches_to_per_tile_launches_only_beside_the_gradient_exchange(monkeypatch):
-    """runtime.exchange_launch_mode: in a multi-process job the backward pass of the LAST micro-batch (the one whose gradients are
-    all-reduced while it runs) is launched per tile, everything else on the persistent grids; restored afterwards, also on errors."""
-    from whisper_finetune.engine import lib as L
+    """runtime.exchange_launch_mode: in a multi-process job the LAST micro-batch of an accumulation window (the one whose gradients are
+    all-reduced while its backward pass runs) is traced with `backward_launch_mode() == 1`, which the engine's autograd nodes note in
+    their forward and hand to their backward kernels per call; everything else keeps the persistent grids.  The mode is THREAD-LOCAL
+    (an evaluator on another thread is not affected) and nests / unwinds on errors; libwft itself holds no launch state."""
+    import threading
 
-    lib = L.load()
     seen = []
 
     class Spy(_TinyDDPModel):
         def forward(self, x, y_in):
-            seen.append(("fwd", lib.wft_gemm_set_persistent(-1), lib.wft_attn_set_persistent(-1)))
-            out = super().forward(x, y_in)
-            out.register_hook(lambda g: seen.append(("bwd", lib.wft_gemm_set_persistent(-1), lib.wft_attn_set_persistent(-1))))
-            return out
+            seen.append(rt.backward_launch_mode())
+            return super().forward(x, y_in)
 
-    assert lib.wft_gemm_set_persistent(-1) == 1 and lib.wft_attn_set_persistent(-1) == 1
+    assert rt.backward_launch_mode() == 0
     with rt.exchange_launch_mode(True):
-        assert lib.wft_gemm_set_persistent(-1) == 0 and lib.wft_attn_set_persistent(-1) == 0
+        assert rt.backward_launch_mode() == 1
+        other = []
+        t = threading.Thread(target=lambda: other.append(rt.backward_launch_mode()))
+        t.start(); t.join()
+        assert other == [0]  # another thread (an evaluator, a second model) keeps its own mode
+        with rt.exchange_launch_mode(False):
+            assert rt.backward_launch_mode() == 1
     with rt.exchange_launch_mode(False):
-        assert lib.wft_gemm_set_persistent(-1) == 1
+        assert rt.backward_launch_mode() == 0
     try:
         with rt.exchange_launch_mode(True):
             raise RuntimeError("x")
     except RuntimeError:
         pass
-    assert lib.wft_gemm_set_persistent(-1) == 1 and lib.wft_attn_set_persistent(-1) == 1
+    assert rt.backward_launch_mode() == 0
     # train_step: the mode is decided per micro-batch; on the CPU (this test) it never switches — the device check — so patch it
     monkeypatch.setattr(rt, "IS_DISTRIBUTED", True)
     real = rt.exchange_launch_mode
-    monkeypatch.setattr(rt, "exchange_launch_mode", lambda active: real(rt.IS_DISTRIBUTED and len([s for s in seen if s[0] == "fwd"]) == 4))
+    monkeypatch.setattr(rt, "exchange_launch_mode", lambda active: real(rt.IS_DISTRIBUTED and len(seen) == 3))
     m = Spy()
     model_utils.train_step(m, _batches(4), torch.optim.SGD(m.parameters(), lr=0.1), _Sched(), dict(T_CFG))
-    assert [s for s in seen if s[0] == "fwd"] == [("fwd", 1, 1)] * 4
-    assert [s for s in seen if s[0] == "bwd"] == [("bwd", 1, 1)] * 3 + [("bwd", 0, 0)]
-    assert lib.wft_gemm_set_persistent(-1) == 1 and lib.wft_attn_set_persistent(-1) == 1
+    assert seen == [0, 0, 0, 1]
+    assert rt.backward_launch_mode() == 0
 
 
 def test_train_step_no_sync_not_used_without_ddp(monkeypatch):

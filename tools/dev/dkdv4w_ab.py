@@ -37,7 +37,7 @@ for B, H, Tq, Tk in ((2, 8, 1500, 1500), (3, 6, 200, 1500), (1, 8, 128, 70), (2,
         o, lse = K.attn_fwd(q, k, v, H, False, 0.125)
         outs = []
         for var in (1, 0):
-            lib.wft_attn_set_dkdv_variant(var)
+            K.set_variant("dkdv", var)
             cs = (torch.empty(H * 64, device=dev), torch.empty(H * 64, device=dev))
             dq, dk, dv = K.attn_bwd(q, k, v, o, lse, do, H, False, 0.125, colsums=cs)
             torch.cuda.synchronize()
@@ -54,6 +54,6 @@ for B, H, Tq, Tk in ((32, 20, 1500, 1500), (64, 20, 128, 1500)):
     o, lse = K.attn_fwd(q, k, v, H, False, 0.125)
     for rnd in range(2):
         for var in (1, 0):
-            lib.wft_attn_set_dkdv_variant(var)
+            K.set_variant("dkdv", var)
             ms = t(lambda: K.attn_bwd(q, k, v, o, lse, do, H, False, 0.125))
             print(f"B{B} {Tq}x{Tk} variant {var}: bwd {ms:.3f} ms", flush=True)

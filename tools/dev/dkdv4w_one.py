@@ -31,7 +31,7 @@ for Tq in ((1500,) if os.environ.get('ONE') else (1500, 3000)):
     o, lse = K.attn_fwd(q, k, v, H, False, 0.125)
     cs = (torch.empty(H * 64, device=dev), torch.empty(H * 64, device=dev))
     for var in ((1, 0) if os.environ.get('ONE') else (1, 0, 1, 0)):
-        lib.wft_attn_set_dkdv_variant(var); lib.wft_attn_set_dq_variant(var); lib.wft_attn_set_fwd_variant(var)
+        K.set_variant("dkdv", var); K.set_variant("dq", var); K.set_variant("fwd", var)
         for _ in range(3):
             K.attn_fwd(q, k, v, H, False, 0.125)
         for _ in range(2 if os.environ.get('ONE') else 5):

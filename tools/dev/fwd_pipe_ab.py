@@ -7,7 +7,7 @@ from whisper_finetune.engine import kernels as K, lib as L
 dev = torch.device("cuda:0"); lib = L.load()
 torch.manual_seed(0)
 def run(v, q, k, vv, H, causal):
-    old = lib.wft_attn_set_fwd_variant(v)
+    old = K.set_variant("fwd", v)
     try:
         for _ in range(3): o, lse = K.attn_fwd(q, k, vv, H, causal, 0.125)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -18,7 +18,7 @@ def run(v, q, k, vv, H, causal):
             e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) / 5 * 1e3)
         return o, lse, min(ts)
     finally:
-        lib.wft_attn_set_fwd_variant(old)
+        K.set_variant("fwd", old)
 for B, H, Tq, Tk, causal in ((32, 20, 1500, 1500, False), (68, 20, 1500, 1500, False), (87, 20, 1500, 1500, False), (68, 20, 128, 128, True),
                              (68, 20, 128, 1500, False), (32, 20, 448, 448, True), (32, 20, 448, 1500, False), (3, 6, 50, 1500, False),
                              (2, 8, 77, 77, True), (2, 6, 1, 1, True), (4, 8, 1500, 1500, False), (1, 20, 200, 190, False)):

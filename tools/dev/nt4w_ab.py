@@ -9,7 +9,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[2] / "whisper-finetune_a
 from whisper_finetune.engine import kernels as K, lib as L
 dev = torch.device("cuda:0")
 lib = L.load()
-def variant(v): lib.wft_gemm_set_nt_variant(v)  # 0 = 4w where eligible, 1 = ping-pong
+def variant(v): K.set_variant("nt", v)  # 0 = 4w where eligible, 1 = ping-pong
 bf = lambda x: x.to(torch.bfloat16)
 
 def gelu(x): return torch.nn.functional.gelu(x)

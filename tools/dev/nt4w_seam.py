@@ -18,7 +18,7 @@ out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
 bias = torch.randn(N, device=dev); res = torch.randn(M, N, device=dev).to(torch.bfloat16)
 for ename, kw in (("plain", {}), ("bias", dict(bias=bias)), ("bias+res", dict(bias=bias, residual=res)), ("mul_aux", dict(epilogue=L.EPI_MUL_AUX, aux=res)), ("gelu_grad", dict(bias=bias, epilogue=L.EPI_GELU_GRAD, aux=res))):
     for v, name in ((1, "pp"), (0, "4w")):
-        lib.wft_gemm_set_nt_variant(v)
+        K.set_variant("nt", v)
         pts = []
         for Kd in (256, 512, 1280, 2560, 5120):
             a = torch.randn(M, Kd, device=dev).to(torch.bfloat16); b = (torch.randn(N, Kd, device=dev) * 0.03).to(torch.bfloat16)

@@ -6,7 +6,7 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parents[2] / "whisper-finetune_amd"))
 from whisper_finetune.engine import kernels as K, lib as L
 dev = torch.device("cuda:0"); lib = L.load()
-def variant(v): lib.wft_gemm_set_tn_variant(v)
+def variant(v): K.set_variant("tn", v)
 bf = lambda x: x.to(torch.bfloat16)
 
 def check():

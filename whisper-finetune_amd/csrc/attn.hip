@@ -25,6 +25,7 @@
 #define ATT_NEG (-1.0e30f)
 #define ATT_TAU 8.0f  // lazy-rescale threshold (log2 units)
 #define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
 
 struct AttnP {
   const unsigned short* q; long ldq, q_bs;
@@ -42,6 +43,13 @@ struct AttnP {
   float* cs_q;  // [B * ceil(Tq/32)][H*64] per-wave column sums of dq (or NULL)
   float* cs_v;  // [B * ceil(Tk/32)][H*64] per-wave column sums of dv (or NULL)
   int xcd;      // XCD-aware block placement on (WFT_ATTN_XCD=0 switches it off for A/B runs)
+  // q_prescaled (wft.h): q already carries scale * log2(e) (folded into the forward weight shadow of the q projection in fp32, one
+  // bf16 rounding), so the scores ARE the exponent of exp2 and no kernel multiplies them by c.  c: factor between the q.k
+  // accumulators and log2 units (1 when prescaled); ls: factor between them and natural-log units (lse = m * ls + log l; the
+  // row constant that enters the S chains of the backward kernels is -lse / ls; dK = dS^T q * ls).  dQ keeps `scale`: the kernels
+  // return the gradient w.r.t. the UNSCALED projection output, which is what the projection's backward GEMMs consume.
+  int qpre;
+  float c, ls;
 };
 
 __device__ __forceinline__ int att_F(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
@@ -301,8 +309,10 @@ extern "C" void wft_fwd_dbg_read(unsigned long long* host, int reset) {
 // (s_waitcnt vmcnt(0)) in front of the first ds_read_b64_tr of each tile, which cut the prefetch distance to
 // half a tile and left the kernel latency-bound (no-load experiment: +27 %).
 #if FWD_ABL == 9  // (occupancy experiment: three workgroups per CU = three waves per SIMD, <= 168 registers)
+template <bool PRE>
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnP p) {
 #else
+template <bool PRE>  // PRE: q_prescaled — c is the literal 1, the c-multiplies fold away
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
 #endif
   __shared__ __attribute__((aligned(16))) char smem[3 * 16384];  // [slot 3][K 8K | V 8K]
@@ -318,7 +328,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   const unsigned short* qrow = p.q + (long)b * p.q_bs + (long)qc * p.ldq + hd * 64;
   const unsigned short* kb = p.k + (long)b * p.k_bs + hd * 64;
   const unsigned short* vb = p.v + (long)b * p.v_bs + hd * 64;
-  const float c = p.scale * LOG2E;
+#if FWD_PRE_MODE == 1
+  const float c = p.c;
+#else
+  const float c = PRE ? 1.0f : p.c;
+#endif
   bf16x8 qf[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) qf[s] = att_load_reg_frag(qrow, s, h);
@@ -499,7 +513,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
                     pack2bf(oacc[db][4 * a + 2] * inv, oacc[db][4 * a + 3] * inv)};
         *(u32x2*)(orow + d) = pk;
       }
-    if (h == 0 && p.lse) p.lse[((long)b * p.H + hd) * p.Tq + qi] = m * p.scale + __logf(l);
+    if (h == 0 && p.lse) p.lse[((long)b * p.H + hd) * p.Tq + qi] = m * p.ls + __logf(l);
   }
 #ifdef FWD_STAMPS
   if (lane == 0 && qw0 < p.Tq) {
@@ -524,6 +538,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
 //                 K(kt+2) fragment reads | P.V(kt) MFMAs
 // Same arithmetic in the same order as attn_fwd_kernel (the stale maximum that enters S(kt+1) as its initial accumulator is the
 // one softmax(kt) has just settled, exactly what the un-pipelined kernel uses at the head of tile kt+1): bit-identical results.
+template <bool PRE>
 __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(AttnP p) {
   __shared__ __attribute__((aligned(16))) char smem[4 * 16384];  // [slot 4][K 8K | V 8K]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -538,7 +553,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(AttnP p) {
   const unsigned short* qrow = p.q + (long)b * p.q_bs + (long)qc * p.ldq + hd * 64;
   const unsigned short* kb = p.k + (long)b * p.k_bs + hd * 64;
   const unsigned short* vb = p.v + (long)b * p.v_bs + hd * 64;
-  const float c = p.scale * LOG2E;
+#if FWD_PRE_MODE == 1
+  const float c = p.c;
+#else
+  const float c = PRE ? 1.0f : p.c;
+#endif
   bf16x8 qf[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) qf[s] = att_load_reg_frag(qrow, s, h);
@@ -644,7 +663,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(AttnP p) {
       for (int kb2 = 0; kb2 < 2; ++kb2)
 #pragma unroll
         for (int e = 0; e < 16; e += 2) {
-          const f32x2 sc = f32x2{sacc[kb2][e], sacc[kb2][e + 1]} * c;  // (one v_pk_mul_f32 per pair: hipcc leaves the scalar form unpacked)
+          f32x2 sc = f32x2{sacc[kb2][e], sacc[kb2][e + 1]};
+          if constexpr (!PRE) sc = sc * c;  // (one v_pk_mul_f32 per pair: hipcc leaves the scalar form unpacked)
           const float p0 = __builtin_amdgcn_exp2f(sc[0]);
           const float p1 = __builtin_amdgcn_exp2f(sc[1]);
           ls0 += p0;
@@ -707,7 +727,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(AttnP p) {
                     pack2bf(oacc[db][4 * a + 2] * inv, oacc[db][4 * a + 3] * inv)};
         *(u32x2*)(orow + d) = pk;
       }
-    if (h == 0 && p.lse) p.lse[((long)b * p.H + hd) * p.Tq + qi] = m * p.scale + __logf(l);
+    if (h == 0 && p.lse) p.lse[((long)b * p.H + hd) * p.Tq + qi] = m * p.ls + __logf(l);
   }
 }
 
@@ -745,7 +765,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
   const AttStage stK = att_stage_init(p.ldk, wave, lane), stV = att_stage_init(p.ldv, wave, lane);
   const long sidx = ((long)b * p.H + hd) * p.Tq + qc;
   // row constants of this lane's query, negated: the initial accumulators of the S and dP chains
-  const float nlse = -p.lse[sidx] / p.scale;
+  const float nlse = -p.lse[sidx] / p.ls;
   float ndlt;
   {
     const unsigned short* orow = p.o + (long)b * p.o_bs + (long)qc * p.ldo + hd * 64;
@@ -772,7 +792,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
     const int last = (q0 + 127) / 64 + 1;
     nkt = nkt < last ? nkt : last;
   }
-  const float c = p.scale * LOG2E;
+  const float c = p.c;
   const f32x16 zero16 = f32x16{0};
   f32x16 dqacc[2];
   dqacc[0] = zero16;
@@ -920,7 +940,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) rowa[cb][s] = lds0 + cb * DKDV_BUF + offs.row[s];
   const unsigned rca = lds0 + 16 * h;  // this lane's first row constant: query 4 h of a 32-query half (+ buffer, + 32 a via immediates)
-  const float c = p.scale * LOG2E;
+  const float c = p.c;
   const f32x2 c2 = {c, c};
   const int nqt = (p.Tq + DKDV_Q - 1) / DKDV_Q;
   const int qt0 = p.causal ? (k0 / DKDV_Q) : 0;  // first query tile that can see key k0
@@ -1064,8 +1084,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
         const int d = 32 * db + 8 * a + 4 * h;
-        u32x2 pk = {pack2bf(dkacc[db][4 * a] * p.scale, dkacc[db][4 * a + 1] * p.scale),
-                    pack2bf(dkacc[db][4 * a + 2] * p.scale, dkacc[db][4 * a + 3] * p.scale)};
+        u32x2 pk = {pack2bf(dkacc[db][4 * a] * p.ls, dkacc[db][4 * a + 1] * p.ls),
+                    pack2bf(dkacc[db][4 * a + 2] * p.ls, dkacc[db][4 * a + 3] * p.ls)};
         *(u32x2*)(dkrow + d) = pk;
         u32x2 pv = {pack2bf(dvacc[db][4 * a], dvacc[db][4 * a + 1]),
                     pack2bf(dvacc[db][4 * a + 2], dvacc[db][4 * a + 3])};
@@ -1108,6 +1128,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
 
 #ifndef D4_EXP
 #define D4_EXP 0  // developer timing experiments (results wrong): 1 no LDS-DMA in the loop, 2 no vector arithmetic, 3 no LDS reads, 4 no barrier
+#endif
+#ifndef FWD_PRE_MODE
+#define FWD_PRE_MODE 0  // (experiment) 1: the forward kernels keep c as a run-time value (1.0 when prescaled); only the per-score multiply is dropped
 #endif
 #define D4_ASM_MACROS ".set d4_exp, " D4_STR(D4_EXP) "\n" R"ASM(
 .macro D4_VALU ops:vararg
@@ -1247,7 +1270,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
     .endif
     .if d4_s < 16
       D4_M2 d4_s
+      .if att_pre == 0
       D4_VALU v_mul_f32 v[\gV+32+d4_s], %[c], v[\gV+32+d4_s]
+      .endif
       D4_EXPF v[\gV+d4_s], v[\gV+d4_s]
       D4_RD1 d4_s, \rb1, \cb1, \qb1
       D4_EXPF v[\gV+32+d4_s], v[\gV+32+d4_s]
@@ -1271,8 +1296,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
         D4_VALU v_cvt_pk_bf16_f32 v[40+(d4_s-24)], v[\gV+16+2*(d4_s-24)], v[\gV+16+2*(d4_s-24)+1]
         D4_RD2 d4_s-16, \tb2, \qb2
         D4_VALU v_cvt_pk_bf16_f32 v[56+(d4_s-24)], v[\gV+48+2*(d4_s-24)], v[\gV+48+2*(d4_s-24)+1]
+        .if att_pre == 0
         D4_VALU v_mul_f32 v[\gM+2*(d4_s-24)], %[c], v[\gM+2*(d4_s-24)]
         D4_VALU v_mul_f32 v[\gM+2*(d4_s-24)+1], %[c], v[\gM+2*(d4_s-24)+1]
+        .endif
       .endif
     .endif
     .set d4_s, d4_s+1
@@ -1426,6 +1453,7 @@ extern "C" void wft_dbg_read(unsigned long long* host, int reset) {
 .purgem D4_STAGE2
 )ASM"
 
+template <bool PRE>  // PRE: q_prescaled — the asm loops are assembled without their c-scale multiplies (.set att_pre)
 __global__ __launch_bounds__(256) void attn_bwd_dkdv4w_kernel(AttnP p) {
 #ifdef D4_STAMPS
   unsigned long long st0 = __builtin_amdgcn_s_memtime();
@@ -1467,7 +1495,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv4w_kernel(AttnP p) {
   const unsigned ldk2 = __builtin_amdgcn_readfirstlane((unsigned)p.ldk * 2u), ldv2 = __builtin_amdgcn_readfirstlane((unsigned)p.ldv * 2u);
   const unsigned stQ = __builtin_amdgcn_readfirstlane((unsigned)p.ldq * 128u), stD = __builtin_amdgcn_readfirstlane((unsigned)p.lddo * 128u);
   const unsigned npair = __builtin_amdgcn_readfirstlane((unsigned)((p.Tq + 63) >> 6));  // 64-query tiles = iteration pairs
-  const float cscale = p.scale * LOG2E;
+  const float cscale = p.c;
   const unsigned cbits = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, cscale));
   const unsigned wv = (unsigned)wave;
   // everything that depends on the work item
@@ -1501,7 +1529,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv4w_kernel(AttnP p) {
   const int b = cur.b, hd = cur.hd, kw0 = cur.kw0;
   const unsigned first = __builtin_amdgcn_readfirstlane((unsigned)(t == w0));
 
-  asm volatile(D4_ASM_MACROS D4_ASM_MACROS2 R"ASM(
+  asm volatile(".set att_pre, %c[pre]\n" D4_ASM_MACROS D4_ASM_MACROS2 R"ASM(
     D4_SRD_INIT
     s_mov_b32 s66, %[npair]      ; loop counter
     s_cmp_eq_u32 %[first], 0
@@ -1552,10 +1580,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv4w_kernel(AttnP p) {
     s_nop 15
     s_nop 15
     .set d4_i, 0
+    .if att_pre == 0
     .rept 16
       v_mul_f32 v[128+d4_i], %[c], v[128+d4_i]
       .set d4_i, d4_i+1
     .endr
+    .endif
 1:
     ; ==== tile boundary: tile T+1 has landed for every wave, tile T-1's buffer is free -> tile T+2 goes into it during this
     ; iteration (a fourth buffer and three tiles of distance measured the same; the space carries the K / V transit areas)
@@ -1597,7 +1627,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv4w_kernel(AttnP p) {
                  [voC] "v"(voC), [voKp] "v"(cur.voKp), [voVp] "v"(cur.voVp), [bK] "s"(cur.bK),
                  [bV] "s"(cur.bV), [bQ] "s"(cur.bQ), [bD] "s"(cur.bD), [bL] "s"(cur.bL), [bT] "s"(cur.bT), [tq] "s"(tq), [tk] "s"(tk),
                  [ldk2] "s"(ldk2), [ldv2] "s"(ldv2), [first] "s"(first), [stQ] "s"(stQ), [stD] "s"(stD), [npair] "s"(npair), [c] "s"(cbits),
-                 [lds0] "s"(lds0), [wave] "s"(wv)
+                 [lds0] "s"(lds0), [wave] "s"(wv), [pre] "n"(PRE ? 1 : 0)
                : "memory", "vcc", "scc", D4_CLOBBER_A, D4_CLOBBER_V, D4_CLOBBER_S);
 
 #ifdef D4_STAMPS
@@ -1607,7 +1637,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv4w_kernel(AttnP p) {
     // ---- prefetch block: once every wave has left the LDS buffers, request the NEXT item's K / V rows (transit area) and
     // first two tiles; they fly while the accumulators of this item are scaled, summed and stored below
     const Item nx = item(t + wstep);
-    asm volatile(D4_ASM_MACROS D4_ASM_MACROS2 R"ASM(
+    asm volatile(".set att_pre, 0\n" D4_ASM_MACROS D4_ASM_MACROS2 R"ASM(
       s_barrier
       D4_SRD_INIT
       D4_KVDMA
@@ -1646,7 +1676,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv4w_kernel(AttnP p) {
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
         const int d = 32 * db + 8 * (2 * m + h);
-        const u32x4 pk = row16(dk[db], m, p.scale), pv = row16(dv[db], m, 1.0f);  // (every lane takes part in the swaps)
+        const u32x4 pk = row16(dk[db], m, p.ls), pv = row16(dv[db], m, 1.0f);  // (every lane takes part in the swaps)
         if (ki < p.Tk) {
           *(u32x4*)(dkrow + d) = pk;
           *(u32x4*)(dvrow + d) = pv;
@@ -1703,6 +1733,9 @@ static int attn_fill(const wft_attn_args* a, AttnP& p) {
   p.lse = a->lse;
   p.B = a->B; p.H = a->H; p.Tq = a->Tq; p.Tk = a->Tk; p.causal = a->causal;
   p.scale = a->scale;
+  p.qpre = a->q_prescaled ? 1 : 0;
+  p.c = p.qpre ? 1.0f : a->scale * LOG2E;
+  p.ls = p.qpre ? LN2 : a->scale;
   p.d_o = a->d_o; p.lddo = a->lddo; p.do_bs = a->do_bs;
   p.delta = a->delta;
   p.dq = a->dq; p.lddq = a->lddq; p.dq_bs = a->dq_bs;
@@ -1820,7 +1853,9 @@ static int attn_fill(const wft_attn_args* a, AttnP& p) {
         v_cndmask_b32 v[\gV+q4_s], v31, v[\gV+q4_s], vcc
       .endif
       v_exp_f32 v[\gV+q4_s], v[\gV+q4_s]
+      .if att_pre == 0
       v_mul_f32 v[\gV+32+q4_s], %[c], v[\gV+32+q4_s]
+      .endif
       .if q4_s < 8
         Q4_RD1 q4_s, \rb1, \hf1
       .endif
@@ -1850,8 +1885,10 @@ static int attn_fill(const wft_attn_args* a, AttnP& p) {
         Q4_RD2 q4_s-12, \tb2, \hf2
       .endif
       v_cvt_pk_bf16_f32 v[32+(q4_s-16)], v[\gV+16+2*(q4_s-16)], v[\gV+16+2*(q4_s-16)+1]
+      .if att_pre == 0
       v_mul_f32 v[\gM+2*(q4_s-16)], %[c], v[\gM+2*(q4_s-16)]
       v_mul_f32 v[\gM+2*(q4_s-16)+1], %[c], v[\gM+2*(q4_s-16)+1]
+      .endif
       v_cvt_pk_bf16_f32 v[40+(q4_s-16)], v[\gV+48+2*(q4_s-16)], v[\gV+48+2*(q4_s-16)+1]
     .endif
     .set q4_s, q4_s+1
@@ -1887,6 +1924,7 @@ static int attn_fill(const wft_attn_args* a, AttnP& p) {
 // a0..a159
 #define Q4_CLOBBER_A "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", D4_A8(1), D4_A8(2), D4_A8(3), D4_A8(4), D4_A8(5), D4_A8(6), D4_A8(7), D4_A8(8), D4_A8(9), D4_A8(10), D4_A8(11), D4_A8(12), D4_A8(13), D4_A8(14), D4_A8(15)
 
+template <bool PRE>
 __global__ __launch_bounds__(256) void attn_bwd_dq4w_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1921,7 +1959,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq4w_kernel(AttnP p) {
     const int qi = qw0 + 32 * qb + r;
     const int qc = qi < p.Tq ? qi : p.Tq - 1;
     const long sidx = ((long)b * p.H + hd) * p.Tq + qc;
-    nl[qb] = -p.lse[sidx] / p.scale;
+    nl[qb] = -p.lse[sidx] / p.ls;
     const unsigned short* orow = p.o + (long)b * p.o_bs + (long)qc * p.ldo + hd * 64;
     const unsigned short* dorow = p.d_o + (long)b * p.do_bs + (long)qc * p.lddo + hd * 64;
     float part = 0.f;
@@ -1950,11 +1988,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq4w_kernel(AttnP p) {
   const unsigned stK = __builtin_amdgcn_readfirstlane((unsigned)p.ldk * 128u), stV = __builtin_amdgcn_readfirstlane((unsigned)p.ldv * 128u);
   const unsigned npair = __builtin_amdgcn_readfirstlane((unsigned)((p.Tk + 63) >> 6));  // 64-key tiles
   const int lim0 = p.Tk - 64 * ((p.Tk + 63) / 64 - 1) - 4 * h;  // keys left from the first key of the LAST tile, minus 4 h
-  const float cscale = p.scale * LOG2E;
+  const float cscale = p.c;
   const unsigned cbits = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, cscale));
   const unsigned wv = (unsigned)wave;
 
-  asm volatile(Q4_ASM_MACROS R"ASM(
+  asm volatile(".set att_pre, %c[pre]\n" Q4_ASM_MACROS R"ASM(
     ; ---- descriptors: K s[40:43], V s[44:47] (tile strides s56, s57), Q s[68:71], dO s[72:75]
     s_mov_b64 s[40:41], %[bK]
     s_lshr_b32 s61, %[stK], 6
@@ -2066,10 +2104,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq4w_kernel(AttnP p) {
     s_nop 15
     s_nop 15
     .set q4_i, 0
+    .if att_pre == 0
     .rept 16
       v_mul_f32 v[128+q4_i], %[c], v[128+q4_i]
       .set q4_i, q4_i+1
     .endr
+    .endif
     s_cmp_eq_u32 s66, 0
     s_cbranch_scc1 5f
 1:
@@ -2095,7 +2135,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq4w_kernel(AttnP p) {
                : [rb] "v"(rb), [tb] "v"(tb), [voK0] "v"(voK0), [voK1] "v"(voK1), [voV0] "v"(voV0), [voV1] "v"(voV1), [voQ] "v"(voQ),
                  [voD] "v"(voD), [nl0] "v"(nl[0]), [nl1] "v"(nl[1]), [nd0] "v"(nd[0]), [nd1] "v"(nd[1]), [lim0] "v"(lim0), [bK] "s"(bK),
                  [bV] "s"(bV), [bQ] "s"(bQ), [bD] "s"(bD), [tq] "s"(tq), [tk] "s"(tk), [ldq2] "s"(ldq2), [ldd2] "s"(ldd2), [stK] "s"(stK),
-                 [stV] "s"(stV), [npair] "s"(npair), [c] "s"(cbits), [lds0] "s"(lds0), [wave] "s"(wv)
+                 [stV] "s"(stV), [npair] "s"(npair), [c] "s"(cbits), [lds0] "s"(lds0), [wave] "s"(wv), [pre] "n"(PRE ? 1 : 0)
                : "memory", "vcc", "scc", Q4_CLOBBER_A, D4_CLOBBER_V, "v30", "v31", D4_CLOBBER_S);
 
   // ---- epilogue: lane (r, h) holds dQ [query qw0 + 32 qb + r][d = 32 db + 8 a + 4 h + e] in register 4 a + e of (qb, db)
@@ -2149,14 +2189,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq4w_kernel(AttnP p) {
 // four-slot ring's longer prologue costs 2-5 % there); 1 = attn_fwd_kernel everywhere.  Bit-identical results either way.
 // (Round 4's one-wave-per-SIMD forward kernel measured equal to attn_fwd_kernel and was removed in round 5.)
 static int g_fwd_variant = [] { const char* e = wft_dev_getenv("WFT_FWD_VARIANT"); return (e && !strcmp(e, "8w")) ? 1 : 0; }();
-extern "C" int wft_attn_set_fwd_variant(int v) {
-  const int old = g_fwd_variant;
-  if (v >= 0) g_fwd_variant = v ? 1 : 0;
-  return old;
-}
 static bool wft_fwd_pipe_eligible(const wft_attn_args* a) {
   static const int min_tk = [] { const char* e = wft_dev_getenv("WFT_FWDPIPE_MIN_TK"); return e ? atoi(e) : 512; }();
-  return g_fwd_variant == 0 && !a->causal && a->Tk >= min_tk;
+  return g_fwd_variant == 0 && !(a->variant & 1) && !a->causal && a->Tk >= min_tk;
 }
 
 extern "C" int wft_attn_fwd_bf16(const wft_attn_args* a, void* stream) {
@@ -2169,8 +2204,13 @@ extern "C" int wft_attn_fwd_bf16(const wft_attn_args* a, void* stream) {
   AttnP p;
   attn_fill(a, p);
   dim3 grid((unsigned)(((a->Tq + 127) / 128) * a->H * a->B)), block(256);  // 1-D: see att_block_coords
-  if (wft_fwd_pipe_eligible(a)) hipLaunchKernelGGL(attn_fwd_pipe_kernel, grid, block, 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(attn_fwd_kernel, grid, block, 0, (hipStream_t)stream, p);
+  if (wft_fwd_pipe_eligible(a)) {
+    if (p.qpre) hipLaunchKernelGGL(attn_fwd_pipe_kernel<true>, grid, block, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(attn_fwd_pipe_kernel<false>, grid, block, 0, (hipStream_t)stream, p);
+  } else {
+    if (p.qpre) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, p);
+  }
   WFT_CHECK_LAUNCH();
   return WFT_OK;
 }
@@ -2208,35 +2248,35 @@ extern "C" int64_t wft_attn_bwd_colsum_workspace_bytes(const wft_attn_args* a) {
 // persistent dK/dV launches (one workgroup per CU) or one item per workgroup: WFT_ATTN_PERSISTENT=0 at load time (engine/lib.py sets it
 // in a multi-GPU job), wft_attn_set_persistent() inside a process (bench.py's ddp_mode_1gpu block)
 static int g_attn_persistent = [] { const char* e = getenv("WFT_ATTN_PERSISTENT"); return (e && e[0] == '0') ? 0 : 1; }();
-extern "C" int wft_attn_set_persistent(int v) { const int o = g_attn_persistent; if (v >= 0) g_attn_persistent = v ? 1 : 0; return o; }
 static int g_dkdv_variant = [] { const char* e = wft_dev_getenv("WFT_DKDV_VARIANT"); return (e && !strcmp(e, "8w")) ? 1 : 0; }();
-extern "C" int wft_attn_set_dkdv_variant(int v) {
-  const int old = g_dkdv_variant;
-  if (v >= 0) g_dkdv_variant = v ? 1 : 0;
-  return old;
-}
 // the same for the dQ kernel (attn_bwd_dq4w_kernel): WFT_DQ_VARIANT=8w|4w
 static int g_dq_variant = [] { const char* e = wft_dev_getenv("WFT_DQ_VARIANT"); return (e && !strcmp(e, "8w")) ? 1 : 0; }();
-extern "C" int wft_attn_set_dq_variant(int v) {
-  const int old = g_dq_variant;
-  if (v >= 0) g_dq_variant = v ? 1 : 0;
-  return old;
-}
 // non-causal calls with enough queries to fill 256-query workgroups; byte offsets must fit the asm block's 32-bit buffer addressing
 static bool wft_dq4w_eligible(const wft_attn_args* a) {
   static const int min_tq = [] { const char* e = wft_dev_getenv("WFT_DQ4W_MIN_TQ"); return e ? atoi(e) : 512; }();
-  if (g_dq_variant != 0 || a->causal || a->Tq < min_tq) return false;
+  if (g_dq_variant != 0 || (a->variant & 2) || a->causal || a->Tq < min_tq) return false;
   const long lim = 0x7fffffffL;
   return (long)(a->Tq + 256) * a->ldq * 2 < lim && (long)(a->Tq + 256) * a->lddo * 2 < lim && (long)(a->Tk + 256) * a->ldk * 2 < lim &&
          (long)(a->Tk + 256) * a->ldv * 2 < lim;
 }
 // non-causal sweeps over at least two 64-query tiles whose byte offsets fit the 32-bit buffer addressing of the asm block
 static bool wft_dkdv4w_eligible(const wft_attn_args* a) {
-  if (g_dkdv_variant != 0 || a->causal || a->Tq < 128) return false;
+  if (g_dkdv_variant != 0 || (a->variant & 4) || a->causal || a->Tq < 128) return false;
   const long lim = 0x7fffffffL;
   // (+ 256: the last workgroup's lanes address rows up to 255 past the end; the descriptors return zeros for them)
   return (long)(a->Tq + 256) * a->ldq * 2 < lim && (long)(a->Tq + 256) * a->lddo * 2 < lim && (long)(a->Tk + 256) * a->ldk * 2 < lim &&
          (long)(a->Tk + 256) * a->ldv * 2 < lim;
+}
+
+// Which kernel serves these arguments (pure host function; bench.py / tests attribute timings and assert the dispatch):
+// which = 0 forward: 2 attn_fwd_pipe_kernel, 1 attn_fwd_kernel; 1 dQ: 4 attn_bwd_dq4w_kernel, 8 attn_bwd_dq_kernel;
+// 2 dK/dV: 4 attn_bwd_dkdv4w_kernel, 8 attn_bwd_dkdv_kernel
+extern "C" int wft_attn_variant(const wft_attn_args* a, int which) {
+  if (!a) return WFT_ERR_ARG;
+  if (which == 0) return wft_fwd_pipe_eligible(a) ? 2 : 1;
+  if (which == 1) return wft_dq4w_eligible(a) ? 4 : 8;
+  if (which == 2) return wft_dkdv4w_eligible(a) ? 4 : 8;
+  return WFT_ERR_ARG;
 }
 
 extern "C" int wft_attn_bwd_bf16(const wft_attn_args* a, void* stream) {
@@ -2264,14 +2304,17 @@ extern "C" int wft_attn_bwd_bf16(const wft_attn_args* a, void* stream) {
     int devq = 0;
     if (hipGetDevice(&devq) != hipSuccess || devq < 0 || devq >= 64) devq = 0;
     if (!ldsq_set[devq]) {
-      const hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dq4w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Q4_LDS);
+      hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dq4w_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, Q4_LDS);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_dq4w_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, Q4_LDS);
       if (e != hipSuccess) {
         wft_set_error("wft_attn_bwd_bf16: the dQ kernel needs %d bytes of dynamic LDS, hipFuncSetAttribute: %s", Q4_LDS, hipGetErrorString(e));
         return WFT_ERR_LAUNCH;
       }
       ldsq_set[devq] = true;
     }
-    hipLaunchKernelGGL(attn_bwd_dq4w_kernel, dim3((unsigned)(((a->Tq + 255) / 256) * a->H * a->B)), dim3(256), Q4_LDS, s, p);
+    const dim3 gq((unsigned)(((a->Tq + 255) / 256) * a->H * a->B));
+    if (p.qpre) hipLaunchKernelGGL(attn_bwd_dq4w_kernel<true>, gq, dim3(256), Q4_LDS, s, p);
+    else hipLaunchKernelGGL(attn_bwd_dq4w_kernel<false>, gq, dim3(256), Q4_LDS, s, p);
   } else {
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(((a->Tq + 127) / 128) * a->H * a->B)), dim3(256), 0, s, p);
   }
@@ -2292,7 +2335,8 @@ extern "C" int wft_attn_bwd_bf16(const wft_attn_args* a, void* stream) {
   if (wft_dkdv4w_eligible(a)) {
     static bool lds4_set[64] = {false};
     if (!lds4_set[dev]) {
-      const hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dkdv4w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, D4_LDS);
+      hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dkdv4w_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, D4_LDS);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_dkdv4w_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, D4_LDS);
       if (e != hipSuccess) {
         wft_set_error("wft_attn_bwd_bf16: the dK/dV kernel needs %d bytes of dynamic LDS, hipFuncSetAttribute: %s", D4_LDS, hipGetErrorString(e));
         return WFT_ERR_LAUNCH;
@@ -2304,12 +2348,13 @@ extern "C" int wft_attn_bwd_bf16(const wft_attn_args* a, void* stream) {
     // collective kernels hold CUs during the backward pass, and a static walk would leave those CUs' share of the items for a
     // second round; the hardware dispatcher balances single-item workgroups (measured equal on one GPU: 732 vs 735 us)
     static const int wgs_env = [] { const char* e = wft_dev_getenv("WFT_DKDV_WGS"); return e ? atoi(e) : 0; }();
-    const bool persistent = g_attn_persistent != 0;
+    const bool persistent = g_attn_persistent != 0 && a->launch_mode != 1;
     const long items = (long)((a->Tk + 255) / 256) * a->H * a->B;
     long wgs = wgs_env > 0 ? wgs_env : (persistent ? wft_num_cus() : items);
     if (wgs > items) wgs = items;
     if (((long)a->H * a->B) % 8 == 0 && wgs >= 8) wgs -= wgs % 8;  // XCD mode needs the same number of workgroups on every XCD
-    hipLaunchKernelGGL(attn_bwd_dkdv4w_kernel, dim3((unsigned)wgs), dim3(256), D4_LDS, s, p);
+    if (p.qpre) hipLaunchKernelGGL(attn_bwd_dkdv4w_kernel<true>, dim3((unsigned)wgs), dim3(256), D4_LDS, s, p);
+    else hipLaunchKernelGGL(attn_bwd_dkdv4w_kernel<false>, dim3((unsigned)wgs), dim3(256), D4_LDS, s, p);
   } else {
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3((unsigned)(((a->Tk + 127) / 128) * a->H * a->B)), dim3(256), 2 * DKDV_BUF, s, p);
   }

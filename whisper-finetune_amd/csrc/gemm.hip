@@ -1441,7 +1441,7 @@ static int g_nt256_min_tiles = 128, g_tn256_min_steps = 64, g_tn256_min_out_tile
 static bool g_nt256_persistent = true;
 static int g_nt256_band = 5;
 // which 256x256 NT kernel: 0 = the one-wave-per-SIMD kernel where it applies (gemm_nt4w.hip), 1 = always the ping-pong kernel.
-// WFT_NT_VARIANT=pp|4w at load time; wft_gemm_set_nt_variant() for A/B runs inside one process.
+// WFT_NT_VARIANT=pp|4w at load time (timing builds); per call: wft_gemm_args.variant.
 static int g_nt_variant = 0;
 bool wft_nt4w_eligible(const wft_gemm_args* a);
 // the one-wave-per-SIMD weight-gradient kernel (gemm_tn4w.hip): WFT_TN_VARIANT=pp keeps gemm_tn256_kernel
@@ -1449,14 +1449,14 @@ static int g_tn_variant = 0;
 bool wft_tn4w_eligible(const wft_gemm_args* a);
 void wft_tn4w_plan(const wft_gemm_args* a, int* nsplit_out, int* per_out);
 int wft_tn4w_launch(const wft_gemm_args* a, GemmP p, int nsplit, int per, void* stream);
-extern "C" int wft_gemm_set_tn_variant(int v) { const int o = g_tn_variant; if (v >= 0) g_tn_variant = v; return o; }
+
 int wft_nt4w_launch(const wft_gemm_args* a, const GemmP& p, bool persistent, void* stream);
-extern "C" int wft_gemm_set_persistent(int v);
-extern "C" int wft_gemm_set_nt_variant(int v) { const int o = g_nt_variant; if (v >= 0) g_nt_variant = v; return o; }
+
+
 static bool g_force_128 = false;  // debugging / A-B switch: WFT_GEMM_FORCE_128=1
 static struct EnvInit { EnvInit() { const char* e = wft_dev_getenv("WFT_GEMM_FORCE_128"); g_force_128 = e && e[0] == '1'; const char* d = wft_dev_getenv("WFT_GEMM_DIAG"); g_diag = d ? atoi(d) : 0; const char* t1 = wft_dev_getenv("WFT_NT256_MIN_TILES"); if (t1) g_nt256_min_tiles = atoi(t1); const char* t2 = wft_dev_getenv("WFT_TN256_MIN_STEPS"); if (t2) g_tn256_min_steps = atoi(t2); const char* t3 = wft_dev_getenv("WFT_TN256_MIN_OUT_TILES"); if (t3) g_tn256_min_out_tiles = atoi(t3); const char* pe = getenv("WFT_NT256_PERSISTENT"); if (pe) g_nt256_persistent = pe[0] != '0'; const char* bw = wft_dev_getenv("WFT_NT256_BAND"); if (bw && atoi(bw) > 0) g_nt256_band = atoi(bw); const char* nv = wft_dev_getenv("WFT_NT_VARIANT"); if (nv) g_nt_variant = (nv[0] == 'p') ? 1 : 0; const char* tv = wft_dev_getenv("WFT_TN_VARIANT"); if (tv) g_tn_variant = (tv[0] == 'p') ? 1 : 0; } } g_env_init;
 
-extern "C" int wft_gemm_set_persistent(int v) { const int o = g_nt256_persistent ? 1 : 0; if (v >= 0) g_nt256_persistent = v != 0; return o; }
+
 
 static int fill_params(const wft_gemm_args* a, GemmP& p) {
   p.A = a->A; p.lda = a->lda; p.sA = a->strideA;
@@ -1507,7 +1507,7 @@ static bool nt_uses_256(const wft_gemm_args* a) {
 }
 extern "C" int wft_gemm_nt_variant(const wft_gemm_args* a) {
   if (!a || !nt_uses_256(a)) return 128;
-  return (g_nt_variant != 1 && wft_nt4w_eligible(a)) ? 4 : 256;
+  return (g_nt_variant != 1 && a->variant == 0 && wft_nt4w_eligible(a)) ? 4 : 256;
 }
 
 extern "C" int64_t wft_gemm_nt_colsum_workspace_bytes(const wft_gemm_args* a) {
@@ -1541,8 +1541,11 @@ extern "C" int wft_gemm_nt_bf16(const wft_gemm_args* a, void* stream) {
     WFT_CHECK_ARG(!a->c_is_f32 && a->batch == 1, "colsum needs a bf16 C and batch == 1");
     if (cs_fused) p.cs_part = (float*)a->workspace;
   }
-  if (big && g_nt_variant != 1 && wft_nt4w_eligible(a)) {
-    const int rc = wft_nt4w_launch(a, p, g_nt256_persistent, stream);
+  // launch state is per call (wft_gemm_args.launch_mode / variant); the process-wide start values come from the environment at load
+  // time only (WFT_NT256_PERSISTENT; the variant variables in timing builds) and never change afterwards
+  const bool persistent = g_nt256_persistent && a->launch_mode != 1;
+  if (big && g_nt_variant != 1 && a->variant == 0 && wft_nt4w_eligible(a)) {
+    const int rc = wft_nt4w_launch(a, p, persistent, stream);
     if (rc != WFT_OK) return rc;
     if (cs_fused)
       hipLaunchKernelGGL(nt_colsum_reduce_kernel, dim3((unsigned)((a->N + 63) / 64)), dim3(256), 0, s, (const float*)a->workspace,
@@ -1557,7 +1560,7 @@ extern "C" int wft_gemm_nt_bf16(const wft_gemm_args* a, void* stream) {
     // persistent (one workgroup per CU walks the tiles, prefetching across tile seams) unless WFT_NT256_PERSISTENT=0: with
     // collectives running beside the GEMMs (DDP over RCCL) some CUs are busy when the kernel starts, and a static tile
     // walk would leave their share for the end; one workgroup per tile lets the hardware dispatcher balance instead
-    dim3 grid((unsigned)((t256 < ncu || !g_nt256_persistent) ? t256 : ncu)), block(512);
+    dim3 grid((unsigned)((t256 < ncu || !persistent) ? t256 : ncu)), block(512);
 #define LAUNCH_256(E, F)                                                                                   \
   do {                                                                                                    \
     auto kfn = gemm_nt256_kernel<E, F>;                                                                   \
@@ -1743,7 +1746,7 @@ extern "C" int wft_gemm_tn_bf16(const wft_gemm_args* a, void* stream) {
   fill_params(a, p);
   hipStream_t s = (hipStream_t)stream;
   const long nsteps = ((a->K + 63) / 64) * a->batch;
-  if (tn_uses_256(a) && g_tn_variant != 1 && wft_tn4w_eligible(a)) {
+  if (tn_uses_256(a) && g_tn_variant != 1 && a->variant == 0 && wft_tn4w_eligible(a)) {
     int nsplit, per;
     wft_tn4w_plan(a, &nsplit, &per);
     const bool use_ws = (nsplit > 1 || seg) && a->workspace && a->workspace_bytes >= (int64_t)nsplit * a->M * a->N * 4 &&

@@ -60,7 +60,9 @@ extern "C" int wft_cast_bf16_f32(const wft_bf16* src, float* dst, int64_t n, voi
 // `fast` = every pointer / leading dimension allows that (checked on the host), otherwise element-wise.
 __global__ __launch_bounds__(256) void cast_pad_t_kernel(const float* src, long rows, long cols, unsigned short* dst,
                                                           unsigned short* dst_t, long rows_pad, long cols_pad,
-                                                          long ld_dst, long ld_dst_t, int fast) {
+                                                          long ld_dst, long ld_dst_t, int fast, float fs) {
+  // fs (fwd_scale): dst = bf16(fs * src) — ONE rounding of the scaled value — while dst_t stays bf16(src): the softmax scale folded
+  // into the forward shadow of an attention q projection (wft_attn_args.q_prescaled)
   __shared__ unsigned short tile[64][68];
   const long r0 = (long)blockIdx.y * 64, c0 = (long)blockIdx.x * 64;
   if (fast) {
@@ -77,7 +79,8 @@ __global__ __launch_bounds__(256) void cast_pad_t_kernel(const float* src, long 
       }
       const u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
       *(u32x2*)&tile[rr][q * 4] = pk;
-      if (r < rows_pad && c < cols_pad) *(u32x2*)(dst + r * ld_dst + c) = pk;  // cols_pad % 4 == 0 in fast mode
+      const u32x2 pf = {pack2bf(v[0] * fs, v[1] * fs), pack2bf(v[2] * fs, v[3] * fs)};
+      if (r < rows_pad && c < cols_pad) *(u32x2*)(dst + r * ld_dst + c) = pf;  // cols_pad % 4 == 0 in fast mode
     }
     if (dst_t) {
       __syncthreads();
@@ -97,10 +100,10 @@ __global__ __launch_bounds__(256) void cast_pad_t_kernel(const float* src, long 
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int rr = ty; rr < 64; rr += 4) {
     const long r = r0 + rr, c = c0 + tx;
-    unsigned short v = 0;
-    if (r < rows && c < cols) v = f2bf(src[r * cols + c]);
+    unsigned short v = 0, vf = 0;
+    if (r < rows && c < cols) { v = f2bf(src[r * cols + c]); vf = f2bf(src[r * cols + c] * fs); }
     tile[rr][tx] = v;
-    if (r < rows_pad && c < cols_pad) dst[r * ld_dst + c] = v;
+    if (r < rows_pad && c < cols_pad) dst[r * ld_dst + c] = vf;
   }
   if (dst_t) {
     __syncthreads();
@@ -112,15 +115,16 @@ __global__ __launch_bounds__(256) void cast_pad_t_kernel(const float* src, long 
 }
 extern "C" int wft_cast_pad_transpose_f32_bf16(const float* src, int64_t rows, int64_t cols, wft_bf16* dst,
                                                wft_bf16* dst_t, int64_t rows_pad, int64_t cols_pad, int64_t ld_dst,
-                                               int64_t ld_dst_t, void* stream) {
+                                               int64_t ld_dst_t, float fwd_scale, void* stream) {
   WFT_CHECK_ARG(src && dst, "null pointer");
+  if (fwd_scale == 0.f) fwd_scale = 1.f;
   WFT_CHECK_ARG(rows >= 1 && cols >= 1 && rows_pad >= rows && cols_pad >= cols, "bad shape");
   WFT_CHECK_ARG(ld_dst >= cols_pad && (!dst_t || ld_dst_t >= rows_pad), "leading dimensions too small");
   dim3 grid((unsigned)((cols_pad + 63) / 64), (unsigned)((rows_pad + 63) / 64));
   const int fast = cols % 4 == 0 && cols_pad % 4 == 0 && rows_pad % 4 == 0 && ld_dst % 4 == 0 && (!dst_t || ld_dst_t % 4 == 0) &&
                    (((uintptr_t)src) & 15) == 0 && (((uintptr_t)dst) & 7) == 0 && (!dst_t || (((uintptr_t)dst_t) & 7) == 0);
   hipLaunchKernelGGL(cast_pad_t_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, (long)rows, (long)cols, dst, dst_t,
-                     (long)rows_pad, (long)cols_pad, (long)ld_dst, (long)ld_dst_t, fast);
+                     (long)rows_pad, (long)cols_pad, (long)ld_dst, (long)ld_dst_t, fast, fwd_scale);
   WFT_CHECK_LAUNCH();
   return WFT_OK;
 }
@@ -131,7 +135,7 @@ extern "C" int wft_cast_pad_transpose_f32_bf16(const float* src, int64_t rows, i
 __global__ __launch_bounds__(256) void lora_merge_kernel(const float* W, long rows, long cols, const float* Bm, const float* Am,
                                                           const float* mask, int r, float scaling, unsigned short* dst,
                                                           unsigned short* dst_t, long rows_pad, long cols_pad, long ld_dst,
-                                                          long ld_dst_t, float* dst_f32, int fast) {
+                                                          long ld_dst_t, float* dst_f32, int fast, float fs) {
   __shared__ unsigned short tile[64][68];
   __shared__ float bs[64][65];                                  // bs[i][q] = B[r0 + i][q]
   __shared__ __attribute__((aligned(16))) float as[64][68];     // as[q][j] = scaling * A[q][c0 + j] * mask[c0 + j]
@@ -173,7 +177,8 @@ __global__ __launch_bounds__(256) void lora_merge_kernel(const float* W, long ro
       }
       const u32x2 pk = {pack2bf(w[0], w[1]), pack2bf(w[2], w[3])};
       *(u32x2*)&tile[rr][q4 * 4] = pk;
-      if (dst && rw < rows_pad && c < cols_pad) *(u32x2*)(dst + rw * ld_dst + c) = pk;
+      const u32x2 pf = {pack2bf(w[0] * fs, w[1] * fs), pack2bf(w[2] * fs, w[3] * fs)};  // (fs: see cast_pad_t_kernel)
+      if (dst && rw < rows_pad && c < cols_pad) *(u32x2*)(dst + rw * ld_dst + c) = pf;
     }
     if (dst_t) {
       __syncthreads();
@@ -193,15 +198,16 @@ __global__ __launch_bounds__(256) void lora_merge_kernel(const float* W, long ro
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int rr = ty; rr < 64; rr += 4) {
     const long rw = r0 + rr, c = c0 + tx;
-    unsigned short v = 0;
+    unsigned short v = 0, vf = 0;
     if (rw < rows && c < cols) {
       float acc = W[rw * cols + c];
       for (int q = 0; q < r; ++q) acc = fmaf(bs[rr][q], as[q][tx], acc);
       if (dst_f32) dst_f32[rw * cols + c] = acc;
       v = f2bf(acc);
+      vf = f2bf(acc * fs);
     }
     tile[rr][tx] = v;
-    if (dst && rw < rows_pad && c < cols_pad) dst[rw * ld_dst + c] = v;
+    if (dst && rw < rows_pad && c < cols_pad) dst[rw * ld_dst + c] = vf;
   }
   if (dst_t) {
     __syncthreads();
@@ -213,8 +219,9 @@ __global__ __launch_bounds__(256) void lora_merge_kernel(const float* W, long ro
 }
 extern "C" int wft_lora_merge(const float* W, int64_t rows, int64_t cols, const float* B, const float* A, const float* mask,
                               int rank, float scaling, wft_bf16* dst, wft_bf16* dst_t, int64_t rows_pad, int64_t cols_pad,
-                              int64_t ld_dst, int64_t ld_dst_t, float* dst_f32, void* stream) {
+                              int64_t ld_dst, int64_t ld_dst_t, float* dst_f32, float fwd_scale, void* stream) {
   WFT_CHECK_ARG(W && B && A && (dst || dst_f32), "null pointer");
+  if (fwd_scale == 0.f) fwd_scale = 1.f;
   WFT_CHECK_ARG(rows >= 1 && cols >= 1 && rank >= 1 && rank <= 64, "rank must be in 1..64");
   WFT_CHECK_ARG(!dst || (rows_pad >= rows && cols_pad >= cols && ld_dst >= cols_pad), "bad bf16 destination shape");
   WFT_CHECK_ARG(!dst_t || (dst && ld_dst_t >= rows_pad), "transposed destination needs dst and ld_dst_t >= rows_pad");
@@ -224,7 +231,7 @@ extern "C" int wft_lora_merge(const float* W, int64_t rows, int64_t cols, const 
                    (((uintptr_t)W) & 15) == 0 && (!dst || (((uintptr_t)dst) & 7) == 0) && (!dst_t || (((uintptr_t)dst_t) & 7) == 0) &&
                    (!dst_f32 || (((uintptr_t)dst_f32) & 15) == 0);
   hipLaunchKernelGGL(lora_merge_kernel, grid, dim3(256), 0, (hipStream_t)stream, W, (long)rows, (long)cols, B, A, mask, rank,
-                     scaling, dst, dst_t, (long)rows_pad, (long)cols_pad, (long)ld_dst, (long)ld_dst_t, dst_f32, fast);
+                     scaling, dst, dst_t, (long)rows_pad, (long)cols_pad, (long)ld_dst, (long)ld_dst_t, dst_f32, fast, fwd_scale);
   WFT_CHECK_LAUNCH();
   return WFT_OK;
 }
@@ -289,7 +296,9 @@ __global__ __launch_bounds__(256) void lora_refresh_mt_kernel(const long* tab, c
   const float* Am = (const float*)e[4];
   const float* mask = (const float*)e[5];
   const int r = (int)e[6];
-  const float scaling = __int_as_float((int)e[7]);
+  const float scaling = __int_as_float((int)(e[7] & 0xffffffffL));
+  const int fsb = (int)(e[7] >> 32);  // bits 32..63: fwd_scale as f32 bits (0 = 1.0): dst = bf16(fs * w), dst_t = bf16(w) — see cast_pad_t_kernel
+  const float fs = fsb ? __int_as_float(fsb) : 1.f;
   unsigned short* dst = (unsigned short*)e[8];
   unsigned short* dst_t = (unsigned short*)e[9];
   const long ld_dst = e[10], ld_dst_t = e[11];
@@ -339,7 +348,8 @@ __global__ __launch_bounds__(256) void lora_refresh_mt_kernel(const long* tab, c
     }
     const u32x2 pk = {pack2bf(w[0], w[1]), pack2bf(w[2], w[3])};
     *(u32x2*)&tile[rr][q4 * 4] = pk;
-    *(u32x2*)(dst + rw * ld_dst + c) = pk;
+    const u32x2 pf = {pack2bf(w[0] * fs, w[1] * fs), pack2bf(w[2] * fs, w[3] * fs)};
+    *(u32x2*)(dst + rw * ld_dst + c) = pf;
   }
   if (dst_t) {
     __syncthreads();
@@ -943,8 +953,14 @@ __global__ __launch_bounds__(256) void mt_copy_f32_kernel(const long* tab) {
   const long* row = tab + 3 * (long)blockIdx.x;
   const float* src = (const float*)row[0];
   float* dst = (float*)row[1];
-  const long n = row[2];
-  for (long i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+  const long n = row[2] & 0xffffffffL;
+  const int fsb = (int)(row[2] >> 32);  // bits 32..63 of the count field: a scale as f32 bits (0 = plain copy): the q slice of a fused bias
+  if (fsb) {
+    const float fs = __int_as_float(fsb);
+    for (long i = threadIdx.x; i < n; i += 256) dst[i] = src[i] * fs;
+  } else {
+    for (long i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+  }
 }
 extern "C" int wft_mt_copy_f32(const void* tab, int n, void* stream) {
   WFT_CHECK_ARG(tab && n >= 1, "bad args");

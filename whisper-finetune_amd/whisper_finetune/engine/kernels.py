@@ -52,8 +52,9 @@ def cast_f32(src: torch.Tensor) -> torch.Tensor:
     return dst
 
 
-def weight_shadow(w: torch.Tensor, rows_pad: int, cols_pad: int, want_t: bool, out=None, out_t=None):
-    """f32 [rows, cols] -> bf16 [rows_pad, cols_pad] (+ transposed [cols_pad, rows_pad])."""
+def weight_shadow(w: torch.Tensor, rows_pad: int, cols_pad: int, want_t: bool, out=None, out_t=None, fwd_scale: float = 1.0):
+    """f32 [rows, cols] -> bf16 [rows_pad, cols_pad] (+ transposed [cols_pad, rows_pad]).  fwd_scale: the straight image is
+    bf16(fwd_scale * w) (one rounding), the transposed one stays bf16(w) (wft.h; ops.QK_PRESCALE)."""
     _chk(w, F32, "w")
     w2 = w.reshape(w.shape[0], -1).contiguous()
     rows, cols = w2.shape
@@ -64,13 +65,13 @@ def weight_shadow(w: torch.Tensor, rows_pad: int, cols_pad: int, want_t: bool, o
     assert dst.stride(1) == 1 and (dst_t is None or dst_t.stride(1) == 1)
     L.check(
         L.load().wft_cast_pad_transpose_f32_bf16(_p(w2), rows, cols, _p(dst), _p(dst_t), rows_pad, cols_pad,
-                                                 dst.stride(0), 0 if dst_t is None else dst_t.stride(0), L.stream_ptr()),
+                                                 dst.stride(0), 0 if dst_t is None else dst_t.stride(0), float(fwd_scale), L.stream_ptr()),
         "wft_cast_pad_transpose_f32_bf16",
     )
     return dst, dst_t
 
 
-def lora_merge(w, B, A, mask, scaling: float, rows_pad=None, cols_pad=None, out=None, out_t=None, out_f32=None):
+def lora_merge(w, B, A, mask, scaling: float, rows_pad=None, cols_pad=None, out=None, out_t=None, out_f32=None, fwd_scale: float = 1.0):
     """W + scaling * B @ (A * mask) -> bf16 shadow `out` [rows_pad, cols_pad] (+ `out_t`) and/or f32 `out_f32` [rows, cols]."""
     for n, t in (("w", w), ("B", B), ("A", A)):
         _chk(t, F32, n)
@@ -90,7 +91,7 @@ def lora_merge(w, B, A, mask, scaling: float, rows_pad=None, cols_pad=None, out=
     L.check(
         L.load().wft_lora_merge(_p(w2), rows, cols, _p(B), _p(A), _p(mask), r, float(scaling), _p(out), _p(out_t),
                                 rows_pad or rows, cols_pad or cols, 0 if out is None else out.stride(0),
-                                0 if out_t is None else out_t.stride(0), _p(out_f32), L.stream_ptr()),
+                                0 if out_t is None else out_t.stride(0), _p(out_f32), float(fwd_scale), L.stream_ptr()),
         "wft_lora_merge",
     )
     return out, out_t, out_f32
@@ -217,11 +218,37 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, mask=None, want_colsum=Fa
 
 
 # --------------------------------------------------------------------------- GEMM
+# Per-call launch state (wft.h: wft_gemm_args / wft_attn_args `launch_mode`, `variant`, `q_prescaled`).  libwft keeps NO mutable state;
+# these Python-side hooks only choose what the wrappers below write into the argument structs.
+#   VARIANT: test / A-B hook — force the 8-wave kernels ("nt", "tn": gemm_nt256 / gemm_tn256; "fwd", "dq", "dkdv": the 8-wave
+#     attention kernels) where the one-wave-per-SIMD kernels would apply; `set_variant` returns the previous value.
+#   LAUNCH_OVERRIDE[0]: bench tooling (bench.py ddp_mode_1gpu) — None: the caller's `launch` argument decides; 0 / 1: every call.
+VARIANT = {"nt": 0, "tn": 0, "fwd": 0, "dq": 0, "dkdv": 0}
+LAUNCH_OVERRIDE = [None]
+LAUNCH_PERSISTENT, LAUNCH_PER_TILE = 0, 1
+
+
+def set_variant(which: str, v: int) -> int:
+    old = VARIANT[which]
+    if v >= 0:
+        VARIANT[which] = 1 if v else 0
+    return old
+
+
+def _launch(launch: int) -> int:
+    o = LAUNCH_OVERRIDE[0]
+    return int(launch) if o is None else int(o)
+
+
+def _attn_variant_bits() -> int:
+    return VARIANT["fwd"] | (VARIANT["dq"] << 1) | (VARIANT["dkdv"] << 2)
+
+
 def gemm_nt(a, b, *, M=None, N=None, K=None, lda=None, ldb=None, out=None, out_f32=False, accumulate=False,
             bias=None, residual=None, aux=None, epilogue=L.EPI_NONE, alpha=1.0, batch=1,
             strideA=0, strideB=0, strideC=0, strideR=0, strideAux=0, ldc=None,
             valid_rows_period=0, valid_rows=0, residual_first=False, ldaux=None, ldr=None, beta=1.0, colsum=None, p_valid=0,
-            _args_only=False):
+            launch=0, _args_only=False):
     """C[M,N] = alpha * A[M,K] @ B[N,K]^T (+bias) (epilogue) (+residual).
 
     a: bf16, row m at a.data_ptr() + m*lda; b: bf16 [N, K] (ldb).  Defaults take the shapes
@@ -265,6 +292,7 @@ def gemm_nt(a, b, *, M=None, N=None, K=None, lda=None, ldb=None, out=None, out_f
     args.valid_rows_period, args.valid_rows = valid_rows_period, valid_rows
     args.residual_first = int(residual_first)
     args.p_valid = int(p_valid)
+    args.launch_mode, args.variant = _launch(launch), VARIANT["nt"]
     if colsum is not None:  # f32 [N]: column sums of C (bias gradient of C's consumer), fused into the epilogue when possible
         _chk(colsum, F32, "colsum")
         args.colsum = colsum.data_ptr()
@@ -336,6 +364,7 @@ def gemm_tn(a, b, *, P=None, Q=None, R=None, lda=None, ldb=None, out=None, out_f
         _chk(col_scale, F32, "col_scale")
         args.tn_col_scale, args.tn_scale_rows = col_scale.data_ptr(), int(scale_rows)
     args.tn_block_n, args.tn_block_r = int(block_n), int(block_r)
+    args.variant = VARIANT["tn"]
     lib = L.load()
     if seg_out is not None:
         end = 0
@@ -395,8 +424,9 @@ def _attn_view(t: torch.Tensor):
     return t.data_ptr(), t.stride(1), t.stride(0)
 
 
-def attn_fwd(q, k, v, n_head: int, causal: bool, scale: float):
-    """q [B,Tq,H*64], k/v [B,Tk,H*64] bf16 views (any row stride) -> o [B,Tq,H*64], lse [B,H,Tq]."""
+def attn_fwd(q, k, v, n_head: int, causal: bool, scale: float, q_prescaled: bool = False):
+    """q [B,Tq,H*64], k/v [B,Tk,H*64] bf16 views (any row stride) -> o [B,Tq,H*64], lse [B,H,Tq].
+    q_prescaled: q already carries scale * log2(e) (ops.QK_PRESCALE folded into the q projection's forward shadow)."""
     for n, t in (("q", q), ("k", k), ("v", v)):
         _chk(t, BF16, n)
     B, Tq, D = q.shape
@@ -411,12 +441,15 @@ def attn_fwd(q, k, v, n_head: int, causal: bool, scale: float):
     a.o, a.ldo, a.o_bs = _attn_view(o)
     a.lse = lse.data_ptr()
     a.B, a.H, a.Tq, a.Tk, a.causal, a.scale = B, n_head, Tq, Tk, int(causal), scale
+    a.variant, a.q_prescaled = _attn_variant_bits(), int(bool(q_prescaled))
     L.check(L.load().wft_attn_fwd_bf16(C.byref(a), L.stream_ptr()), "wft_attn_fwd_bf16")
     return o, lse
 
 
-def attn_bwd(q, k, v, o, lse, do, n_head: int, causal: bool, scale: float, dq=None, dk=None, dv=None, colsums=None):
-    """colsums = (cs_q, cs_v): optional f32 [H*64] outputs, the column sums over (batch, time) of dq / dv (bias gradients)."""
+def attn_bwd(q, k, v, o, lse, do, n_head: int, causal: bool, scale: float, dq=None, dk=None, dv=None, colsums=None,
+             q_prescaled: bool = False, launch: int = 0):
+    """colsums = (cs_q, cs_v): optional f32 [H*64] outputs, the column sums over (batch, time) of dq / dv (bias gradients).
+    q_prescaled: as in attn_fwd; dq is the gradient w.r.t. the UNSCALED projection output either way."""
     B, Tq, D = q.shape
     Tk = k.shape[1]
     _chk(do, BF16, "do")
@@ -438,6 +471,7 @@ def attn_bwd(q, k, v, o, lse, do, n_head: int, causal: bool, scale: float, dq=No
     a.dq, a.lddq, a.dq_bs = _attn_view(dq)
     a.dk, a.lddk, a.dk_bs = _attn_view(dk)
     a.dv, a.lddv, a.dv_bs = _attn_view(dv)
+    a.variant, a.q_prescaled, a.launch_mode = _attn_variant_bits(), int(bool(q_prescaled)), _launch(launch)
     if colsums is not None:
         cs_q, cs_v = colsums
         _chk(cs_q, F32, "cs_q"); _chk(cs_v, F32, "cs_v")

@@ -37,6 +37,7 @@ class GemmArgs(C.Structure):
         ("colsum", c_vp),
         ("tn_col_scale", c_vp), ("tn_scale_rows", C.c_int), ("tn_block_n", C.c_int), ("tn_block_r", C.c_int),
         ("tn_seg_count", C.c_int), ("tn_seg_end", C.c_int * 4), ("tn_seg_ptr", c_vp * 4),
+        ("launch_mode", C.c_int), ("variant", C.c_int),
     ]
 
 
@@ -56,6 +57,7 @@ class AttnArgs(C.Structure):
         ("dk", c_vp), ("lddk", c_i64), ("dk_bs", c_i64),
         ("dv", c_vp), ("lddv", c_i64), ("dv_bs", c_i64),
         ("dq_colsum", c_vp), ("dv_colsum", c_vp), ("colsum_ws", c_vp),
+        ("launch_mode", C.c_int), ("variant", C.c_int), ("q_prescaled", C.c_int),
     ]
 
 
@@ -79,8 +81,8 @@ EPI_NONE, EPI_GELU, EPI_DGELU, EPI_GELU_GRAD, EPI_MUL_AUX = 0, 1, 2, 3, 4
 SIGNATURES = {
     "wft_cast_f32_bf16": [c_vp, c_vp, c_i64, c_vp],
     "wft_cast_bf16_f32": [c_vp, c_vp, c_i64, c_vp],
-    "wft_cast_pad_transpose_f32_bf16": [c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp],
-    "wft_lora_merge": [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, C.c_int, C.c_float, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp],
+    "wft_cast_pad_transpose_f32_bf16": [c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, C.c_float, c_vp],
+    "wft_lora_merge": [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, C.c_int, C.c_float, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, C.c_float, c_vp],
     "wft_lora_refresh_mt": [c_vp, c_vp, C.c_int, C.c_int, c_vp],
     "wft_lora_pack": [c_vp, c_vp, c_vp, C.c_int, c_i64, c_i64, C.c_float, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp],
     "wft_add_bf16": [c_vp, c_vp, c_vp, c_i64, c_vp],
@@ -98,9 +100,6 @@ SIGNATURES = {
     "wft_gemm_nt_bf16": [C.POINTER(GemmArgs), c_vp],
     "wft_gemm_nt_variant": [C.POINTER(GemmArgs)],
     "wft_gemm_tn_segments_ok": [C.POINTER(GemmArgs)],
-    "wft_gemm_set_nt_variant": [C.c_int],
-    "wft_gemm_set_tn_variant": [C.c_int],
-    "wft_gemm_set_persistent": [C.c_int],
     "wft_gemm_nt_colsum_workspace_bytes": [C.POINTER(GemmArgs)],
     "wft_gemm_tn_bf16": [C.POINTER(GemmArgs), c_vp],
     "wft_gemm_nt_rank_pair_bf16": [C.POINTER(GemmArgs), C.POINTER(GemmArgs), c_vp],
@@ -109,10 +108,7 @@ SIGNATURES = {
     "wft_attn_fwd_bf16": [C.POINTER(AttnArgs), c_vp],
     "wft_attn_bwd_bf16": [C.POINTER(AttnArgs), c_vp],
     "wft_attn_bwd_colsum_workspace_bytes": [C.POINTER(AttnArgs)],
-    "wft_attn_set_dkdv_variant": [C.c_int],
-    "wft_attn_set_dq_variant": [C.c_int],
-    "wft_attn_set_fwd_variant": [C.c_int],
-    "wft_attn_set_persistent": [C.c_int],
+    "wft_attn_variant": [C.POINTER(AttnArgs), C.c_int],
     "wft_embed_fwd": [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, C.c_int, c_i64, c_vp],
     "wft_embed_bwd": [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, C.c_int, c_i64, c_vp],
     "wft_ce_fwd": [c_vp, c_i64, c_vp, c_i64, c_i64, C.c_float, c_vp, c_vp, c_vp, c_vp, c_vp],
@@ -168,10 +164,10 @@ def load():
             f"HIP extension {LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(make -C whisper-finetune_amd/csrc). There is no CPU fallback for the product path."
         )
-    # Launch modes of a multi-GPU job: persistent grids by default; model_utils.train_step switches the 256x256 NT GEMMs and the
-    # dK/dV kernel to one workgroup per tile / item for the backward pass that runs beside the gradient all-reduce
-    # (runtime.exchange_launch_mode, wft_gemm_set_persistent / wft_attn_set_persistent; measured in bench.py's ddp_mode_1gpu block).
-    # WFT_NT256_PERSISTENT=0 / WFT_ATTN_PERSISTENT=0 (read when the library is loaded) force per-tile launches everywhere.
+    # Launch modes of a multi-GPU job: persistent grids by default; model_utils.train_step asks for one workgroup per tile / item
+    # (wft_gemm_args / wft_attn_args launch_mode = 1, a per-call field) in the backward pass that runs beside the gradient all-reduce
+    # (runtime.exchange_launch_mode; measured in bench.py's ddp_mode_1gpu block).  The library holds no mutable launch state;
+    # WFT_NT256_PERSISTENT=0 / WFT_ATTN_PERSISTENT=0 (read ONCE when the library is loaded) force per-tile launches everywhere.
     lib = C.CDLL(str(LIB_PATH))
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing

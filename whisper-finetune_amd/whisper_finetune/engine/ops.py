@@ -16,11 +16,22 @@ import os
 import torch
 from torch.optim.optimizer import register_optimizer_step_post_hook
 
+from .. import runtime as _rt
 from . import kernels as K
 from . import lib as L
 
 BF16 = torch.bfloat16
 F32 = torch.float32
+
+# Softmax scale folded into the q projection: the FORWARD bf16 shadow of the self-attention q weight and the q
+# slice of the fused bias carry scale * log2(e) (LinearGroup.fwd_scales -> wft_cast_pad_transpose_f32_bf16 / wft_lora_merge /
+# wft_lora_refresh_mt `fwd_scale`, applied in fp32 before the one bf16 rounding), so the q third of the fused QKV output IS the exp2
+# exponent's left operand and no attention kernel multiplies its scores (wft_attn_args.q_prescaled; -4 % on the three encoder kernels,
+# profiles/r06_attn_prescale.md).  The backward-data shadow W^T stays unscaled and the dQ kernel returns the gradient w.r.t. the unscaled
+# projection output, so dx, dW, db and the LoRA gradients are computed exactly as before.  Reference: whisper's `q * scale`
+# (MultiHeadAttention.qkv_attention, reached from model/model_utils.py:283-285,320-322).  WFT_QK_PRESCALE=0: the old path (A/B runs).
+QK_PRESCALE = os.environ.get("WFT_QK_PRESCALE", "1") != "0"
+QK_ALPHA = float(torch.tensor(64 ** -0.5, dtype=torch.float32) * torch.tensor(1.4426950408889634, dtype=torch.float32))
 
 # bumped by optimizers that update parameters through raw pointers (torch's in-place ops bump
 # tensor._version themselves); part of every shadow-cache key.
@@ -100,12 +111,26 @@ class LinearGroup:
     """bf16 shadows for one or several Linear layers that share their input and are evaluated
     as ONE GEMM (q/k/v -> N = 3*d).  Rebuilt only when a parameter changed."""
 
-    def __init__(self):
+    def __init__(self, fwd_scales: Optional[Sequence[float]] = None):
         self.key = self.bkey = None
         self.bias_aliased = False
         self.W = self.WT = self.bias = None
         self.lkey = None
         self.Am = self.AmT = self.Bb = self.BbT = None
+        # per weight of the group: factor folded into the FORWARD shadow W (and the matching slice of the stacked bias) in fp32
+        # before the bf16 rounding; the transposed shadow W^T (backward-data) and the rank-r LoRA operands stay unscaled.
+        # Self-attention q/k/v groups: (QK_ALPHA, 1, 1) — see QK_PRESCALE above.  A constant of the group: not part of the keys.
+        self.fwd_scales = None if fwd_scales is None or all(float(f) == 1.0 for f in fwd_scales) else tuple(float(f) for f in fwd_scales)
+
+    def fwd_scale(self, i: int) -> float:
+        return 1.0 if self.fwd_scales is None else self.fwd_scales[i]
+
+    @staticmethod
+    def _fbits(f: float) -> int:
+        """f32 bits of a forward scale for the high half of a table field (0 = 1.0; wft.h wft_lora_refresh_mt / wft_mt_copy_f32)."""
+        import struct
+
+        return 0 if f == 1.0 else struct.unpack("<I", struct.pack("<f", f))[0] << 32
 
     @staticmethod
     def dims(weights: Sequence[torch.Tensor]):
@@ -140,15 +165,19 @@ class LinearGroup:
             n, k, npad = self.dims(weights)
             if not any(b is not None for b in biases):
                 self.bias = None
-            elif len(weights) == 1 and n == npad and biases[0].dtype == F32 and biases[0].is_contiguous() and biases[0].data_ptr() % 16 == 0:
+            elif len(weights) == 1 and n == npad and biases[0].dtype == F32 and biases[0].is_contiguous() and biases[0].data_ptr() % 16 == 0 \
+                    and self.fwd_scales is None:
                 self.bias = biases[0].detach()  # the parameter itself: nothing to copy, never stale
             else:
                 if self.bias is None or self.bias.shape[0] != npad or self.bias_aliased:
                     self.bias = torch.zeros(npad, dtype=F32, device=weights[0].device)
                 off = 0
-                for w, b in zip(weights, biases):
+                for i, (w, b) in enumerate(zip(weights, biases)):
                     if b is not None:
-                        self.bias[off:off + w.shape[0]].copy_(b.detach())
+                        if self.fwd_scale(i) == 1.0:
+                            self.bias[off:off + w.shape[0]].copy_(b.detach())
+                        else:  # the forward GEMM adds the bias to the SCALED product
+                            torch.mul(b.detach(), self.fwd_scale(i), out=self.bias[off:off + w.shape[0]])
                     off += w.shape[0]
             self.bias_aliased = self.bias is not None and any(b is not None and b.data_ptr() == self.bias.data_ptr() for b in biases)
             self.bkey = bkey
@@ -167,10 +196,11 @@ class LinearGroup:
                 sp = loras[i] if lkey is not None else None
                 if sp is None:
                     K.weight_shadow(w.detach(), o, k, want_t, out=self.W[off:off + o],
-                                    out_t=self.WT[:, off:off + o] if want_t else None)
+                                    out_t=self.WT[:, off:off + o] if want_t else None, fwd_scale=self.fwd_scale(i))
                 else:
                     K.lora_merge(w.detach(), sp.B.detach(), sp.A.detach(), None if sp.mask is None else sp.mask.detach(), sp.scaling,
-                                 rows_pad=o, cols_pad=k, out=self.W[off:off + o], out_t=self.WT[:, off:off + o] if want_t else None)
+                                 rows_pad=o, cols_pad=k, out=self.W[off:off + o], out_t=self.WT[:, off:off + o] if want_t else None,
+                                 fwd_scale=self.fwd_scale(i))
                 off += o
             self.key = key
             if lkey is not None and None not in lkey:
@@ -254,11 +284,11 @@ class LoraRefreshPlan:
             packed = group.Am is not None
             rpad = group.Am.shape[0] if packed else 0
             off = ro = 0
-            for w, ad in zip(weights, adapters):
+            for wi, (w, ad) in enumerate(zip(weights, adapters)):
                 o, r = w.shape[0], ad.lora_A.shape[0]
                 m = mask_of(ad)
                 rows.append([w.data_ptr(), o, k, ad.lora_B.data_ptr(), ad.lora_A.data_ptr(), 0 if m is None else m.data_ptr(), r,
-                             struct.unpack("<i", struct.pack("<f", float(ad.scaling)))[0],
+                             struct.unpack("<I", struct.pack("<f", float(ad.scaling)))[0] | group._fbits(group.fwd_scale(wi)),
                              group.W.data_ptr() + 2 * off * group.W.stride(0), group.WT.data_ptr() + 2 * off,
                              group.W.stride(0), group.WT.stride(0)]
                             + ([group.Am.data_ptr(), group.AmT.data_ptr(), group.Bb.data_ptr(), group.BbT.data_ptr()] if packed
@@ -374,15 +404,15 @@ class PlainRefreshPlan:
                 n, k, npad = g.dims(ws)
                 off = 0
                 if self._stacks_biases(g, ws, bs):
-                    for w, b in zip(ws, bs):
+                    for wi, (w, b) in enumerate(zip(ws, bs)):
                         if b is not None:
-                            brows.append([b.data_ptr(), g.bias.data_ptr() + 4 * off, w.shape[0]])
+                            brows.append([b.data_ptr(), g.bias.data_ptr() + 4 * off, w.shape[0] | g._fbits(g.fwd_scale(wi))])
                             self.ptrs.extend((b.data_ptr(), g.bias.data_ptr()))
                         off += w.shape[0]
                     off = 0
-                for w in ws:
+                for wi, w in enumerate(ws):
                     o = w.shape[0]
-                    rows.append([w.data_ptr(), o, k, 0, 0, 0, 0, 0, g.W.data_ptr() + 2 * off * g.W.stride(0), g.WT.data_ptr() + 2 * off,
+                    rows.append([w.data_ptr(), o, k, 0, 0, 0, 0, g._fbits(g.fwd_scale(wi)), g.W.data_ptr() + 2 * off * g.W.stride(0), g.WT.data_ptr() + 2 * off,
                                  g.W.stride(0), g.WT.stride(0), 0, 0, 0, 0, 0, npad, 0, off])
                     tiles.append(tiles[-1] + (o // 64) * (k // 64))
                     self.ptrs.append(w.data_ptr())
@@ -616,6 +646,7 @@ class LinearFn(torch.autograd.Function):
         else:
             y = K.gemm_nt(x, W, bias=bias, residual=residual)
         ctx.cfg = cfg
+        ctx.launch = _rt.backward_launch_mode()  # per-call launch mode of this node's backward GEMMs (runtime.exchange_launch_mode)
         ctx.accum = None
         if cfg.accum is not None and ctx.needs_input_grad[0] and gelu_pre is None:
             ctx.accum = cfg.accum
@@ -652,13 +683,15 @@ class LinearFn(torch.autograd.Function):
                 # dpre is the dy of the Linear that produced gelu_pre: its bias gradient (column sums) comes out of this
                 # GEMM's epilogue (see _publish_colsum / _fused_colsum)
                 cs = torch.empty(WT.shape[0], dtype=F32, device=dy.device) if ctx.want_cs else None
-                dpre = K.gemm_nt(dy, WT, epilogue=L.EPI_MUL_AUX if _GELU_PAIR else L.EPI_DGELU, aux=gelu_pre, colsum=cs)
+                dpre = K.gemm_nt(dy, WT, epilogue=L.EPI_MUL_AUX if _GELU_PAIR else L.EPI_DGELU, aux=gelu_pre, colsum=cs, launch=ctx.launch)
                 if cs is not None:
                     _publish_colsum(dpre, cs)
             elif ctx.accum is not None:  # one of several consumers of x: add into the running sum, the fork node returns it
-                dx = ctx.accum.arrive(lambda run: K.gemm_nt(dy, WT) if run is None else K.gemm_nt(dy, WT, residual=run, out=run))
+                lm = ctx.launch
+                dx = ctx.accum.arrive(lambda run: K.gemm_nt(dy, WT, launch=lm) if run is None
+                                      else K.gemm_nt(dy, WT, residual=run, out=run, launch=lm))
             else:
-                dx = K.gemm_nt(dy, WT)
+                dx = K.gemm_nt(dy, WT, launch=ctx.launch)
         out: List[Optional[torch.Tensor]] = [dx, dy if ctx.has_res else None, dpre, None]
         # parameter grads: weights
         w_need = [ctx.needs_input_grad[4 + i] for i in range(n_w)]
@@ -908,29 +941,31 @@ class SelfAttnFn(torch.autograd.Function):
     """qkv bf16 [B, T, 3*d] (fused projection output, consumed in place) -> o bf16 [B, T, d]."""
 
     @staticmethod
-    def forward(ctx, qkv, n_head, causal):
+    def forward(ctx, qkv, n_head, causal, prescaled=False):
+        """prescaled: the q third of qkv carries scale * log2(e) (QK_PRESCALE: the projection's LinearGroup has fwd_scales)."""
         d = qkv.shape[-1] // 3
         q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
         scale = 64 ** -0.5
-        o, lse = K.attn_fwd(q, k, v, n_head, causal, scale)
+        o, lse = K.attn_fwd(q, k, v, n_head, causal, scale, q_prescaled=prescaled)
         ctx.save_for_backward(qkv, o, lse)
-        ctx.cfg = (n_head, causal, scale)
+        ctx.cfg = (n_head, causal, scale, bool(prescaled), _rt.backward_launch_mode())
         ctx.want_cs = BIAS_GRADS[0]
         return o
 
     @staticmethod
     def backward(ctx, do):
         qkv, o, lse = ctx.saved_tensors
-        n_head, causal, scale = ctx.cfg
+        n_head, causal, scale, prescaled, launch = ctx.cfg
         d = qkv.shape[-1] // 3
         dqkv = torch.empty_like(qkv)
         want_cs = ctx.want_cs
         cs = torch.zeros(3 * d, dtype=F32, device=qkv.device) if want_cs else None  # [q | k (no bias in whisper: stays 0) | v]
         K.attn_bwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], o, lse, do.to(BF16), n_head, causal, scale,
-                   dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:], colsums=(cs[:d], cs[2 * d:]) if want_cs else None)
+                   dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:], colsums=(cs[:d], cs[2 * d:]) if want_cs else None,
+                   q_prescaled=prescaled, launch=launch)
         if want_cs and not _K_HAS_BIAS[0]:
             _publish_colsum(dqkv, cs)  # bias gradients of the fused q/k/v projection, summed in the kernels' epilogues
-        return dqkv, None, None
+        return dqkv, None, None, None
 
 
 class CrossAttnFn(torch.autograd.Function):
@@ -942,14 +977,14 @@ class CrossAttnFn(torch.autograd.Function):
         scale = 64 ** -0.5
         o, lse = K.attn_fwd(q, kv[..., :d], kv[..., d:], n_head, False, scale)
         ctx.save_for_backward(q, kv, o, lse)
-        ctx.cfg = (n_head, scale)
+        ctx.cfg = (n_head, scale, _rt.backward_launch_mode())
         ctx.want_cs = BIAS_GRADS[0]
         return o
 
     @staticmethod
     def backward(ctx, do):
         q, kv, o, lse = ctx.saved_tensors
-        n_head, scale = ctx.cfg
+        n_head, scale, launch = ctx.cfg
         d = q.shape[-1]
         dq = torch.empty_like(q)
         dkv = torch.empty_like(kv)
@@ -957,7 +992,7 @@ class CrossAttnFn(torch.autograd.Function):
         cs_q = torch.empty(d, dtype=F32, device=q.device) if want_cs else None
         cs_kv = torch.zeros(2 * d, dtype=F32, device=q.device) if want_cs else None  # [k (no bias) | v]
         K.attn_bwd(q, kv[..., :d], kv[..., d:], o, lse, do.to(BF16), n_head, False, scale, dq=dq, dk=dkv[..., :d], dv=dkv[..., d:],
-                   colsums=(cs_q, cs_kv[d:]) if want_cs else None)
+                   colsums=(cs_q, cs_kv[d:]) if want_cs else None, launch=launch)
         if want_cs:
             _publish_colsum(dq, cs_q)
             if not _K_HAS_BIAS[0]:
@@ -1009,6 +1044,7 @@ class ConvStemFn(torch.autograd.Function):
         ctx.save_for_backward(mel_t, pre1, act1, pre2)
         ctx.cache = cache
         ctx.shapes = (B, T, c_pad, d, w1.shape[1])
+        ctx.launch = _rt.backward_launch_mode()
         return x
 
     @staticmethod
@@ -1033,12 +1069,12 @@ class ConvStemFn(torch.autograd.Function):
         # odd padded rows tau = 2j+1 (j = 0..T2-1): dpre2[j] @ W2[:,:,1]
         K.gemm_nt(dpre2[:, 1:], cache["w2_odd"], M=T2, N=d, K=d, lda=d, ldb=d, out=dpre1[:, 1:], ldc=2 * d,
                   epilogue=L.EPI_DGELU, aux=pre1[:, 1:], ldaux=2 * d, batch=B, strideA=(T2 + 2) * d, strideC=Tp * d,
-                  strideAux=Tp * d)
+                  strideAux=Tp * d, launch=ctx.launch)
         # even padded rows tau = 2j (j = 1..T2): [dpre2[j-1], dpre2[j]] @ [W2[:,:,2]; W2[:,:,0]]
         aux_even = pre1[:, 2:]
         K.gemm_nt(dpre2[:, 1:], cache["w2_even"], M=T2, N=d, K=2 * d, lda=d, ldb=2 * d, out=dpre1[:, 2:], ldc=2 * d,
                   epilogue=L.EPI_DGELU, aux=aux_even, ldaux=2 * d, batch=B, strideA=(T2 + 2) * d, strideC=Tp * d,
-                  strideAux=Tp * d)
+                  strideAux=Tp * d, launch=ctx.launch)
         db1 = K.colsum(dpre1.view(B * Tp, d))
         dW1 = K.gemm_tn(dpre1[:, 1:], mel_t, R=T, P=d, Q=3 * c_pad, lda=d, ldb=c_pad, batch=B, strideA=Tp * d,
                         strideB=Tp * c_pad)
@@ -1076,6 +1112,7 @@ class TiedLogitsFn(torch.autograd.Function):
         logits = K.gemm_nt(x, W)
         ctx.save_for_backward(x, emb)
         ctx.group = group
+        ctx.launch = _rt.backward_launch_mode()
         return logits
 
     @staticmethod
@@ -1083,7 +1120,7 @@ class TiedLogitsFn(torch.autograd.Function):
         x, emb = ctx.saved_tensors
         W, WT, _ = ctx.group.shadows([emb], [None], need_t=True)
         dl = dl.to(BF16).contiguous()
-        dx = K.gemm_nt(dl, WT) if ctx.needs_input_grad[0] else None
+        dx = K.gemm_nt(dl, WT, launch=ctx.launch) if ctx.needs_input_grad[0] else None
         dE = K.gemm_tn(dl, x)[: emb.shape[0], : emb.shape[1]] if ctx.needs_input_grad[1] else None
         return dx, dE, None
 

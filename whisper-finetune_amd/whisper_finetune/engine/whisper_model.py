@@ -160,7 +160,8 @@ class MultiHeadAttention(nn.Module):
         self.key = Linear(n_state, n_state, bias=False)
         self.value = Linear(n_state, n_state)
         self.out = Linear(n_state, n_state)
-        self._qkv_group = ops.LinearGroup()
+        # self-attention: the softmax scale * log2(e) rides in the q rows of the fused projection's FORWARD shadow (ops.QK_PRESCALE)
+        self._qkv_group = ops.LinearGroup(fwd_scales=(ops.QK_ALPHA, 1.0, 1.0) if ops.QK_PRESCALE else None)
         self._kv_group = ops.LinearGroup()
         self.wft_fp32 = False
 
@@ -181,7 +182,7 @@ class MultiHeadAttention(nn.Module):
             lin = [self.query, self.key, self.value]
             qkv = ops.linear(x2, self._qkv_group, [m.base_weight() for m in lin], [m.bias for m in lin],
                              [m.lora_spec() for m in lin])
-            o = ops.SelfAttnFn.apply(qkv.view(B, T, 3 * d), self.n_head, mask is not None)
+            o = ops.SelfAttnFn.apply(qkv.view(B, T, 3 * d), self.n_head, mask is not None, self._qkv_group.fwd_scales is not None)
         else:
             Ta = xa.shape[1]
             q = self.query(x2)

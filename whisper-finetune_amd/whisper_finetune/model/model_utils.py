@@ -81,12 +81,13 @@ def train_step(
                 if graphed is not None:  # training.wft_hip_graph: forward + loss + backward as ONE graph launch (engine/graph.py)
                     total_loss += graphed(x, y_in, y_out).item()
                     break
-                with rt.maybe_no_sync(model, enabled=rt.IS_DISTRIBUTED and not last):
+                # the backward pass that runs beside the bucketed all-reduce gets per-tile launches: the mode is noted by the autograd
+                # nodes while the forward runs on this thread and handed to their backward kernels per call (runtime.exchange_launch_mode)
+                with rt.maybe_no_sync(model, enabled=rt.IS_DISTRIBUTED and not last), \
+                        rt.exchange_launch_mode(rt.IS_DISTRIBUTED and last and device.type == "cuda"):
                     with torch.autocast(device_type=device.type, enabled=mixed, dtype=amp_dtype):
                         loss = _micro_batch_loss(model, x, y_in, y_out, label_smoothing) / accum
-                    # the backward pass that runs beside the bucketed all-reduce: per-tile launches (runtime.exchange_launch_mode)
-                    with rt.exchange_launch_mode(rt.IS_DISTRIBUTED and last and device.type == "cuda"):
-                        (scaler.scale(loss) if scaler else loss).backward()
+                    (scaler.scale(loss) if scaler else loss).backward()
                 total_loss += loss.item()
                 break
             except RuntimeError as err:

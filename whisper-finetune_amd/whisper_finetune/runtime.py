@@ -11,6 +11,7 @@ imported lazily and only when enabled.
 from __future__ import annotations
 
 import contextlib
+import threading
 import datetime
 import os
 from typing import Optional
@@ -101,26 +102,34 @@ def ddp_bucket_cap_mb(model, default_mb: int = 64, one_bucket_below_mb: int = 25
     return int(mb) + 1 if mb <= one_bucket_below_mb else default_mb
 
 
+_TLS = threading.local()
+
+
+def backward_launch_mode() -> int:
+    """What the autograd functions of engine/ops.py record at FORWARD time for their backward kernels: 1 (one workgroup per tile /
+    item) inside `exchange_launch_mode` on THIS thread, else 0 (persistent grids)."""
+    return 1 if getattr(_TLS, "exchange", 0) > 0 else 0
+
+
 @contextlib.contextmanager
 def exchange_launch_mode(active: bool):
-    """Launch modes while a gradient exchange is in flight: inside this context (the backward pass of the LAST micro-batch of an
-    accumulation window in a multi-process job — the only kernels that run beside RCCL's collective kernels; the reference's
-    `no_sync()` window, model/model_utils.py:63-72) the 256x256 NT GEMMs and the dK/dV attention kernel are launched one workgroup
-    per tile / item, everywhere else on their persistent grids.  Measured on one GPU with a side-stream kernel that holds CUs the
-    way the collectives do (bench.py `ddp_mode_1gpu`): per-tile launches cost 0.5-0.9 % of a step while nothing holds CUs and
-    are 0.6-1.1 % faster than persistent grids while 24 CUs are held."""
+    """Launch mode of the backward pass that runs beside a gradient exchange.  `train_step` wraps forward + backward of the LAST
+    micro-batch of an accumulation window of a multi-process job in this context (the reference's `no_sync()` window ends there,
+    model/model_utils.py:63-72): every autograd function of the engine notes `backward_launch_mode()` in its forward and hands it to
+    its backward kernels as a PER-CALL argument (wft_gemm_args.launch_mode / wft_attn_args.launch_mode) — the 256x256 NT GEMMs and
+    the dK/dV attention kernel of that backward pass run one workgroup per tile / item, the forward pass, the `no_sync()`
+    micro-batches and anything another thread does (an evaluator, a second model) keep their persistent grids.  Nothing is switched
+    inside libwft: the mode is thread-local here and travels through the autograd graph.  Measured on one GPU with a side-stream
+    kernel that holds CUs the way the collectives do (bench.py `ddp_mode_1gpu`): per-tile launches cost 0.5-0.9 % of a step while
+    nothing holds CUs and are 0.6-1.1 % faster than persistent grids while 24 CUs are held."""
     if not active:
         yield
         return
-    from whisper_finetune.engine import lib as L
-
-    lib = L.load()
-    old = (lib.wft_gemm_set_persistent(0), lib.wft_attn_set_persistent(0))
+    _TLS.exchange = getattr(_TLS, "exchange", 0) + 1
     try:
         yield
     finally:
-        lib.wft_gemm_set_persistent(old[0])
-        lib.wft_attn_set_persistent(old[1])
+        _TLS.exchange -= 1
 
 
 # ---------------------------------------------------------------- wandb (rank 0 only)
