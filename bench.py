@@ -518,7 +518,7 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--model", default="large-v3")
-    ap.add_argument("--batch", type=int, default=87, help="clips per GPU per step")
+    ap.add_argument("--batch", type=int, default=96, help="clips per GPU per step")
     ap.add_argument("--seq", type=int, default=128)
     ap.add_argument("--lora", action="store_true", help="BASELINE configs[2]: LoRA r=16 alpha=32 dropout 0.1 on every Linear")
     ap.add_argument("--muon", action="store_true", help="Muon + auxiliary Adam param groups (config_large_v3_best_muon.yaml)")

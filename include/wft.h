@@ -159,7 +159,18 @@ enum {
    * bytes — and the backward-data GEMM multiplies by it, so the derivative's exp/rcp/polynomial (about 30 % of a
    * K = 1280 tile's time when done in the backward epilogue) is computed once, beside gelu() itself.  bf16 C only. */
   WFT_EPI_GELU_GRAD = 3, /* C = gelu_erf(acc + bias); aux (required) <- gelu'(acc + bias) */
-  WFT_EPI_MUL_AUX = 4    /* C = acc * aux */
+  WFT_EPI_MUL_AUX = 4,   /* C = acc * aux */
+  /* The same pair with gelu' stored in ONE BYTE per element (round 6): code = round(200 gelu') + 26, a 1/200 grid on which
+   * gelu' = 0 and gelu' = 1 are exact, range [-0.13, 1.145] (gelu' lies in [-0.129, 1.129]), |error| <= 0.0025 — about the bf16
+   * half-ulp near 1.  `aux` is then NOT an [M, N] matrix but an opaque buffer of wft_gemm_nt_aux8_bytes(args) bytes in the
+   * FRAGMENT order of gemm_nt4w_kernel (16 KiB per 256x256 tile and wave; lda / strides of aux are ignored): the writer (mlp.0's
+   * forward GEMM) and the reader (mlp.2's backward-data GEMM) have the same M and N, hence the same tiles.  Only the
+   * one-wave-per-SIMD kernel carries them: ask wft_gemm_nt_aux8_bytes (0 = not served: use the bf16 pair).  batch 1, alpha 1.
+   * Halves the bytes of the pair's second tensor on the store / load path that prices these epilogues, and saves one byte per
+   * MLP activation element of saved-for-backward memory (21 GiB at 87 clips of large-v3).  Reference: `F.gelu` in
+   * whisper.model.ResidualAttentionBlock.mlp (keys mlp.0 / mlp.2, scripts/convert_openai_to_hf.py:91-92).                     */
+  WFT_EPI_GELU_GRAD8 = 5, /* C = gelu_erf(acc + bias); aux <- codes of gelu'(acc + bias) */
+  WFT_EPI_MUL_AUX8 = 6    /* C = acc * decode(aux) */
 };
 /* C[b][m, n] = alpha * sum_k A[b][m, k] * B[b][n, k]  (+ bias[n]) (epilogue)
  *              (+ residual[b][m, n]);  bf16 inputs, fp32 MFMA accumulation.
@@ -245,6 +256,9 @@ int wft_gemm_nt_variant(const wft_gemm_args* args);
  * well-formed segment list), 0 if the caller has to use C and copy.  Pure host function.                                    */
 int wft_gemm_tn_segments_ok(const wft_gemm_args* args);
 int64_t wft_gemm_nt_colsum_workspace_bytes(const wft_gemm_args* args);
+/* Size of the one-byte gelu' buffer of WFT_EPI_GELU_GRAD8 / WFT_EPI_MUL_AUX8 for these arguments, or 0 if the call would not be
+ * served in that form (not a gemm_nt4w_kernel problem).  Pure host function.                                                */
+int64_t wft_gemm_nt_aux8_bytes(const wft_gemm_args* args);
 /* C[p, q] (+)= alpha * sum_r A[r, p] * B[r, q]   (weight gradients dW = dY^T X:
  * what autograd's mm-backward computes for whisper.model.Linear).
  *  A bf16 [R, P] (row r at A + r*lda, P contiguous), B bf16 [R, Q];

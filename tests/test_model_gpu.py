@@ -348,37 +348,6 @@ def test_base_full_finetune_step_matches_oracle():
     _grad_check(m, p_req, "base vs fp32 oracle")
 
 
-@pytest.mark.parametrize("name", ["small", "medium"])
-def test_small_and_medium_full_finetune_step_matches_oracle(name):
-    """whisper-small (d = 768, 12 heads, 12 + 12 layers: the reference's configs/DEBUG.yaml:2 `init_name: small`) and whisper-medium
-    (d = 1024, 16 heads, 24 + 24 layers) through the engine — the LayerNorm column templates, GEMM tile plans and attention head counts
-    no other model-level test touches.  2 clips, S = 32, against the fp32 oracle, same bounds as whisper-base."""
-    dims = O.DIMS[name]
-    assert (dims.n_audio_state, dims.n_audio_head) == {"small": (768, 12), "medium": (1024, 16)}[name]
-    params = O.init_params(dims, seed=11)
-    audio, y_in, y_out = O.synthetic_batch(dims, 2, 32)
-    y_out[1, :3] = -100
-    p_req = {k: v.clone().requires_grad_(k != "encoder.positional_embedding") for k, v in params.items()}
-    mel_ref = O.log_mel_spectrogram(audio, dims.n_mels)
-    loss_ref = O.cross_entropy(O.Oracle(dims, p_req).forward(mel_ref, y_in), y_out, 0.1)
-    loss_ref.backward()
-    m = _engine(dims, params).train()
-    mel = K.logmel(audio.to(DEV), O.mel_filters(dims.n_mels).to(DEV))
-    loss = m(mel, y_in.to(DEV), targets=y_out.to(DEV), label_smoothing=0.1)
-    loss.backward()
-    assert abs(loss.item() - loss_ref.item()) < 5e-4 * loss_ref.item()
-    _grad_check(m, p_req, f"{name} vs fp32 oracle")
-    # teacher-forced argmax on the evaluation path: same tokens as the oracle wherever its top-2 margin exceeds bf16 resolution
-    m.eval()
-    with torch.no_grad():
-        logits = m(mel, y_in.to(DEV)).float().cpu()
-        ref = O.Oracle(dims, params).forward(mel_ref, y_in)
-    top2 = ref.topk(2, -1).values
-    clear = (top2[..., 0] - top2[..., 1]) > 0.05 * ref.abs().amax(-1)
-    assert clear.any() and torch.equal(logits.argmax(-1)[clear], ref.argmax(-1)[clear])
-    assert rel(logits, ref) < 2e-2
-
-
 def test_turbo_lora_prompt_and_timestamp_targets_match_oracle():
     """BASELINE configs[4] shape: large-v3-turbo (32 encoder / 4 decoder layers, 128 mels), LoRA r=16 alpha=32 on every
     Linear, a batch item with a prompt (targets -100 up to and including the prompt) and timestamp tokens in the target

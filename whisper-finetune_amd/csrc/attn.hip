@@ -309,10 +309,8 @@ extern "C" void wft_fwd_dbg_read(unsigned long long* host, int reset) {
 // (s_waitcnt vmcnt(0)) in front of the first ds_read_b64_tr of each tile, which cut the prefetch distance to
 // half a tile and left the kernel latency-bound (no-load experiment: +27 %).
 #if FWD_ABL == 9  // (occupancy experiment: three workgroups per CU = three waves per SIMD, <= 168 registers)
-template <bool PRE>
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnP p) {
 #else
-template <bool PRE>  // PRE: q_prescaled — c is the literal 1, the c-multiplies fold away
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
 #endif
   __shared__ __attribute__((aligned(16))) char smem[3 * 16384];  // [slot 3][K 8K | V 8K]
@@ -328,11 +326,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   const unsigned short* qrow = p.q + (long)b * p.q_bs + (long)qc * p.ldq + hd * 64;
   const unsigned short* kb = p.k + (long)b * p.k_bs + hd * 64;
   const unsigned short* vb = p.v + (long)b * p.v_bs + hd * 64;
-#if FWD_PRE_MODE == 1
+  // (q_prescaled: c = 1.0 at run time.  A template instantiation without the multiplies measured 1 % SLOWER — 1 417 -> 1 432 us per
+  // encoder call at 87 clips, three runs; the compiler's schedule, not the instruction count, decides here: profiles/r06_attn_prescale.md)
   const float c = p.c;
-#else
-  const float c = PRE ? 1.0f : p.c;
-#endif
   bf16x8 qf[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) qf[s] = att_load_reg_frag(qrow, s, h);
@@ -526,6 +522,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
 }
 
 
+// Round 6: the softmax's vector section of the pipelined forward kernel runs at raised wave priority (s_setprio 1).  Two waves of
+// DIFFERENT workgroups share a SIMD at an arbitrary phase; the arbiter is oldest-first, so without it the wave that is in its exponentials
+// keeps losing issue slots to its partner's MFMA issue and both drift into phase.  Measured, alternating, three runs (encoder call at 87
+// clips, prescaled q): 1 508 / 1 517 / 1 500 us -> 1 477 / 1 468 / 1 504 (-1.7 %); priority on the MFMA clusters instead: +-0.
+// No arithmetic changes: bit-identical outputs (tests/test_attn_fwd_pipe_gpu.py).
+#define FWD_PRIO_MFMA_ON
+#define FWD_PRIO_MFMA_OFF
+#define FWD_PRIO_VALU_ON __builtin_amdgcn_s_setprio(1)
+#define FWD_PRIO_VALU_OFF __builtin_amdgcn_s_setprio(0)
 // ------------------------------------------------------------------------------ forward, software-pipelined (round 5)
 // The ablation builds of attn_fwd_kernel (FWD_ABL, profiles/r05_attn_fwd.md) behave like a SUM of their parts: taking out the S
 // MFMAs saves 29 % of the kernel, the softmax's vector work 24 %, the P.V MFMAs 11 %, the LDS-DMA staging 13 %, the V^T reads
@@ -538,7 +543,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
 //                 K(kt+2) fragment reads | P.V(kt) MFMAs
 // Same arithmetic in the same order as attn_fwd_kernel (the stale maximum that enters S(kt+1) as its initial accumulator is the
 // one softmax(kt) has just settled, exactly what the un-pipelined kernel uses at the head of tile kt+1): bit-identical results.
-template <bool PRE>
 __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(AttnP p) {
   __shared__ __attribute__((aligned(16))) char smem[4 * 16384];  // [slot 4][K 8K | V 8K]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -553,11 +557,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(AttnP p) {
   const unsigned short* qrow = p.q + (long)b * p.q_bs + (long)qc * p.ldq + hd * 64;
   const unsigned short* kb = p.k + (long)b * p.k_bs + hd * 64;
   const unsigned short* vb = p.v + (long)b * p.v_bs + hd * 64;
-#if FWD_PRE_MODE == 1
+  // (q_prescaled: c = 1.0 at run time.  A template instantiation without the multiplies measured 1 % SLOWER — 1 417 -> 1 432 us per
+  // encoder call at 87 clips, three runs; the compiler's schedule, not the instruction count, decides here: profiles/r06_attn_prescale.md)
   const float c = p.c;
-#else
-  const float c = PRE ? 1.0f : p.c;
-#endif
   bf16x8 qf[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) qf[s] = att_load_reg_frag(qrow, s, h);
@@ -659,12 +661,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(AttnP p) {
         for (int e = 0; e < 16; ++e) minit[e] = -m;
       }
       float ls0 = 0.f, ls1 = 0.f;
+      FWD_PRIO_VALU_ON;
 #pragma unroll
       for (int kb2 = 0; kb2 < 2; ++kb2)
 #pragma unroll
         for (int e = 0; e < 16; e += 2) {
-          f32x2 sc = f32x2{sacc[kb2][e], sacc[kb2][e + 1]};
-          if constexpr (!PRE) sc = sc * c;  // (one v_pk_mul_f32 per pair: hipcc leaves the scalar form unpacked)
+          const f32x2 sc = f32x2{sacc[kb2][e], sacc[kb2][e + 1]} * c;  // (one v_pk_mul_f32 per pair: hipcc leaves the scalar form unpacked)
           const float p0 = __builtin_amdgcn_exp2f(sc[0]);
           const float p1 = __builtin_amdgcn_exp2f(sc[1]);
           ls0 += p0;
@@ -675,15 +677,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(AttnP p) {
       l += att_xhalf_sum(ls0 + ls1);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) pf[ks] = att_pack8(sacc[ks >> 1], ks & 1);
+      FWD_PRIO_VALU_OFF;
     }
     // the NEXT tile's scores: on the matrix pipe from here, consumed by the next iteration's softmax
     if (kt + 1 < nkt && is_active(kt + 1)) {
+      FWD_PRIO_MFMA_ON;
 #pragma unroll
       for (int kb2 = 0; kb2 < 2; ++kb2) {
         sacc[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb2][0], qf[0], minit, 0, 0, 0);
 #pragma unroll
         for (int s = 1; s < 4; ++s) sacc[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb2][s], qf[s], sacc[kb2], 0, 0, 0);
       }
+      FWD_PRIO_MFMA_OFF;
     }
     __builtin_amdgcn_sched_barrier(0);
     if (more) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
@@ -697,11 +702,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(AttnP p) {
         for (int s = 0; s < 4; ++s) kf[kb2][s] = att_row_frag(smem + NXT2 * 16384, offs, kb2, s);
     }
     if (active) {
+      FWD_PRIO_MFMA_ON;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int db = 0; db < 2; ++db)
           oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_join(vt[ks][db][0], vt[ks][db][1]), pf[ks], oacc[db], 0, 0, 0);
+      FWD_PRIO_MFMA_OFF;
     }
   };
   int kt = 0;
@@ -1128,9 +1135,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
 
 #ifndef D4_EXP
 #define D4_EXP 0  // developer timing experiments (results wrong): 1 no LDS-DMA in the loop, 2 no vector arithmetic, 3 no LDS reads, 4 no barrier
-#endif
-#ifndef FWD_PRE_MODE
-#define FWD_PRE_MODE 0  // (experiment) 1: the forward kernels keep c as a run-time value (1.0 when prescaled); only the per-score multiply is dropped
 #endif
 #define D4_ASM_MACROS ".set d4_exp, " D4_STR(D4_EXP) "\n" R"ASM(
 .macro D4_VALU ops:vararg
@@ -2204,13 +2208,8 @@ extern "C" int wft_attn_fwd_bf16(const wft_attn_args* a, void* stream) {
   AttnP p;
   attn_fill(a, p);
   dim3 grid((unsigned)(((a->Tq + 127) / 128) * a->H * a->B)), block(256);  // 1-D: see att_block_coords
-  if (wft_fwd_pipe_eligible(a)) {
-    if (p.qpre) hipLaunchKernelGGL(attn_fwd_pipe_kernel<true>, grid, block, 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(attn_fwd_pipe_kernel<false>, grid, block, 0, (hipStream_t)stream, p);
-  } else {
-    if (p.qpre) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, p);
-  }
+  if (wft_fwd_pipe_eligible(a)) hipLaunchKernelGGL(attn_fwd_pipe_kernel, grid, block, 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(attn_fwd_kernel, grid, block, 0, (hipStream_t)stream, p);
   WFT_CHECK_LAUNCH();
   return WFT_OK;
 }

@@ -1510,6 +1510,14 @@ extern "C" int wft_gemm_nt_variant(const wft_gemm_args* a) {
   return (g_nt_variant != 1 && a->variant == 0 && wft_nt4w_eligible(a)) ? 4 : 256;
 }
 
+// bytes of the fragment-ordered one-byte gelu' buffer (WFT_EPI_GELU_GRAD8 writes, WFT_EPI_MUL_AUX8 reads) if these arguments are
+// served — only gemm_nt4w_kernel carries the two epilogues — else 0: 16 KiB per (256x256 tile, wave) = one byte per tile element
+extern "C" int64_t wft_gemm_nt_aux8_bytes(const wft_gemm_args* a) {
+  if (!a || (a->epilogue != WFT_EPI_GELU_GRAD8 && a->epilogue != WFT_EPI_MUL_AUX8)) return 0;
+  if (!nt_uses_256(a) || g_nt_variant == 1 || a->variant != 0 || !wft_nt4w_eligible(a)) return 0;
+  return (int64_t)((a->M + 255) / 256) * (a->N / 256) * 65536;
+}
+
 extern "C" int64_t wft_gemm_nt_colsum_workspace_bytes(const wft_gemm_args* a) {
   if (!a || !a->colsum || a->c_is_f32 || a->batch != 1 || !nt_uses_256(a)) return 0;
   return (int64_t)2 * ((a->M + 255) / 256) * a->N * (int64_t)sizeof(float);
@@ -1524,10 +1532,15 @@ extern "C" int wft_gemm_nt_bf16(const wft_gemm_args* a, void* stream) {
   WFT_CHECK_ARG(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->B & 15) == 0 && ((uintptr_t)a->C & 15) == 0,
                 "base pointers must be 16-byte aligned");
   WFT_CHECK_ARG(!(a->accumulate && !a->c_is_f32), "accumulate needs an f32 C");
-  WFT_CHECK_ARG((a->epilogue != WFT_EPI_DGELU && a->epilogue != WFT_EPI_GELU_GRAD && a->epilogue != WFT_EPI_MUL_AUX) || a->aux,
+  const bool aux8 = a->epilogue == WFT_EPI_GELU_GRAD8 || a->epilogue == WFT_EPI_MUL_AUX8;
+  WFT_CHECK_ARG((a->epilogue != WFT_EPI_DGELU && a->epilogue != WFT_EPI_GELU_GRAD && a->epilogue != WFT_EPI_MUL_AUX && !aux8) || a->aux,
                 "DGELU / GELU_GRAD / MUL_AUX epilogues need aux");
-  WFT_CHECK_ARG((a->epilogue != WFT_EPI_GELU_GRAD && a->epilogue != WFT_EPI_MUL_AUX) || !a->c_is_f32,
+  WFT_CHECK_ARG((a->epilogue != WFT_EPI_GELU_GRAD && a->epilogue != WFT_EPI_MUL_AUX && !aux8) || !a->c_is_f32,
                 "GELU_GRAD / MUL_AUX epilogues write a bf16 C");
+  if (aux8 && wft_gemm_nt_aux8_bytes(a) == 0) {
+    wft_set_error("wft_gemm_nt_bf16: the one-byte gelu' epilogues exist on gemm_nt4w_kernel only (ask wft_gemm_nt_aux8_bytes first)");
+    return WFT_ERR_UNSUPPORTED;
+  }
   WFT_CHECK_ARG(a->M < (1ll << 31) && a->N < (1ll << 31) && a->K < (1ll << 31), "dims exceed int32");
   GemmP p;
   fill_params(a, p);

@@ -393,11 +393,19 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmP p) {
   desc_of(t, cur);
   unsigned first = 1;
   constexpr bool RD_AUX = (EPI == WFT_EPI_MUL_AUX), WR_AUX = (EPI == WFT_EPI_GELU_GRAD);
+  // ONE-BYTE gelu' (round 6): aux is not a [M, N] bf16 matrix but 16 KiB per (tile, wave) in FRAGMENT order — the 16 bytes a lane
+  // holds for X fragment fx and W fragment pair up (columns 32 (2 up) + 8 q .. +7 and 32 (2 up + 1) + 8 q .. +7 of row 16 fx + mr) at
+  // ((tile * 4 + wave) * 16 + up * 8 + fx) * 1024 + lane * 16.  Every store / load instruction moves one contiguous KiB (8 whole lines);
+  // the writer (fc1's forward GEMM) and the reader (fc2's backward-data GEMM) have the same M, N and therefore the same tiles.
+  // Code q = round(200 g') + 26: a grid of 1/200 on which gelu' = 0 and gelu' = 1 (saturated units) are exact, range [-0.13, 1.145]
+  // (gelu' lies in [-0.129, 1.129]), |error| <= 0.0025.  Halves the second output's bytes on the per-CU memory path that prices these
+  // two epilogue variants (profiles/README.md §3) and one byte per MLP activation element of saved-for-backward memory.
+  constexpr bool RD_AUX8 = (EPI == WFT_EPI_MUL_AUX8), WR_AUX8 = (EPI == WFT_EPI_GELU_GRAD8);
   constexpr bool has_res = RES;  // (a residual operand; MUL_AUX reads aux instead)
   // vector-memory operations every wave issues per tile AFTER the K loop (a lower bound: the column-sum stores are not counted):
   // 32 stores of C, 32 of aux (GELU_GRAD), 32 loads of aux (MUL_AUX), 32 loads of the residual.  They are buffer operations
   // bounded by the tile's valid rows: no row masks, no branches, so the count holds on ragged tiles too.
-  const unsigned nops = nt4w_sgpr(32u + (RD_AUX || WR_AUX ? 32u : 0u) + (has_res ? 32u : 0u));
+  const unsigned nops = nt4w_sgpr(32u + (RD_AUX || WR_AUX ? 32u : 0u) + (RD_AUX8 || WR_AUX8 ? 16u : 0u) + (has_res ? 32u : 0u));
   const unsigned bgo = nt4w_sgpr((p.bias != nullptr && wave == 0) ? 1u : 0u);
   int bpar = 0;  // which bias slice this tile reads
   if (!p.bias) {  // no bias: both slices hold zeros for the whole launch (ordered before their first read by the K loop's barriers)
@@ -486,6 +494,13 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmP p) {
     if constexpr (RD_AUX || has_res) nt4w_for<0, 16>(load_o);
     const auto srdA = srd_of(WR_AUX ? p.aux + (long)bz * p.sAux + (long)m0 * p.ldaux : (const unsigned short*)p.C, (WR_AUX && p.diag != 23 && p.diag != 24) ? p.ldaux : 0);  // (DIAG 23: C and aux stores dropped, 24: aux only — timing)
     const unsigned stepA = 32u * (unsigned)p.ldaux;  // (wave-uniform by construction: no readfirstlane — it would cost a vector register across the K loop)
+    // one-byte gelu': this (tile, wave)'s 16 KiB block; lane offset 16 (lane) + 1024 (up * 8 + fx)
+    const unsigned long long a8base = nt4w_sgpr64((unsigned long long)((const char*)p.aux + (((long)bz * tiles + (long)tm * tiles_n + tn) * 4 + wave) * 16384));
+    const auto srdA8 = __builtin_amdgcn_make_buffer_rsrc((void*)a8base, (short)0, (RD_AUX8 || WR_AUX8) ? 16384 : 0, 0x00020000);
+    const unsigned offA8 = ((tid_e & 63) << 4) + after_loop;
+    u32x4 a8q[16];
+    if constexpr (RD_AUX8)
+      nt4w_for<0, 16>([&](auto ic) { constexpr int i = decltype(ic)::value; a8q[i] = __builtin_amdgcn_raw_buffer_load_b128(srdA8, offA8 + 1024u * i, 0, 0); });
     // Whole-line stores.  As they leave the MFMA a lane (q, mr) holds 16 bytes of row mr in each column chunk, so one store
     // instruction would write 16 rows x 64 B: half lines, and the CU's store path is paid per request (measured: whole lines cost
     // 27 % less, profiles/README.md round 4).  Two DPP moves per dword (row_ror:8 = lanes mr <-> mr + 8 of a 16-lane row, bank
@@ -526,6 +541,29 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmP p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) gelu_both_f(v[e], v[e], dv[e]);
             dpk[hh] = u32x4{pack2bf(dv[0], dv[1]), pack2bf(dv[2], dv[3]), pack2bf(dv[4], dv[5]), pack2bf(dv[6], dv[7])};
+          } else if constexpr (WR_AUX8) {
+            // q = round-to-nearest-even(200 g') + 26 through the fp32 magic constant 1.5 * 2^23 (+ 26): the code is the low byte of the
+            // sum's bit pattern; four codes are gathered into a dword by two v_perm_b32 and an or
+            unsigned qb[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              float dv;
+              gelu_both_f(v[e], v[e], dv);
+              qb[e] = __builtin_bit_cast(unsigned, fmaf(dv, 200.0f, 12582912.0f + 26.0f));
+            }
+            dpk[0][2 * hh] = __builtin_amdgcn_perm(qb[1], qb[0], 0x0c0c0400u) | __builtin_amdgcn_perm(qb[3], qb[2], 0x04000c0cu);
+            dpk[0][2 * hh + 1] = __builtin_amdgcn_perm(qb[5], qb[4], 0x0c0c0400u) | __builtin_amdgcn_perm(qb[7], qb[6], 0x04000c0cu);
+          } else if constexpr (RD_AUX8) {
+            const u32x4 a4 = a8q[up * 8 + fx];
+            const unsigned w0 = a4[2 * hh], w1 = a4[2 * hh + 1];  // ((float)((w >> 8 k) & 255) compiles to v_cvt_f32_ubyte<k>)
+            v[0] *= fmaf((float)((w0 >> 0) & 0xffu), 0.005f, -0.13f);
+            v[1] *= fmaf((float)((w0 >> 8) & 0xffu), 0.005f, -0.13f);
+            v[2] *= fmaf((float)((w0 >> 16) & 0xffu), 0.005f, -0.13f);
+            v[3] *= fmaf((float)((w0 >> 24) & 0xffu), 0.005f, -0.13f);
+            v[4] *= fmaf((float)((w1 >> 0) & 0xffu), 0.005f, -0.13f);
+            v[5] *= fmaf((float)((w1 >> 8) & 0xffu), 0.005f, -0.13f);
+            v[6] *= fmaf((float)((w1 >> 16) & 0xffu), 0.005f, -0.13f);
+            v[7] *= fmaf((float)((w1 >> 24) & 0xffu), 0.005f, -0.13f);
           } else if constexpr (EPI == WFT_EPI_MUL_AUX) {
             const u32x4 a4 = opq[o & 15];
 #pragma unroll
@@ -552,6 +590,7 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmP p) {
           }
         });
         if constexpr (WR_AUX) store_pair(srdA, offAL + fx * stepA + 128u * up, stepA >> 1, dpk[0], dpk[1]);
+        if constexpr (WR_AUX8) __builtin_amdgcn_raw_buffer_store_b128(dpk[0], srdA8, offA8 + 1024u * (up * 8 + fx), 0, NT4W_ST_AUX);
         if (p.diag == 30) {  // (A/B: half-line stores, default cache policy — the first form of this epilogue)
           __builtin_amdgcn_raw_buffer_store_b128(pk[0], srdC, offC + fx * stepC + 128u * up, 0, 0);
           __builtin_amdgcn_raw_buffer_store_b128(pk[1], srdC, offC + fx * stepC + 128u * up + 64u, 0, 0);
@@ -589,11 +628,13 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmP p) {
 // multiple of 128 and >= 256 (the k loop is unrolled in k-step pairs around a two-step head and tail), 32-bit offsets inside a
 // 256-row tile of every operand.
 bool wft_nt4w_eligible(const wft_gemm_args* a) {
-  const bool epi_ok = a->epilogue == WFT_EPI_NONE || ((a->epilogue == WFT_EPI_GELU_GRAD || a->epilogue == WFT_EPI_MUL_AUX) && !a->residual);
-  if (a->colsum && a->epilogue != WFT_EPI_MUL_AUX) return false;  // (fused column sums exist for the fc2 backward-data product only)
+  const bool aux8 = a->epilogue == WFT_EPI_GELU_GRAD8 || a->epilogue == WFT_EPI_MUL_AUX8;
+  const bool epi_ok = a->epilogue == WFT_EPI_NONE || ((a->epilogue == WFT_EPI_GELU_GRAD || a->epilogue == WFT_EPI_MUL_AUX || aux8) && !a->residual);
+  if (a->colsum && a->epilogue != WFT_EPI_MUL_AUX && a->epilogue != WFT_EPI_MUL_AUX8) return false;  // (fused column sums exist for the fc2 backward-data product only)
+  if (aux8 && (a->batch != 1 || a->alpha != 1.f)) return false;
   return epi_ok && !a->c_is_f32 && !a->accumulate && a->K % 128 == 0 && a->K >= 256 && a->N % 256 == 0 && a->lda >= a->K &&
          a->valid_rows_period == 0 && !a->residual_first && 256 * a->lda * 2 < (1ll << 31) && 256 * a->ldb * 2 < (1ll << 31) &&
-         256 * a->ldc * 2 < (1ll << 31) && 256 * a->ldr * 2 < (1ll << 31) && 256 * a->ldaux * 2 < (1ll << 31);
+         256 * a->ldc * 2 < (1ll << 31) && 256 * a->ldr * 2 < (1ll << 31) && (aux8 || 256 * a->ldaux * 2 < (1ll << 31));
 }
 
 int wft_nt4w_launch(const wft_gemm_args* a, const GemmP& p, bool persistent, void* stream) {
@@ -613,6 +654,8 @@ int wft_nt4w_launch(const wft_gemm_args* a, const GemmP& p, bool persistent, voi
     case WFT_EPI_NONE: if (res) LAUNCH_4W(WFT_EPI_NONE, true, false); else LAUNCH_4W(WFT_EPI_NONE, false, false); break;
     case WFT_EPI_GELU_GRAD: LAUNCH_4W(WFT_EPI_GELU_GRAD, false, false); break;
     case WFT_EPI_MUL_AUX: if (csf) LAUNCH_4W(WFT_EPI_MUL_AUX, false, true); else LAUNCH_4W(WFT_EPI_MUL_AUX, false, false); break;
+    case WFT_EPI_GELU_GRAD8: LAUNCH_4W(WFT_EPI_GELU_GRAD8, false, false); break;
+    case WFT_EPI_MUL_AUX8: if (csf) LAUNCH_4W(WFT_EPI_MUL_AUX8, false, true); else LAUNCH_4W(WFT_EPI_MUL_AUX8, false, false); break;
     default: wft_set_error("wft_gemm_nt_bf16: unknown epilogue %d", a->epilogue); return WFT_ERR_ARG;
   }
 #undef LAUNCH_4W

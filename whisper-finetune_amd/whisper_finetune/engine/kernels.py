@@ -284,7 +284,11 @@ def gemm_nt(a, b, *, M=None, N=None, K=None, lda=None, ldb=None, out=None, out_f
     if residual is not None:
         _chk(residual, BF16, "residual")
         args.residual, args.ldr, args.strideR = residual.data_ptr(), (residual.stride(-2) if ldr is None else ldr), strideR
-    if aux is not None:
+    if aux is not None and epilogue in (L.EPI_GELU_GRAD8, L.EPI_MUL_AUX8):
+        # one-byte gelu' in gemm_nt4w_kernel's fragment order (wft.h): an opaque uint8 buffer of aux8_bytes(...) bytes
+        _chk(aux, torch.uint8, "aux")
+        args.aux, args.ldaux, args.strideAux = aux.data_ptr(), 0, 0
+    elif aux is not None:
         _chk(aux, BF16, "aux")
         args.aux, args.ldaux, args.strideAux = aux.data_ptr(), (aux.stride(-2) if ldaux is None else ldaux), strideAux
     args.epilogue, args.alpha, args.beta = epilogue, alpha, beta
@@ -302,6 +306,10 @@ def gemm_nt(a, b, *, M=None, N=None, K=None, lda=None, ldb=None, out=None, out_f
             args.workspace, args.workspace_bytes = ws.data_ptr(), ws.numel()
     if _args_only:  # (paired launches: gemm_nt_rank_pair)
         return args, out
+    if epilogue in (L.EPI_GELU_GRAD8, L.EPI_MUL_AUX8):
+        need = L.load().wft_gemm_nt_aux8_bytes(C.byref(args))
+        if need <= 0 or aux is None or aux.numel() < need:
+            raise L.WftError(f"one-byte gelu' epilogue: the call is not served in that form or the buffer is too small (need {need} bytes)")
     if PROFILE_NT is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
@@ -312,6 +320,20 @@ def gemm_nt(a, b, *, M=None, N=None, K=None, lda=None, ldb=None, out=None, out_f
         return out
     L.check(L.load().wft_gemm_nt_bf16(C.byref(args), L.stream_ptr()), "wft_gemm_nt_bf16")
     return out
+
+
+def gemm_nt_aux8_bytes(M: int, N: int, K: int, device, epilogue=None, colsum: bool = False) -> int:
+    """Bytes of the one-byte gelu' buffer if an [M, K] x [N, K]^T product with the GELU_GRAD8 / MUL_AUX8 epilogue is served by
+    gemm_nt4w_kernel (wft_gemm_nt_aux8_bytes), else 0.  Shapes only — the pointers are placeholders with the alignment real operands have."""
+    args = L.GemmArgs()
+    args.A = args.B = args.C = args.aux = 1 << 20
+    args.lda, args.ldb, args.ldc = K, K, N
+    args.M, args.N, args.K, args.batch, args.alpha, args.beta = M, N, K, 1, 1.0, 1.0
+    args.epilogue = L.EPI_GELU_GRAD8 if epilogue is None else epilogue
+    args.variant = VARIANT["nt"]
+    if colsum:
+        args.colsum = 1 << 20
+    return int(L.load().wft_gemm_nt_aux8_bytes(C.byref(args)))
 
 
 def gemm_tn(a, b, *, P=None, Q=None, R=None, lda=None, ldb=None, out=None, out_f32=True, accumulate=False,

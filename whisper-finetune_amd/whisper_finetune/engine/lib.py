@@ -74,7 +74,7 @@ class GemmF32Args(C.Structure):
     ]
 
 
-EPI_NONE, EPI_GELU, EPI_DGELU, EPI_GELU_GRAD, EPI_MUL_AUX = 0, 1, 2, 3, 4
+EPI_NONE, EPI_GELU, EPI_DGELU, EPI_GELU_GRAD, EPI_MUL_AUX, EPI_GELU_GRAD8, EPI_MUL_AUX8 = 0, 1, 2, 3, 4, 5, 6
 
 # name -> argtypes (restype is int unless listed in _RESTYPES); this table is also what
 # tests/test_abi.py checks against the declarations in include/wft.h.
@@ -101,6 +101,7 @@ SIGNATURES = {
     "wft_gemm_nt_variant": [C.POINTER(GemmArgs)],
     "wft_gemm_tn_segments_ok": [C.POINTER(GemmArgs)],
     "wft_gemm_nt_colsum_workspace_bytes": [C.POINTER(GemmArgs)],
+    "wft_gemm_nt_aux8_bytes": [C.POINTER(GemmArgs)],
     "wft_gemm_tn_bf16": [C.POINTER(GemmArgs), c_vp],
     "wft_gemm_nt_rank_pair_bf16": [C.POINTER(GemmArgs), C.POINTER(GemmArgs), c_vp],
     "wft_gemm_tn_rank_pair_bf16": [C.POINTER(GemmArgs), C.POINTER(GemmArgs), c_vp],
@@ -144,7 +145,7 @@ SIGNATURES = {
     "wft_version": [],
 }
 _RESTYPES = {"wft_last_error": C.c_char_p, "wft_version": C.c_char_p, "wft_layernorm_bwd_workspace": c_i64,
-             "wft_gemm_tn_workspace_bytes": c_i64, "wft_gemm_nt_colsum_workspace_bytes": c_i64, "wft_colsum_workspace_bytes": c_i64,
+             "wft_gemm_tn_workspace_bytes": c_i64, "wft_gemm_nt_colsum_workspace_bytes": c_i64, "wft_gemm_nt_aux8_bytes": c_i64, "wft_colsum_workspace_bytes": c_i64,
              "wft_attn_bwd_colsum_workspace_bytes": c_i64}
 
 _lib = None

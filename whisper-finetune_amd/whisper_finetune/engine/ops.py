@@ -591,12 +591,14 @@ def _weight_grad_homes(weights, w_need):
 
 
 class _LinearCfg:
-    __slots__ = ("group", "n_w", "has_bias", "loras", "gelu_out", "gelu_in", "out_features", "accum")
+    __slots__ = ("group", "n_w", "has_bias", "loras", "gelu_out", "gelu_in", "out_features", "accum", "gelu_next_n", "gelu_codes")
 
-    def __init__(self, group, n_w, has_bias, loras, gelu_out, gelu_in, out_features, accum=None):
+    def __init__(self, group, n_w, has_bias, loras, gelu_out, gelu_in, out_features, accum=None, gelu_next_n=0, gelu_codes=None):
         self.group, self.n_w, self.has_bias, self.loras = group, n_w, has_bias, loras
         self.gelu_out, self.gelu_in, self.out_features = gelu_out, gelu_in, out_features
         self.accum = accum
+        self.gelu_next_n = gelu_next_n  # gelu_out: out-features of the Linear that consumes the activation (0: unknown -> bf16 gelu')
+        self.gelu_codes = gelu_codes    # gelu_in: the one-byte gelu' buffer the producer returned beside `pre` (None: `pre` holds bf16 gelu')
 
 
 # WFT_LORA_PVALID=0: rank-r weight-gradient GEMMs without the p_valid shortcut (A/B runs)
@@ -607,6 +609,10 @@ _LORA_FUSED_OUT = os.environ.get("WFT_LORA_FUSED_OUT", "1") != "0"
 _LORA_PAIR = os.environ.get("WFT_LORA_PAIR", "1") != "0"
 # WFT_GELU_PAIR=0: keep the pre-activation and evaluate gelu' in the backward-data GEMM's epilogue (A/B runs)
 _GELU_PAIR = os.environ.get("WFT_GELU_PAIR", "1") != "0"
+# WFT_GELU_AUX8=0: gelu' travels as bf16 [M, N] everywhere (A/B runs).  Default: ONE BYTE per element in gemm_nt4w_kernel's fragment
+# order wherever both GEMMs of the pair run on that kernel (WFT_EPI_GELU_GRAD8 / WFT_EPI_MUL_AUX8, include/wft.h): half the bytes of
+# the pair's second tensor, 21 GiB less saved-for-backward memory at 87 clips of large-v3.
+_GELU_AUX8 = os.environ.get("WFT_GELU_AUX8", "1") != "0"
 
 
 class LinearFn(torch.autograd.Function):
@@ -639,10 +645,24 @@ class LinearFn(torch.autograd.Function):
         kpad = k
         assert x.dtype == BF16 and x.dim() == 2 and x.is_contiguous() and x.shape[1] == kpad, (x.shape, kpad)
         M = x.shape[0]
-        out_pre = None
+        out_pre = aux8 = None
         if cfg.gelu_out:
-            out_pre = torch.empty((M, npad), dtype=BF16, device=x.device)
-            y = K.gemm_nt(x, W, bias=bias, epilogue=L.EPI_GELU_GRAD if _GELU_PAIR else L.EPI_GELU, aux=out_pre, residual=residual)
+            # one-byte gelu' if this GEMM AND the backward-data GEMM of the consuming Linear ([M, next_n] x [npad, next_n]^T with the
+            # fused column sums) both run on gemm_nt4w_kernel
+            nb8 = 0
+            if _GELU_PAIR and _GELU_AUX8 and residual is None and cfg.gelu_next_n > 0:
+                nb8 = K.gemm_nt_aux8_bytes(M, npad, kpad, x.device)
+                if nb8 and not K.gemm_nt_aux8_bytes(M, npad, cfg.gelu_next_n, x.device, epilogue=L.EPI_MUL_AUX8, colsum=BIAS_GRADS[0]):
+                    nb8 = 0
+            if nb8:
+                aux8 = torch.empty(nb8, dtype=torch.uint8, device=x.device)
+                y = K.gemm_nt(x, W, bias=bias, epilogue=L.EPI_GELU_GRAD8, aux=aux8)
+                # the stand-in for the pre-activation in the autograd graph: its gradient is a dense [M, npad] tensor, its VALUES
+                # are never read (a zero-stride view of one element); the codes ride on the tensor object
+                out_pre = torch.empty(1, dtype=BF16, device=x.device).expand(M, npad)
+            else:
+                out_pre = torch.empty((M, npad), dtype=BF16, device=x.device)
+                y = K.gemm_nt(x, W, bias=bias, epilogue=L.EPI_GELU_GRAD if _GELU_PAIR else L.EPI_GELU, aux=out_pre, residual=residual)
         else:
             y = K.gemm_nt(x, W, bias=bias, residual=residual)
         ctx.cfg = cfg
@@ -653,10 +673,15 @@ class LinearFn(torch.autograd.Function):
         ctx.has_res = residual is not None
         ctx.want_cs = BIAS_GRADS[0]
         ctx.dims = (n, k, npad, kpad)
-        ctx.save_for_backward(x, gelu_pre, out_pre, *params)
+        # (gelu_pre is either the bf16 gelu' matrix or the zero-stride stand-in whose one-byte codes arrive in cfg.gelu_codes)
+        pre_codes = cfg.gelu_codes if gelu_pre is not None else None
+        ctx.pre_is_aux8 = pre_codes is not None
+        ctx.save_for_backward(x, pre_codes if pre_codes is not None else gelu_pre, None if aux8 is not None else out_pre, *params)
         if cfg.gelu_out:
             ctx.mark_non_differentiable(y)
-            return out_pre, y
+            if aux8 is not None:
+                ctx.mark_non_differentiable(aux8)
+            return out_pre, y, aux8
         return y
 
     @staticmethod
@@ -683,7 +708,8 @@ class LinearFn(torch.autograd.Function):
                 # dpre is the dy of the Linear that produced gelu_pre: its bias gradient (column sums) comes out of this
                 # GEMM's epilogue (see _publish_colsum / _fused_colsum)
                 cs = torch.empty(WT.shape[0], dtype=F32, device=dy.device) if ctx.want_cs else None
-                dpre = K.gemm_nt(dy, WT, epilogue=L.EPI_MUL_AUX if _GELU_PAIR else L.EPI_DGELU, aux=gelu_pre, colsum=cs, launch=ctx.launch)
+                epi = L.EPI_MUL_AUX8 if ctx.pre_is_aux8 else (L.EPI_MUL_AUX if _GELU_PAIR else L.EPI_DGELU)
+                dpre = K.gemm_nt(dy, WT, epilogue=epi, aux=gelu_pre, colsum=cs, launch=ctx.launch)
                 if cs is not None:
                     _publish_colsum(dpre, cs)
             elif ctx.accum is not None:  # one of several consumers of x: add into the running sum, the fork node returns it
@@ -853,11 +879,16 @@ def _bias_list(cfg, params):
     return res
 
 
-def linear(x, group: LinearGroup, weights, biases, loras=None, residual=None, gelu_out=False, gelu_pre=None, dx_accum=None):
-    """Functional front door of LinearFn. x bf16 [M, K] contiguous.  dx_accum: the GradAccum of `grad_fork(x)` (x must be that fork)."""
+def linear(x, group: LinearGroup, weights, biases, loras=None, residual=None, gelu_out=False, gelu_pre=None, dx_accum=None, gelu_next_n=0,
+           gelu_codes=None):
+    """Functional front door of LinearFn. x bf16 [M, K] contiguous.  dx_accum: the GradAccum of `grad_fork(x)` (x must be that fork).
+    gelu_out -> (pre, act, codes): `pre` stands for the pre-activation in the autograd graph (its values are gelu'(pre) in bf16, or —
+    codes is not None — nothing at all: a zero-stride stand-in, the derivative travels as one byte per element in `codes`); hand both to the
+    consuming Linear as gelu_pre / gelu_codes.  gelu_next_n (with gelu_out): out-features of that consumer — lets the pair use the
+    one-byte form when both of its GEMMs qualify."""
     loras = list(loras) if loras is not None else [None] * len(weights)
     cfg = _LinearCfg(group, len(weights), tuple(b is not None for b in biases), tuple(loras), gelu_out,
-                     gelu_pre is not None, sum(w.shape[0] for w in weights), dx_accum)
+                     gelu_pre is not None, sum(w.shape[0] for w in weights), dx_accum, int(gelu_next_n), gelu_codes)
     params = list(weights) + [b for b in biases if b is not None]
     params += [s.A for s in loras if s is not None] + [s.B for s in loras if s is not None]
     return LinearFn.apply(x, residual, gelu_pre, cfg, *params)
