@@ -252,7 +252,9 @@ class Case:
             self.net = DDP(self.model, device_ids=[local_rank], output_device=local_rank, broadcast_buffers=False,
                            gradient_as_bucket_view=True, bucket_cap_mb=rt.ddp_bucket_cap_mb(self.model), find_unused_parameters=sd > 0)
         self.t_cfg = {"mixed_precision_training": True, "mp_dtype": "bf16", "accum_grad_steps": 1, "max_grad_norm": 1.0,
-                      "label_smoothing": 0.1, "is_lora_run": False}
+                      "label_smoothing": 0.1, "is_lora_run": False,
+                      # (A/B hook: WFT_DEFER_LOSS=0 puts the reference's synchronous loss.item() back in front of the optimizer step)
+                      "wft_defer_loss_readback": os.environ.get("WFT_DEFER_LOSS", "1") != "0"}
 
     def mode(self):
         return (("LoRA r=16 alpha=32 p=0.1" if self.lora else "full fine-tune") + (", Muon+AuxAdam" if self.muon else ", AdamW")

@@ -252,6 +252,37 @@ def test_train_step_loss_sequence_decreases_and_matches_first_step():
     assert last < first - 0.05
 
 
+def test_deferred_loss_readback_returns_the_same_floats():
+    """train_step reads the micro-batch losses back through pinned slots behind an event AFTER it has enqueued clip + optimizer
+    (the reference's `loss.item()` at model/model_utils.py:73 sits in front of them): same returned values, same parameters, bit for
+    bit, as the synchronous read-back (`wft_defer_loss_readback: False`), with accumulation 3."""
+    from whisper_finetune.model.optimizer import WftAdamW
+
+    dims, params, audio, y_in, y_out = _tiny_case(B=2, S=12)
+    mels = [K.logmel((audio * (1 + 0.1 * i)).to(DEV), O.mel_filters(dims.n_mels).to(DEV)) for i in range(3)]
+
+    def run(defer):
+        m = _engine(dims, params)
+        opt = WftAdamW(m.parameters(), lr=2e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.1)
+        sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: 1.0)
+        t_cfg = {"mixed_precision_training": True, "accum_grad_steps": 3, "max_grad_norm": 1.0, "mp_dtype": "bf16", "label_smoothing": 0.1,
+                 "wft_defer_loss_readback": defer}
+
+        def batches():
+            i = 0
+            while True:
+                yield mels[i % 3], y_in.to(DEV), y_out.to(DEV)
+                i += 1
+
+        it = batches()
+        return [model_utils.train_step(m, it, opt, sched, t_cfg) for _ in range(3)], [p.detach().clone() for p in m.parameters()]
+
+    l1, p1 = run(True)
+    l0, p0 = run(False)
+    assert l1 == l0 and all(isinstance(v, float) for v in l1)
+    assert all(torch.equal(a, b) for a, b in zip(p1, p0))
+
+
 def test_loss_curve_parity_with_the_cpu_oracle_over_optimizer_steps():
     """configs[0]-shaped loss-curve parity: 4 optimizer steps of train_step (accumulation 2, label smoothing, clip 1.0,
     AdamW) on the engine with the libwft optimizer vs the SAME steps on the fp32 CPU oracle with torch.optim.AdamW +

@@ -534,8 +534,10 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmP p) {
           float v[8];
           v[0] = nt4w_acc<i0>(); v[1] = nt4w_acc<i0 + 1>(); v[2] = nt4w_acc<i0 + 2>(); v[3] = nt4w_acc<i0 + 3>();
           v[4] = nt4w_acc<i1>(); v[5] = nt4w_acc<i1 + 1>(); v[6] = nt4w_acc<i1 + 2>(); v[7] = nt4w_acc<i1 + 3>();
+          if constexpr (!RD_AUX8) {  // (the one-byte backward-data form has alpha = 1 and no bias by contract: wft_nt4w_eligible)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { v[e] = v[e] * p.alpha + b0[e]; v[4 + e] = v[4 + e] * p.alpha + b1[e]; }
+            for (int e = 0; e < 4; ++e) { v[e] = v[e] * p.alpha + b0[e]; v[4 + e] = v[4 + e] * p.alpha + b1[e]; }
+          }
           if constexpr (EPI == WFT_EPI_GELU_GRAD) {
             float dv[8];
 #pragma unroll
@@ -556,14 +558,16 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmP p) {
           } else if constexpr (RD_AUX8) {
             const u32x4 a4 = a8q[up * 8 + fx];
             const unsigned w0 = a4[2 * hh], w1 = a4[2 * hh + 1];  // ((float)((w >> 8 k) & 255) compiles to v_cvt_f32_ubyte<k>)
-            v[0] *= fmaf((float)((w0 >> 0) & 0xffu), 0.005f, -0.13f);
-            v[1] *= fmaf((float)((w0 >> 8) & 0xffu), 0.005f, -0.13f);
-            v[2] *= fmaf((float)((w0 >> 16) & 0xffu), 0.005f, -0.13f);
-            v[3] *= fmaf((float)((w0 >> 24) & 0xffu), 0.005f, -0.13f);
-            v[4] *= fmaf((float)((w1 >> 0) & 0xffu), 0.005f, -0.13f);
-            v[5] *= fmaf((float)((w1 >> 8) & 0xffu), 0.005f, -0.13f);
-            v[6] *= fmaf((float)((w1 >> 16) & 0xffu), 0.005f, -0.13f);
-            v[7] *= fmaf((float)((w1 >> 24) & 0xffu), 0.005f, -0.13f);
+            // decode + multiply on value PAIRS: two v_cvt_f32_ubyte, one v_pk_fma_f32, one v_pk_mul_f32 per pair
+            const f32x2 k5 = f32x2{0.005f, 0.005f}, k13 = f32x2{-0.13f, -0.13f};
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+              const unsigned w = e < 4 ? w0 : w1;
+              const f32x2 qf = f32x2{(float)((w >> (8 * (e & 3))) & 0xffu), (float)((w >> (8 * (e & 3) + 8)) & 0xffu)};
+              const f32x2 gd = __builtin_elementwise_fma(qf, k5, k13);
+              const f32x2 pr = f32x2{v[e], v[e + 1]} * gd;
+              v[e] = pr[0]; v[e + 1] = pr[1];
+            }
           } else if constexpr (EPI == WFT_EPI_MUL_AUX) {
             const u32x4 a4 = opq[o & 15];
 #pragma unroll

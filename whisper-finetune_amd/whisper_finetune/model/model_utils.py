@@ -70,6 +70,13 @@ def train_step(
     device = next(model.parameters()).device
     graphed = _graphed_micro_batch(model, t_config, mixed, amp_dtype, label_smoothing, accum, scaler)
     total_loss = 0.0
+    # The reference reads every micro-batch loss back with `loss.item()` (model/model_utils.py:73) — a host sync in front of clip +
+    # optimizer.step(), whose Python (pointer tables over 1 259 tensors) then runs while the GPU idles: 4 ms per headline step
+    # (bench.py hand_rolled_ms_per_step).  On a HIP device without a GradScaler the value is copied to a pinned slot behind an
+    # event instead; the clip / optimizer / scheduler / zero_grad launches are enqueued, and only then does the host wait — for
+    # the EVENT, i.e. for the backward pass, not for the optimizer kernels.  Same returned float, same order of additions.
+    defer = device.type == "cuda" and scaler is None and t_config.get("wft_defer_loss_readback", True)
+    pending = []
     for micro in range(accum):
         last = micro == accum - 1
         for attempt in range(3):
@@ -79,7 +86,10 @@ def train_step(
                 y_in = y_in.to(device, non_blocking=True)
                 y_out = y_out.to(device, non_blocking=True)
                 if graphed is not None:  # training.wft_hip_graph: forward + loss + backward as ONE graph launch (engine/graph.py)
-                    total_loss += graphed(x, y_in, y_out).item()
+                    if defer:
+                        pending.append(_async_readback(graphed(x, y_in, y_out), device, micro, accum))
+                    else:
+                        total_loss += graphed(x, y_in, y_out).item()
                     break
                 # the backward pass that runs beside the bucketed all-reduce gets per-tile launches: the mode is noted by the autograd
                 # nodes while the forward runs on this thread and handed to their backward kernels per call (runtime.exchange_launch_mode)
@@ -88,7 +98,10 @@ def train_step(
                     with torch.autocast(device_type=device.type, enabled=mixed, dtype=amp_dtype):
                         loss = _micro_batch_loss(model, x, y_in, y_out, label_smoothing) / accum
                     (scaler.scale(loss) if scaler else loss).backward()
-                total_loss += loss.item()
+                if defer:
+                    pending.append(_async_readback(loss.detach(), device, micro, accum))
+                else:
+                    total_loss += loss.item()
                 break
             except RuntimeError as err:
                 # the reference retries sporadic illegal-memory-access errors 3x on one GPU and
@@ -133,7 +146,27 @@ def train_step(
     # (graph mode: the captured backward adds into persistent gradient buffers — zeroed in place, never dropped; this holds for
     # every later step of a model that has captured graphs, also one that runs eagerly)
     optimizer.zero_grad(set_to_none=graphed is None and not _has_graphs(model))
+    for slot, ev in pending:  # (in micro-batch order: the reference's order of additions)
+        ev.synchronize()
+        total_loss += slot.item()
     return total_loss
+
+
+_READBACK = {}  # (device index, accum) -> pinned f32 [accum]
+
+
+def _async_readback(loss: Tensor, device, micro: int, accum: int):
+    """-> (pinned one-element view that will hold `loss`, event behind the copy).  The slots of one optimizer step are distinct; the
+    next step reuses them after its predecessor has read them."""
+    key = (device.index, accum)
+    buf = _READBACK.get(key)
+    if buf is None:
+        buf = _READBACK[key] = torch.empty(accum, dtype=torch.float32, pin_memory=True)
+    slot = buf[micro:micro + 1]
+    slot.copy_(loss.reshape(1).float(), non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return slot, ev
 
 
 def _has_graphs(model) -> bool:
