@@ -34,7 +34,12 @@ from whisper_finetune.model.optimizer import get_optimizer  # noqa: E402
 DEV = torch.device("cuda:0")
 EMU_FLOOR, EMU_MED = 2e-2, 1.5e-2   # vs the bf16-emulating oracle (+ 2 cond per tensor)
 F32_FLOOR, F32_MED = 3e-2, 2.5e-2   # vs the fp32 oracle
-ALLOW_CAP = 0.35                    # no tensor may be further than this from either oracle, whatever its conditioning
+# No tensor may be further than this from either oracle, whatever its conditioning (1.5 x the measured maximum per
+# role class).  The decoder's self-attention q / k projections and their adapters — the ill-conditioned class: 0.195 (full fine-tune) and
+# 0.249 (rank-16 adapters) measured against the emulated oracle in round 6 — keep 0.35; every other tensor gets ALLOW_CAP_OTHER.
+ALLOW_CAP = 0.35
+ALLOW_CAP_OTHER = 0.10              # 1.5 x 0.063, the round-6 maximum over all five tests of this file (rank-16 adapters of the LoRA + Muon
+#                                     configuration; full fine-tune 0.048, B = 2 0.055, whisper-small 0.020, whisper-medium 0.029)
 
 
 def rel(a, b):
@@ -96,8 +101,14 @@ def _check(got, emu, f32, tag, emu_med=EMU_MED, f32_med=F32_MED):
     _report(e_f32, tag + " gpu vs fp32")
     # (the allowance is capped: a sign / scale slip moves a tensor by 50-100 % and must not hide behind 3 cond on the worst-
     # conditioned q / k tensors — VERDICT r3 item 7)
+    ill = re.compile(r"decoder\.blocks\.\d+\.attn\.(query|key)\.")
+    cap_of = lambda n: ALLOW_CAP if ill.search(n) else ALLOW_CAP_OTHER
+    others = [n for n in got if not ill.search(n)]
+    if others:
+        print(f"[{tag}] largest error outside the decoder's self-attention q / k: vs emulated {max(e_emu[n] for n in others):.4f}, "
+              f"vs fp32 {max(e_f32[n] for n in others):.4f} (cap {ALLOW_CAP_OTHER})")
     bad = [(n, e_emu[n], e_f32[n], cond[n]) for n in got
-           if e_emu[n] > min(EMU_FLOOR + 3 * cond[n], ALLOW_CAP) or e_f32[n] > min(F32_FLOOR + 3 * cond[n], ALLOW_CAP)]
+           if e_emu[n] > min(EMU_FLOOR + 3 * cond[n], cap_of(n)) or e_f32[n] > min(F32_FLOOR + 3 * cond[n], cap_of(n))]
     assert not bad, sorted(bad, key=lambda t: -t[1])[:8]
     # per ROLE (one parameter name over all blocks): the median over the blocks is insensitive to the few badly conditioned
     # layers that set the per-tensor allowance above, so it gets the tight bound — a factor-2 slip in one role (a mis-scaled
@@ -229,7 +240,10 @@ def test_large_v3_full_finetune_batch_of_two_ragged_targets_matches_fp32_oracle(
     assert abs(loss.item() - loss_ref) < 2e-3 * loss_ref, (loss.item(), loss_ref)
     errs = {n: rel(got[n], p_req[n].grad) for n in got}
     _report(errs, "full-FT B=2 gpu vs fp32")
-    assert max(errs.values()) < ALLOW_CAP, sorted(errs.items(), key=lambda kv: -kv[1])[:6]
+    ill = re.compile(r"decoder\.blocks\.\d+\.attn\.(query|key)\.")
+    print(f"[full-FT B=2] largest error outside the decoder's self-attention q / k: {max(e for n, e in errs.items() if not ill.search(n)):.4f}")
+    bad = {n: e for n, e in errs.items() if e > (ALLOW_CAP if ill.search(n) else ALLOW_CAP_OTHER)}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:6]
     roles = defaultdict(list)
     for n, e in errs.items():
         roles[re.sub(r"blocks\.\d+\.", "blocks.*.", n)].append(e)
