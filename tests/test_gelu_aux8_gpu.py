@@ -156,3 +156,4 @@ def test_mlp_gradients_with_one_byte_derivative_against_fp32_math():
     assert errs[True]["y"] == errs[False]["y"]  # the forward values do not depend on the form
     for n in ref:
         assert errs[True][n] < 3e-2 and errs[True][n] <= errs[False][n] + 2e-3, (n, errs[True][n], errs[False][n])
+
