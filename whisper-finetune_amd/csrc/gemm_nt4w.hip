@@ -465,7 +465,6 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmP p) {
     // tile's last valid row: stores to rows >= M are dropped and loads return zero in hardware (the row offset is in the
     // per-lane offset, which is what the range check sees).
     const int rows = p.M - m0 < 256 ? p.M - m0 : 256;
-    const bool affine = p.alpha != 1.0f || p.bias != nullptr;  // (kernel arguments: scalar registers)
     unsigned after_loop;  // an opaque 0 defined here: offsets built on it cannot be hoisted above the K loop, where registers are scarce
     asm volatile("v_mov_b32 %0, 0" : "=v"(after_loop));
     const unsigned row_l = (unsigned)(wm * 128 + mr) + after_loop;  // + 16 fx
@@ -531,17 +530,13 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmP p) {
         nt4w_for<0, 2>([&](auto hc) {
           constexpr int hh = decltype(hc)::value, u = 2 * up + hh, o = 16 * up + 2 * fx + hh;
           constexpr int i0 = (fx * 8 + 2 * u) * 4, i1 = i0 + 4;
+          const f32x4 b0 = *(const f32x4*)(bias_l + 32 * u), b1 = *(const f32x4*)(bias_l + 32 * u + 4);
           float v[8];
           v[0] = nt4w_acc<i0>(); v[1] = nt4w_acc<i0 + 1>(); v[2] = nt4w_acc<i0 + 2>(); v[3] = nt4w_acc<i0 + 3>();
           v[4] = nt4w_acc<i1>(); v[5] = nt4w_acc<i1 + 1>(); v[6] = nt4w_acc<i1 + 2>(); v[7] = nt4w_acc<i1 + 3>();
           if constexpr (!RD_AUX8) {  // (the one-byte backward-data form has alpha = 1 and no bias by contract: wft_nt4w_eligible)
-            // round 6: alpha = 1 without a bias (every backward-data GEMM) skips the 8 multiply-adds and the two LDS reads of the bias
-            // slice — a wave-uniform scalar branch per group
-            if (EPI != WFT_EPI_NONE || affine) {  // (only the plain epilogue takes the branch: the others have a bias or no room for it)
-              const f32x4 b0 = *(const f32x4*)(bias_l + 32 * u), b1 = *(const f32x4*)(bias_l + 32 * u + 4);
 #pragma unroll
-              for (int e = 0; e < 4; ++e) { v[e] = v[e] * p.alpha + b0[e]; v[4 + e] = v[4 + e] * p.alpha + b1[e]; }
-            }
+            for (int e = 0; e < 4; ++e) { v[e] = v[e] * p.alpha + b0[e]; v[4 + e] = v[4 + e] * p.alpha + b1[e]; }
           }
           if constexpr (EPI == WFT_EPI_GELU_GRAD) {
             float dv[8];
