@@ -1651,7 +1651,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv4w_kernel(AttnP p) {
                  : [voQ0] "v"(voQ0), [voQ1] "v"(voQ1), [voD0] "v"(voD0), [voD1] "v"(voD1), [voC] "v"(voC), [voKp] "v"(nx.voKp), [voVp] "v"(nx.voVp), [rb] "v"(rb), [bK] "s"(nx.bK), [bV] "s"(nx.bV), [bQ] "s"(nx.bQ),
                    [bD] "s"(nx.bD), [bL] "s"(nx.bL), [bT] "s"(nx.bT), [tq] "s"(tq), [tk] "s"(tk), [ldk2] "s"(ldk2), [ldv2] "s"(ldv2),
                    [stQ] "s"(stQ), [stD] "s"(stD), [lds0] "s"(lds0), [wave] "s"(wv), [c] "s"(cbits)
-                 : "memory", "scc", D4_CLOBBER_S, D4_A8(13), D4_A8(14), D4_A8(15), D4_A8(16), D4_A8(17), D4_A8(18), "a128", "a129", "a190", "a191");
+                 : "memory", "scc", "v29", "v30", D4_CLOBBER_S, D4_A8(13), D4_A8(14), D4_A8(15), D4_A8(16), D4_A8(17), D4_A8(18), "a128", "a129", "a190", "a191");
   }
 #ifdef D4_STAMPS
   const unsigned long long st3b = __builtin_amdgcn_s_memtime();
@@ -1928,15 +1928,98 @@ static int attn_fill(const wft_attn_args* a, AttnP& p) {
 // a0..a159
 #define Q4_CLOBBER_A "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", D4_A8(1), D4_A8(2), D4_A8(3), D4_A8(4), D4_A8(5), D4_A8(6), D4_A8(7), D4_A8(8), D4_A8(9), D4_A8(10), D4_A8(11), D4_A8(12), D4_A8(13), D4_A8(14), D4_A8(15)
 
+// descriptors and requests shared by the main block and the prefetch block of attn_bwd_dq4w_kernel (round 6: persistent, like the dK/dV kernel)
+#define Q4_ASM_MACROS2 R"ASM(
+; descriptors: K s[40:43], V s[44:47] (tile strides s56, s57), Q s[68:71], dO s[72:75]; this wave's Q / dO transit area s53; LDS-DMA
+; destinations inside a tile buffer: piece 2 wave (s58), 2 wave + 1 (s59); buffer offsets: cur (tile T) s63, nxt (T+1) s64, ld (T+2) s65
+.macro Q4_SRD_INIT
+  s_mov_b64 s[40:41], %[bK]
+  s_lshr_b32 s61, %[stK], 6
+  s_sub_u32 s62, %[tk], 1
+  s_mul_i32 s42, s62, s61
+  s_add_u32 s42, s42, 128
+  s_mov_b32 s43, 0x20000
+  s_mov_b64 s[44:45], %[bV]
+  s_lshr_b32 s61, %[stV], 6
+  s_mul_i32 s46, s62, s61
+  s_add_u32 s46, s46, 128
+  s_mov_b32 s47, 0x20000
+  s_mov_b32 s56, %[stK]
+  s_mov_b32 s57, %[stV]
+  s_mov_b64 s[68:69], %[bQ]
+  s_sub_u32 s62, %[tq], 1
+  s_mul_i32 s70, s62, %[ldq2]
+  s_add_u32 s70, s70, 128
+  s_mov_b32 s71, 0x20000
+  s_mov_b64 s[72:73], %[bD]
+  s_mul_i32 s74, s62, %[ldd2]
+  s_add_u32 s74, s74, 128
+  s_mov_b32 s75, 0x20000
+  s_mul_i32 s53, %[wave], )ASM" D4_STR(D4_KV) R"ASM(
+  s_add_u32 s53, s53, 3*)ASM" D4_STR(Q4_BUF) R"ASM(
+  s_add_u32 s53, s53, %[lds0]
+  s_lshl_b32 s61, %[wave], 1
+  s_mul_i32 s58, s61, 1280
+  s_lshr_b32 s62, s61, 1
+  s_lshl_b32 s62, s62, 4
+  s_add_u32 s58, s58, s62
+  s_add_u32 s58, s58, %[lds0]
+  s_add_u32 s59, s58, 1344
+  s_mov_b32 s63, 0
+  s_mov_b32 s64, )ASM" D4_STR(Q4_BUF) R"ASM(
+  s_mov_b32 s65, 2*)ASM" D4_STR(Q4_BUF) R"ASM(
+.endm
+; Q / dO rows of this wave's 64 queries -> its transit area as two tiles in the piece layout (see D4_KVDMA: whole 128-byte rows by
+; LDS-DMA instead of row-per-lane fragment loads); read into a[64:127] by the main block
+.macro Q4_TRANSIT
+  .set q4_i, 0
+  .rept 8
+    s_mul_i32 s61, %[ldq2], (q4_i%%2)+4*(q4_i/2)
+    v_add_u32 v29, s61, %[voQ]
+    s_add_u32 m0, s53, q4_i*1280+64*(q4_i%%2)+16*(q4_i/2)
+    s_mul_i32 s62, %[ldd2], (q4_i%%2)+4*(q4_i/2)
+    buffer_load_dwordx4 v29, s[68:71], 0 offen lds
+    v_add_u32 v30, s62, %[voD]
+    s_add_u32 m0, s53, 10240+q4_i*1280+64*(q4_i%%2)+16*(q4_i/2)
+    s_nop 0
+    buffer_load_dwordx4 v30, s[72:75], 0 offen lds
+    .set q4_i, q4_i+1
+  .endr
+.endm
+; key tiles 0, 1 -> buffers 0, 1 (sources end up two tiles on)
+.macro Q4_STAGE2
+  Q4_STAGE s63
+  Q4_ADVANCE
+  s_nop 4
+  Q4_STAGE s64
+  Q4_ADVANCE
+.endm
+)ASM"
+#define Q4_ASM_PURGE2 R"ASM(
+.purgem Q4_SRD_INIT
+.purgem Q4_TRANSIT
+.purgem Q4_STAGE2
+)ASM"
+
+// Round 6: PERSISTENT like attn_bwd_dkdv4w_kernel — one workgroup per CU (it owns the CU: 143 KB of LDS, one wave per SIMD) walks work
+// items (batch, head, 256-query block) in XCD-local order.  One workgroup per item paid every item's cold start in full (LDS is not
+// shared between two of them, so nothing overlapped: the dK/dV kernel's stamps put a first item's prologue at 11.6 k ticks against 4.1 k
+// for a later one): here the NEXT item's Q / dO rows, its first two key tiles and its row constants (-delta, -lse / ls: the O / dO / lse
+// loads) are requested behind this item's loop and fly while its accumulators are scaled, summed and stored.
 template <bool PRE>
 __global__ __launch_bounds__(256) void attn_bwd_dq4w_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
-  int bx, hd, b;
-  att_block_coords((p.Tq + 255) >> 8, p.H, p.B, p.xcd, bx, hd, b);
-  const int qw0 = bx * 256 + wave * 64;
+  const int nqb = (p.Tq + 255) >> 8;
+  const int ngrp = p.H * p.B;
+  const bool xcd_mode = ((ngrp & 7) == 0) && p.xcd && ((gridDim.x & 7) == 0);
+  const int xcd = xcd_mode ? (int)(blockIdx.x & 7) : 0;
+  const int w0 = xcd_mode ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int wstep = xcd_mode ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+  const int nitems = (xcd_mode ? ngrp >> 3 : ngrp) * nqb;
+  if (w0 >= nitems) return;
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
   // fragment read bases in a tile buffer (layout: see attn_bwd_dkdv4w_kernel)
   const int c = r & 15, pidr = (c & 1) | ((c >> 2) << 1);
@@ -1952,41 +2035,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq4w_kernel(AttnP p) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)x), hi = __builtin_amdgcn_readfirstlane((unsigned)(x >> 32));
     return ((unsigned long long)hi << 32) | lo;
   };
-  const unsigned long long bQ = sg64((unsigned long long)(p.q + (long)b * p.q_bs + hd * 64));
-  const unsigned long long bD = sg64((unsigned long long)(p.d_o + (long)b * p.do_bs + hd * 64));
-  const unsigned long long bK = sg64((unsigned long long)(p.k + (long)b * p.k_bs + hd * 64));
-  const unsigned long long bV = sg64((unsigned long long)(p.v + (long)b * p.v_bs + hd * 64));
-  // row constants of this lane's two queries (query blocks 0 / 1 of the wave), negated; written for the dK/dV kernel
-  float nl[2], nd[2];
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    const int qi = qw0 + 32 * qb + r;
-    const int qc = qi < p.Tq ? qi : p.Tq - 1;
-    const long sidx = ((long)b * p.H + hd) * p.Tq + qc;
-    nl[qb] = -p.lse[sidx] / p.ls;
-    const unsigned short* orow = p.o + (long)b * p.o_bs + (long)qc * p.ldo + hd * 64;
-    const unsigned short* dorow = p.d_o + (long)b * p.do_bs + (long)qc * p.lddo + hd * 64;
-    float part = 0.f;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const bf16x8 of = att_load_reg_frag(orow, s, h), df = att_load_reg_frag(dorow, s, h);
-      const u32x4 ou = __builtin_bit_cast(u32x4, of), du = __builtin_bit_cast(u32x4, df);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        part += bf2f((unsigned short)(ou[e] & 0xffff)) * bf2f((unsigned short)(du[e] & 0xffff));
-        part += bf2f((unsigned short)(ou[e] >> 16)) * bf2f((unsigned short)(du[e] >> 16));
-      }
-    }
-    nd[qb] = -(part + __shfl_xor(part, 32, 64));
-    if (h == 0 && qi < p.Tq) {
-      p.delta[sidx] = nd[qb];
-      p.delta[(long)p.B * p.H * p.Tq + sidx] = nl[qb];
-    }
-  }
-  // this lane's share of Q / dO piece 0 of the wave's 64 queries (slot: query 2 (slot & 1) + 16 (slot >> 1), chunk lane & 7): byte
-  // offsets relative to the (batch, head) bases (rows past Tq load zeros)
-  const unsigned voQ = (unsigned)((qw0 + 2 * (slot & 1) + 16 * (slot >> 1)) * (int)p.ldq + ch * 8) * 2u;
-  const unsigned voD = (unsigned)((qw0 + 2 * (slot & 1) + 16 * (slot >> 1)) * (int)p.lddo + ch * 8) * 2u;
   const unsigned tq = __builtin_amdgcn_readfirstlane((unsigned)p.Tq), tk = __builtin_amdgcn_readfirstlane((unsigned)p.Tk);
   const unsigned ldq2 = __builtin_amdgcn_readfirstlane((unsigned)p.ldq * 2u), ldd2 = __builtin_amdgcn_readfirstlane((unsigned)p.lddo * 2u);
   const unsigned stK = __builtin_amdgcn_readfirstlane((unsigned)p.ldk * 128u), stV = __builtin_amdgcn_readfirstlane((unsigned)p.ldv * 128u);
@@ -1996,67 +2044,77 @@ __global__ __launch_bounds__(256) void attn_bwd_dq4w_kernel(AttnP p) {
   const unsigned cbits = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, cscale));
   const unsigned wv = (unsigned)wave;
 
-  asm volatile(".set att_pre, %c[pre]\n" Q4_ASM_MACROS R"ASM(
-    ; ---- descriptors: K s[40:43], V s[44:47] (tile strides s56, s57), Q s[68:71], dO s[72:75]
-    s_mov_b64 s[40:41], %[bK]
-    s_lshr_b32 s61, %[stK], 6
-    s_sub_u32 s62, %[tk], 1
-    s_mul_i32 s42, s62, s61
-    s_add_u32 s42, s42, 128
-    s_mov_b32 s43, 0x20000
-    s_mov_b64 s[44:45], %[bV]
-    s_lshr_b32 s61, %[stV], 6
-    s_mul_i32 s46, s62, s61
-    s_add_u32 s46, s46, 128
-    s_mov_b32 s47, 0x20000
-    s_mov_b32 s56, %[stK]
-    s_mov_b32 s57, %[stV]
-    s_mov_b64 s[68:69], %[bQ]
-    s_sub_u32 s62, %[tq], 1
-    s_mul_i32 s70, s62, %[ldq2]
-    s_add_u32 s70, s70, 128
-    s_mov_b32 s71, 0x20000
-    s_mov_b64 s[72:73], %[bD]
-    s_mul_i32 s74, s62, %[ldd2]
-    s_add_u32 s74, s74, 128
-    s_mov_b32 s75, 0x20000
-    ; Q / dO rows of this wave's 64 queries -> its transit area (s53) as two tiles in the piece layout (see D4_KVDMA: whole 128-byte
-    ; rows by LDS-DMA instead of row-per-lane fragment loads), from there into a[64:127] below
-    s_mul_i32 s53, %[wave], )ASM" D4_STR(D4_KV) R"ASM(
-    s_add_u32 s53, s53, 3*)ASM" D4_STR(Q4_BUF) R"ASM(
-    s_add_u32 s53, s53, %[lds0]
-    .set q4_i, 0
-    .rept 8
-      s_mul_i32 s61, %[ldq2], (q4_i%%2)+4*(q4_i/2)
-      v_add_u32 v29, s61, %[voQ]
-      s_add_u32 m0, s53, q4_i*1280+64*(q4_i%%2)+16*(q4_i/2)
-      s_mul_i32 s62, %[ldd2], (q4_i%%2)+4*(q4_i/2)
-      buffer_load_dwordx4 v29, s[68:71], 0 offen lds
-      v_add_u32 v30, s62, %[voD]
-      s_add_u32 m0, s53, 10240+q4_i*1280+64*(q4_i%%2)+16*(q4_i/2)
-      s_nop 0
-      buffer_load_dwordx4 v30, s[72:75], 0 offen lds
-      .set q4_i, q4_i+1
-    .endr
-    ; LDS-DMA destinations inside a buffer: piece 2 wave (s58), 2 wave + 1 (s59)
-    s_lshl_b32 s61, %[wave], 1
-    s_mul_i32 s58, s61, 1280
-    s_lshr_b32 s62, s61, 1
-    s_lshl_b32 s62, s62, 4
-    s_add_u32 s58, s58, s62
-    s_add_u32 s58, s58, %[lds0]
-    s_add_u32 s59, s58, 1344
-    ; buffer offsets: cur (tile T) s63, nxt (T+1) s64, ld (T+2) s65; loop counter s66
-    s_mov_b32 s63, 0
-    s_mov_b32 s64, )ASM" D4_STR(Q4_BUF) R"ASM(
-    s_mov_b32 s65, 2*)ASM" D4_STR(Q4_BUF) R"ASM(
-    s_sub_u32 s66, %[npair], 1
-    ; ---- tiles 0, 1
-    Q4_STAGE s63
+  // everything that depends on the work item
+  struct Item {
+    int b, hd, qw0;
+    unsigned long long bQ, bD, bK, bV;
+    unsigned voQ, voD;
+    float nl[2], nd[2];
+  };
+  auto coords = [&](int t, Item& x) {
+    const int g = xcd_mode ? (t / nqb) * 8 + xcd : t / nqb;
+    x.hd = g % p.H;
+    x.b = g / p.H;
+    x.qw0 = (t % nqb) * 256 + wave * 64;
+    x.bQ = sg64((unsigned long long)(p.q + (long)x.b * p.q_bs + x.hd * 64));
+    x.bD = sg64((unsigned long long)(p.d_o + (long)x.b * p.do_bs + x.hd * 64));
+    x.bK = sg64((unsigned long long)(p.k + (long)x.b * p.k_bs + x.hd * 64));
+    x.bV = sg64((unsigned long long)(p.v + (long)x.b * p.v_bs + x.hd * 64));
+    // this lane's share of Q / dO piece 0 of the wave's 64 queries (slot: query 2 (slot & 1) + 16 (slot >> 1), chunk lane & 7): byte
+    // offsets relative to the (batch, head) bases (rows past Tq load zeros)
+    x.voQ = (unsigned)((x.qw0 + 2 * (slot & 1) + 16 * (slot >> 1)) * (int)p.ldq + ch * 8) * 2u;
+    x.voD = (unsigned)((x.qw0 + 2 * (slot & 1) + 16 * (slot >> 1)) * (int)p.lddo + ch * 8) * 2u;
+  };
+  // row constants of this lane's two queries (query blocks 0 / 1 of the wave), negated; written for the dK/dV kernel
+  auto row_consts = [&](Item& x) {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int qi = x.qw0 + 32 * qb + r;
+      const int qc = qi < p.Tq ? qi : p.Tq - 1;
+      const long sidx = ((long)x.b * p.H + x.hd) * p.Tq + qc;
+      x.nl[qb] = -p.lse[sidx] / p.ls;
+      const unsigned short* orow = p.o + (long)x.b * p.o_bs + (long)qc * p.ldo + x.hd * 64;
+      const unsigned short* dorow = p.d_o + (long)x.b * p.do_bs + (long)qc * p.lddo + x.hd * 64;
+      float part = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 of = att_load_reg_frag(orow, s, h), df = att_load_reg_frag(dorow, s, h);
+        const u32x4 ou = __builtin_bit_cast(u32x4, of), du = __builtin_bit_cast(u32x4, df);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          part += bf2f((unsigned short)(ou[e] & 0xffff)) * bf2f((unsigned short)(du[e] & 0xffff));
+          part += bf2f((unsigned short)(ou[e] >> 16)) * bf2f((unsigned short)(du[e] >> 16));
+        }
+      }
+      x.nd[qb] = -(part + __shfl_xor(part, 32, 64));
+      if (h == 0 && qi < p.Tq) {
+        p.delta[sidx] = x.nd[qb];
+        p.delta[(long)p.B * p.H * p.Tq + sidx] = x.nl[qb];
+      }
+    }
+  };
+  Item cur;
+  coords(w0, cur);
+  row_consts(cur);
+
+  for (int t = w0; t < nitems; t += wstep) {
+  const int b = cur.b, hd = cur.hd, qw0 = cur.qw0;
+  const unsigned first = __builtin_amdgcn_readfirstlane((unsigned)(t == w0));
+  asm volatile(".set att_pre, %c[pre]\n" Q4_ASM_MACROS Q4_ASM_MACROS2 R"ASM(
+    Q4_SRD_INIT
+    s_sub_u32 s66, %[npair], 1      ; loop counter
+    s_cmp_eq_u32 %[first], 0
+    s_cbranch_scc1 2f
+    ; ---- first item of this workgroup: its Q / dO rows and key tiles 0, 1 are requested here ...
+    Q4_TRANSIT
+    Q4_STAGE2
+    s_branch 3f
+2:
+    ; ---- ... later ones found them requested by the prefetch block behind the previous item (below): only the descriptors move on
     Q4_ADVANCE
-    s_nop 4
-    Q4_STAGE s64
     Q4_ADVANCE
+    s_waitcnt vmcnt(0)
+3:
     ; ---- (under the loads) accumulators, packed dS and transposed fragments start from zero; the row constants spread out
     .set q4_i, 0
     .rept 64
@@ -2134,13 +2192,34 @@ __global__ __launch_bounds__(256) void attn_bwd_dq4w_kernel(AttnP p) {
     .endr
     s_waitcnt vmcnt(0)
     s_nop 15
-  )ASM" Q4_ASM_PURGE
+  )ASM" Q4_ASM_PURGE Q4_ASM_PURGE2
                :
-               : [rb] "v"(rb), [tb] "v"(tb), [voK0] "v"(voK0), [voK1] "v"(voK1), [voV0] "v"(voV0), [voV1] "v"(voV1), [voQ] "v"(voQ),
-                 [voD] "v"(voD), [nl0] "v"(nl[0]), [nl1] "v"(nl[1]), [nd0] "v"(nd[0]), [nd1] "v"(nd[1]), [lim0] "v"(lim0), [bK] "s"(bK),
-                 [bV] "s"(bV), [bQ] "s"(bQ), [bD] "s"(bD), [tq] "s"(tq), [tk] "s"(tk), [ldq2] "s"(ldq2), [ldd2] "s"(ldd2), [stK] "s"(stK),
-                 [stV] "s"(stV), [npair] "s"(npair), [c] "s"(cbits), [lds0] "s"(lds0), [wave] "s"(wv), [pre] "n"(PRE ? 1 : 0)
+               : [rb] "v"(rb), [tb] "v"(tb), [voK0] "v"(voK0), [voK1] "v"(voK1), [voV0] "v"(voV0), [voV1] "v"(voV1), [voQ] "v"(cur.voQ),
+                 [voD] "v"(cur.voD), [nl0] "v"(cur.nl[0]), [nl1] "v"(cur.nl[1]), [nd0] "v"(cur.nd[0]), [nd1] "v"(cur.nd[1]), [lim0] "v"(lim0),
+                 [bK] "s"(sg64(cur.bK)), [bV] "s"(sg64(cur.bV)), [bQ] "s"(sg64(cur.bQ)), [bD] "s"(sg64(cur.bD)), [tq] "s"(tq), [tk] "s"(tk), [ldq2] "s"(ldq2),
+                 [ldd2] "s"(ldd2), [stK] "s"(stK), [stV] "s"(stV), [npair] "s"(npair), [c] "s"(cbits), [lds0] "s"(lds0), [wave] "s"(wv),
+                 [first] "s"(first), [pre] "n"(PRE ? 1 : 0)
                : "memory", "vcc", "scc", Q4_CLOBBER_A, D4_CLOBBER_V, "v30", "v31", D4_CLOBBER_S);
+
+  Item nx;
+  const bool more = t + wstep < nitems;
+  if (more) {
+    // ---- prefetch block: once every wave has left the tile buffers, request the NEXT item's Q / dO rows (transit areas) and first
+    // two key tiles, then form its row constants: all of it flies while this item's accumulators are scaled, summed and stored below
+    coords(t + wstep, nx);
+    asm volatile(".set att_pre, 0\n" Q4_ASM_MACROS Q4_ASM_MACROS2 R"ASM(
+      s_barrier
+      Q4_SRD_INIT
+      Q4_TRANSIT
+      Q4_STAGE2
+    )ASM" Q4_ASM_PURGE Q4_ASM_PURGE2
+                 :
+                 : [rb] "v"(rb), [tb] "v"(tb), [c] "s"(cbits), [voK0] "v"(voK0), [voK1] "v"(voK1), [voV0] "v"(voV0), [voV1] "v"(voV1), [voQ] "v"(nx.voQ), [voD] "v"(nx.voD), [bK] "s"(sg64(nx.bK)),
+                   [bV] "s"(sg64(nx.bV)), [bQ] "s"(sg64(nx.bQ)), [bD] "s"(sg64(nx.bD)), [tq] "s"(tq), [tk] "s"(tk), [ldq2] "s"(ldq2), [ldd2] "s"(ldd2),
+                   [stK] "s"(stK), [stV] "s"(stV), [lds0] "s"(lds0), [wave] "s"(wv)
+                 : "memory", "scc", "v29", "v30", D4_CLOBBER_S);
+    row_consts(nx);
+  }
 
   // ---- epilogue: lane (r, h) holds dQ [query qw0 + 32 qb + r][d = 32 db + 8 a + 4 h + e] in register 4 a + e of (qb, db)
   auto row16 = [&](const f32x16& acc, int m, float mul) {
@@ -2183,6 +2262,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq4w_kernel(AttnP p) {
   };
   store(IntC<0>{});
   store(IntC<1>{});
+  if (more) cur = nx;
+  }  // work items of this workgroup
 }
 
 
@@ -2311,7 +2392,13 @@ extern "C" int wft_attn_bwd_bf16(const wft_attn_args* a, void* stream) {
       }
       ldsq_set[devq] = true;
     }
-    const dim3 gq((unsigned)(((a->Tq + 255) / 256) * a->H * a->B));
+    // persistent like the dK/dV kernel below: one workgroup per CU walks the (batch, head, 256-query block) items; launch_mode = 1
+    // (or WFT_ATTN_PERSISTENT=0): one item per workgroup
+    const long qitems = (long)((a->Tq + 255) / 256) * a->H * a->B;
+    long qwgs = (g_attn_persistent != 0 && a->launch_mode != 1) ? wft_num_cus() : qitems;
+    if (qwgs > qitems) qwgs = qitems;
+    if (((long)a->H * a->B) % 8 == 0 && qwgs >= 8) qwgs -= qwgs % 8;  // XCD mode needs the same number of workgroups on every XCD
+    const dim3 gq((unsigned)qwgs);
     if (p.qpre) hipLaunchKernelGGL(attn_bwd_dq4w_kernel<true>, gq, dim3(256), Q4_LDS, s, p);
     else hipLaunchKernelGGL(attn_bwd_dq4w_kernel<false>, gq, dim3(256), Q4_LDS, s, p);
   } else {
