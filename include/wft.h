@@ -256,6 +256,12 @@ int wft_gemm_nt_variant(const wft_gemm_args* args);
  * well-formed segment list), 0 if the caller has to use C and copy.  Pure host function.                                    */
 int wft_gemm_tn_segments_ok(const wft_gemm_args* args);
 int64_t wft_gemm_nt_colsum_workspace_bytes(const wft_gemm_args* args);
+/* Split-K form of the 128-tile kernel (round 6): bytes of fp32 partial tiles [nsplit][M][N] if a PLAIN bf16 product (batch 1, no bias /
+ * residual / epilogue / colsum) has so few output tiles and so deep a K that the library would split K over the idle CUs when given
+ * `workspace` of at least this size (the tied-embedding backward-data product of a short decoder batch, dX[B*S, d] = dlogits[B*S, V] E[V, d],
+ * whisper.model.TextDecoder.forward's logits matmul reached from model_utils.py:83-84: 1 024 x 512 x 51 968 runs on 32 of 256 CUs
+ * unsplit).  0: the call is not split.  Partials are summed in split order: bitwise reproducible.  Pure host function.          */
+int64_t wft_gemm_nt_splitk_workspace_bytes(const wft_gemm_args* args);
 /* Size of the one-byte gelu' buffer of WFT_EPI_GELU_GRAD8 / WFT_EPI_MUL_AUX8 for these arguments, or 0 if the call would not be
  * served in that form (not a gemm_nt4w_kernel problem).  Pure host function.                                                */
 int64_t wft_gemm_nt_aux8_bytes(const wft_gemm_args* args);

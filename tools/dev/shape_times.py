@@ -1,6 +1,6 @@
 """Developer script (GPU box): where one headline step's kernel time goes BY SHAPE — every libwft wrapper call of one steady-state
 train_step bracketed by HIP events on the launch stream (serialised: the numbers are per-call device times, not overlapped time).
-    python tools/dev/shape_times.py [batch]"""
+    python tools/dev/shape_times.py [batch] [model]"""
 import collections
 import sys
 from pathlib import Path
@@ -15,7 +15,7 @@ from whisper_finetune.engine import kernels as K  # noqa: E402
 
 
 class A:
-    model = "large-v3"
+    model = sys.argv[2] if len(sys.argv) > 2 else "large-v3"
 
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 96

@@ -21,9 +21,23 @@
 #include "gemm_common.h"
 
 // ---------------------------------------------------------------------------------- NT
-template <int EPI, bool C_F32>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
-  __shared__ __attribute__((aligned(16))) char smem[65536];  // [buf 2][A 16K | B 16K]
+template <int IMM>
+__device__ __forceinline__ bf16x8 nt_b128_asm(unsigned lds_byte_addr) {
+  bf16x8 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(lds_byte_addr), "n"(IMM));
+  return r;
+}
+// NST = 2: two k-step buffers in 64 KiB of static LDS, two workgroups per CU hide each other's load latency — the form for grids
+//   of more than one workgroup per CU.
+// NST = 4 (round 6): a ring of four k-step buffers (128 KiB of dynamic LDS, one workgroup per CU) for grids that do NOT fill the
+//   chip (a decoder block's Linears at 1 024 rows: 32 workgroups): with a single workgroup per CU the two-buffer form pays one
+//   exposed HBM/L2 latency per k-step (measured 0.8-1.5 us per k-step: 47 us for 1 024 x 512 x 2 048, 675 us for the tied-embedding
+//   backward-data product 1 024 x 512 x 51 968).  Loads run three k-steps ahead behind counted s_waitcnt vmcnt, plain s_barrier,
+//   inline-asm fragment reads (hipcc would drain the LDS-DMA queue in front of its own ds_reads).  Same products in the same order:
+//   bit-identical to NST = 2.  With p.nsplit > 1 blockIdx.z is a split of the K range (p.band k-steps each, every split non-empty)
+//   and C is the fp32 partial buffer [split][M][ldc] (host: nt_splitk_*; summed in split order by nt_splitk_reduce_kernel).
+template <int EPI, bool C_F32, int NST = 2>
+__global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm_nt_kernel(GemmP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int tiles_n = p.N >> 7;
@@ -32,8 +46,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
   const int tm = sid / tiles_n, tn = sid - tm * tiles_n;
   const int m0 = tm << 7, n0 = tn << 7;
   const int bz = blockIdx.z;
-  const unsigned short* Ab = p.A + (long)bz * p.sA;
-  const unsigned short* Bb = p.B + (long)bz * p.sB;
+  const bool ksplit = NST > 2 && p.nsplit > 1;
+  const int kb = ksplit ? bz * p.band : 0;  // first k-step of this workgroup
+  const unsigned short* Ab = ksplit ? p.A + (long)kb * 64 : p.A + (long)bz * p.sA;
+  const unsigned short* Bb = ksplit ? p.B + (long)kb * 64 : p.B + (long)bz * p.sB;
 
   // per-lane source pointers for the 4+4 staging instructions this wave issues per K-tile
   const int lr = lane >> 3, lc = lane & 7;
@@ -47,50 +63,114 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
     asrc[j] = Ab + (long)gm * p.lda + ((lc ^ lr) << 3);
     bsrc[j] = Bb + (long)(n0 + row) * p.ldb + ((lc ^ lr) << 3);
   }
-  auto stage = [&](int buf, int kt) {
-    char* sa = smem + buf * 32768 + wave * 4096;
-    char* sb = sa + 16384;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      glds16(asrc[j] + kt * 64, sa + j * 1024);
-      glds16(bsrc[j] + kt * 64, sb + j * 1024);
-    }
-  };
-
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.K >> 6;
-  stage(0, 0);
-  __syncthreads();
+  const int nk_all = p.K >> 6;
+  const int nk = ksplit ? ((kb + p.band <= nk_all) ? p.band : nk_all - kb) : nk_all;
   const int frow = lane & 15, fg = lane >> 4, sw = lane & 7;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-    const char* sa = smem + cur * 32768 + (wm * 64 + frow) * 128;
-    const char* sb = smem + cur * 32768 + 16384 + (wn * 64 + frow) * 128;
+  if constexpr (NST == 2) {
+    __shared__ __attribute__((aligned(16))) char smem[65536];  // [buf 2][A 16K | B 16K]
+    auto stage = [&](int buf, int kt) {
+      char* sa = smem + buf * 32768 + wave * 4096;
+      char* sb = sa + 16384;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        glds16(asrc[j] + kt * 64, sa + j * 1024);
+        glds16(bsrc[j] + kt * 64, sb + j * 1024);
+      }
+    };
+    stage(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+      const char* sa = smem + cur * 32768 + (wm * 64 + frow) * 128;
+      const char* sb = smem + cur * 32768 + 16384 + (wn * 64 + frow) * 128;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int coff = ((s * 4 + fg) ^ sw) << 4;
+        bf16x8 af[4], bfr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(sa + i * 2048 + coff);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(sb + j * 2048 + coff);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  } else {
+    extern __shared__ __attribute__((aligned(16))) char dsmem[];  // [slot NST][A 16K | B 16K]
+    int ld_slot = 0, ld_k = 0;
+    auto stage = [&]() {
+      char* sa = dsmem + ld_slot * 32768 + wave * 4096;
+      char* sb = sa + 16384;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        glds16(asrc[j] + ld_k * 64, sa + j * 1024);
+        glds16(bsrc[j] + ld_k * 64, sb + j * 1024);
+      }
+      ++ld_k;
+      if (++ld_slot == NST) ld_slot = 0;
+    };
+    // fragment addresses inside a slot: the k half s flips chunk bit 2 (an XOR with the lane's swizzle: one base per half)
+    const unsigned lds0 = lds_addr_of(dsmem);
+    unsigned aoff[2], boff[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      const int coff = ((s * 4 + fg) ^ sw) << 4;
-      bf16x8 af[4], bfr[4];
+      const unsigned coff = (unsigned)(((s * 4 + fg) ^ sw) << 4);
+      aoff[s] = (unsigned)((wm * 64 + frow) * 128) + coff;
+      boff[s] = 16384u + (unsigned)((wn * 64 + frow) * 128) + coff;
+    }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(sa + i * 2048 + coff);
+    for (int u = 0; u < NST - 1; ++u)
+      if (u < nk) stage();
+    int rd_slot = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      // k-step kt has landed when at most the younger k-steps' loads (8 per wave and k-step) are outstanding
+      const int ahead = nk - 1 - kt;
+      if (ahead >= NST - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * 8) : "memory");
+      else if (NST == 4 && ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // ... for every wave; and every wave is done reading the slot stage() refills now
+      if (kt + NST - 1 < nk) stage();
+      const unsigned sb = lds0 + rd_slot * 32768;
+      bf16x8 af[2][4], bfr[2][4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(sb + j * 2048 + coff);
+      for (int s = 0; s < 2; ++s) {
+        af[s][0] = nt_b128_asm<0>(sb + aoff[s]); af[s][1] = nt_b128_asm<2048>(sb + aoff[s]);
+        af[s][2] = nt_b128_asm<4096>(sb + aoff[s]); af[s][3] = nt_b128_asm<6144>(sb + aoff[s]);
+        bfr[s][0] = nt_b128_asm<0>(sb + boff[s]); bfr[s][1] = nt_b128_asm<2048>(sb + boff[s]);
+        bfr[s][2] = nt_b128_asm<4096>(sb + boff[s]); bfr[s][3] = nt_b128_asm<6144>(sb + boff[s]);
+      }
+      // LDS reads return in order: the first half's 8 fragments are there when 8 reads are still outstanding
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[0][j], af[0][i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[1][j], af[1][i], acc[i][j], 0, 0, 0);
+      if (++rd_slot == NST) rd_slot = 0;
     }
-    __syncthreads();
   }
 
   // ---- epilogue: lane holds C[m][n..n+3] per (i,j)
-  const long cb = (long)bz * p.sC;
+  const long cb = ksplit ? (long)bz * p.M * p.ldc : (long)bz * p.sC;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + wm * 64 + i * 16 + frow;
@@ -1475,6 +1555,7 @@ static int fill_params(const wft_gemm_args* a, GemmP& p) {
   p.band = g_nt256_band;
   p.ws = nullptr;
   p.cs_part = nullptr;
+  p.nsplit = 1;
   return 0;
 }
 
@@ -1498,6 +1579,42 @@ __global__ __launch_bounds__(256) void nt_colsum_reduce_kernel(const float* part
   }
 }
 
+static bool nt_uses_256(const wft_gemm_args* a);
+// C[m][n] = bf16(sum over splits, in split order, of ws[split][m][n]): finishes the split-K form of the 128-tile NT kernel
+__global__ __launch_bounds__(256) void nt_splitk_reduce_kernel(const float* ws, int nsplit, int M, int N, unsigned short* C, long ldc) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;  // one thread per 4 consecutive columns
+  const int n4 = N >> 2;
+  if (i >= (long)M * n4) return;
+  const int m = (int)(i / n4), n = (int)(i - (long)m * n4) << 2;
+  const float* src = ws + (long)m * N + n;
+  f32x4 t = *(const f32x4*)src;
+  for (int k = 1; k < nsplit; ++k) t += *(const f32x4*)(src + (long)k * M * N);
+  const u32x2 pk = {pack2bf(t[0], t[1]), pack2bf(t[2], t[3])};
+  *(u32x2*)(C + (long)m * ldc + n) = pk;
+}
+// 128-tile NT problems whose grid leaves most CUs idle over a deep K (the tied-embedding backward-data product of a short decoder
+// batch: 1 024 x 512 x 51 968 = 32 tiles of 812 k-steps): K is split over the idle CUs, fp32 partial tiles go to the caller's
+// workspace and are summed in split order (bitwise reproducible).  Plain products only, and not N = 128: those are the rank-r adapter
+// products, which stay bit-identical to their p_valid form (gemm_nt_rank_kernel).  Returns the split count (1 = unsplit).
+static int nt_splitk_plan(const wft_gemm_args* a, int* per_out) {
+  if (a->c_is_f32 || a->batch != 1 || a->epilogue != WFT_EPI_NONE || a->bias || a->residual || a->aux || a->colsum ||
+      a->valid_rows_period != 0 || a->p_valid != 0 || a->N % 128 != 0 || a->N == 128 || g_diag == 11 || g_diag == 12)
+    return 1;
+  const long tiles = ((a->M + 127) / 128) * (a->N / 128), nk = a->K / 64;
+  const int ncu = wft_num_cus();
+  if (tiles * 4 > ncu || nk < 64) return 1;
+  long nsplit = ncu / tiles;
+  if (nsplit > nk / 16) nsplit = nk / 16;
+  const long per = (nk + nsplit - 1) / nsplit;
+  *per_out = (int)per;
+  return (int)((nk + per - 1) / per);  // (no empty split)
+}
+extern "C" int64_t wft_gemm_nt_splitk_workspace_bytes(const wft_gemm_args* a) {
+  if (!a || nt_uses_256(a)) return 0;
+  int per = 0;
+  const int ns = nt_splitk_plan(a, &per);
+  return ns > 1 ? (int64_t)ns * a->M * a->N * 4 : 0;
+}
 static bool nt_uses_256(const wft_gemm_args* a) {
   const bool wide_ok = a->c_is_f32 || (a->ldc % 8 == 0 && (!a->residual || (a->ldr % 8 == 0 && ((uintptr_t)a->residual & 15) == 0)) &&
                                        (!a->aux || (a->ldaux % 8 == 0 && ((uintptr_t)a->aux & 15) == 0)) &&
@@ -1623,6 +1740,47 @@ extern "C" int wft_gemm_nt_bf16(const wft_gemm_args* a, void* stream) {
   }
   const long tiles = ((a->M + 127) / 128) * (a->N / 128);
   dim3 grid((unsigned)tiles, 1, (unsigned)a->batch), block(256);
+  // a grid of at most one workgroup per CU: the four-buffer ring form (one exposed load latency per CALL instead of one per
+  // k-step; WFT_GEMM_DIAG=11 keeps the two-buffer form for A/B runs)
+  const bool ring = tiles * a->batch <= wft_num_cus() && g_diag != 11;
+#define LAUNCH_NT_RING(E, F)                                                       \
+  do {                                                                             \
+    auto kfn = gemm_nt_kernel<E, F, 4>;                                            \
+    static DynLdsOnce once;                                                        \
+    if (!once.set(kfn, 131072)) return WFT_ERR_LAUNCH;                             \
+    hipLaunchKernelGGL(kfn, grid, block, 131072, s, p);                            \
+  } while (0)
+  if (ring) {
+    int per = 0;
+    const int ns = nt_splitk_plan(a, &per);
+    if (ns > 1 && a->workspace && a->workspace_bytes >= (int64_t)ns * a->M * a->N * 4 && (((uintptr_t)a->workspace) & 15) == 0) {
+      GemmP ps = p;  // fp32 partial tiles [split][M][N]; alpha is applied to every partial (linear)
+      ps.C = a->workspace; ps.ldc = a->N; ps.accumulate = 0; ps.nsplit = ns; ps.band = per;
+      grid.z = (unsigned)ns;
+      {
+        auto kfn = gemm_nt_kernel<WFT_EPI_NONE, true, 4>;
+        static DynLdsOnce once;
+        if (!once.set(kfn, 131072)) return WFT_ERR_LAUNCH;
+        hipLaunchKernelGGL(kfn, grid, block, 131072, s, ps);
+      }
+      hipLaunchKernelGGL(nt_splitk_reduce_kernel, dim3((unsigned)((a->M * (a->N / 4) + 255) / 256)), dim3(256), 0, s,
+                         (const float*)a->workspace, ns, (int)a->M, (int)a->N, (unsigned short*)a->C, (long)a->ldc);
+      WFT_CHECK_LAUNCH();
+      return WFT_OK;
+    }
+    switch (a->epilogue) {
+      case WFT_EPI_NONE: if (a->c_is_f32) LAUNCH_NT_RING(WFT_EPI_NONE, true); else LAUNCH_NT_RING(WFT_EPI_NONE, false); break;
+      case WFT_EPI_GELU: if (a->c_is_f32) LAUNCH_NT_RING(WFT_EPI_GELU, true); else LAUNCH_NT_RING(WFT_EPI_GELU, false); break;
+      case WFT_EPI_DGELU: if (a->c_is_f32) LAUNCH_NT_RING(WFT_EPI_DGELU, true); else LAUNCH_NT_RING(WFT_EPI_DGELU, false); break;
+      case WFT_EPI_GELU_GRAD: LAUNCH_NT_RING(WFT_EPI_GELU_GRAD, false); break;
+      case WFT_EPI_MUL_AUX: LAUNCH_NT_RING(WFT_EPI_MUL_AUX, false); break;
+      default: wft_set_error("wft_gemm_nt_bf16: unknown epilogue %d", a->epilogue); return WFT_ERR_ARG;
+    }
+    WFT_CHECK_LAUNCH();
+    if (a->colsum) return wft_colsum_bf16((const wft_bf16*)a->C, a->M, a->N, a->ldc, a->colsum, 0, stream);
+    return WFT_OK;
+  }
+#undef LAUNCH_NT_RING
 #define LAUNCH_NT(E)                                                               \
   do {                                                                             \
     if (a->c_is_f32) hipLaunchKernelGGL((gemm_nt_kernel<E, true>), grid, block, 0, s, p);  \

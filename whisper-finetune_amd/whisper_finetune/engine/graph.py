@@ -7,9 +7,10 @@ model once per micro-batch with tensors of ONE shape per (batch size, decoder le
 launch.  `training.wft_hip_graph: true` makes `model_utils.train_step` route its micro-batches through `GraphedMicroBatch`.
 
 What is captured: autocast + model(x, y_in, targets=y_out, label_smoothing) / accum + backward(), on static input buffers, with
-every trainable parameter's .grad a PERSISTENT tensor the captured AccumulateGrad nodes add into — all graphs (one per input shape)
-share those buffers and gradient accumulation needs no second graph; the step zeroes them in place (`zero_grad(set_to_none=False)`)
-instead of dropping them.  What is not: the GPU front end (log-mel + SpecAugment: its spans are host draws), clipping, the
+every trainable parameter's .grad a PERSISTENT slice of one flat buffer that the graph's last node (one multi-tensor add over the
+graph-private gradient tensors its AccumulateGrad nodes adopted) adds into — all graphs (one per input shape) share those buffers
+and gradient accumulation needs no second graph; the step zeroes the flat buffer in place (one fill) instead of dropping the
+gradients.  What is not: the GPU front end (log-mel + SpecAugment: its spans are host draws), clipping, the
 optimizer and the scheduler (learning rate and bias corrections are kernel arguments that change every step).
 
 Everything whose kernel ARGUMENTS are drawn on the host per call freezes under capture, so the wrapper refuses (loudly, once, and
@@ -82,9 +83,28 @@ class GraphedMicroBatch:
 
         self._epoch0 = ops._SHADOW_EPOCH[0]
         self.device = next(model.parameters()).device
-        for p in model.parameters():  # persistent gradient buffers (see the module docstring)
-            if p.requires_grad and p.grad is None:
-                p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        # persistent gradient buffers (see the module docstring).  Round 6: slices of ONE flat fp32 buffer — the step zeroes it with
+        # one fill instead of one per parameter (245 launches per whisper-base step) — and a captured backward no longer adds into
+        # them parameter by parameter: see _capture
+        self.flat = None
+        self._views = []  # (parameter, its slice of self.flat)
+        train = [p for p in model.parameters() if p.requires_grad]
+        if train and all(p.dtype == torch.float32 and p.is_contiguous() for p in train):
+            offs, total = [], 0
+            for p in train:
+                offs.append(total)
+                total += (p.numel() + 63) // 64 * 64  # 256-byte slices: 16-byte vector accesses in the optimizer kernels
+            self.flat = torch.zeros(total, dtype=torch.float32, device=self.device)
+            for p, o in zip(train, offs):
+                v = self.flat[o:o + p.numel()].view_as(p)
+                if p.grad is not None:
+                    v.copy_(p.grad)
+                p.grad = v
+                self._views.append((p, v))
+        else:
+            for p in train:
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
 
     @property
     def model(self):
@@ -92,6 +112,13 @@ class GraphedMicroBatch:
         if m is None:
             raise RuntimeError("the model of this GraphedMicroBatch no longer exists")
         return m
+
+    def zero_grads(self, optimizer) -> None:
+        """The step's `zero_grad(set_to_none=False)`: one fill of the flat buffer while every gradient still is its slice of it."""
+        if self.flat is not None and all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in self._views):
+            self.flat.zero_()
+        else:
+            optimizer.zero_grad(set_to_none=False)
 
     def _eager(self, x, y_in, y_out):
         with torch.autocast(device_type="cuda", dtype=self.amp_dtype):
@@ -145,12 +172,41 @@ class GraphedMicroBatch:
         side.wait_stream(cur)
         sx, sy_in, sy_out = x.clone(), y_in.clone(), y_out.clone()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.stream(side):
-            with torch.cuda.graph(g, pool=self.pool, stream=side):
-                with torch.autocast(device_type="cuda", dtype=self.amp_dtype):
-                    loss = self.model(sx, sy_in, targets=sy_out, label_smoothing=self.ls) / self.accum
-                loss.backward()
-                sloss = loss.detach()
+        # A captured AccumulateGrad node that finds a .grad ADDS into it: one elementwise launch per parameter (243 of the 830 launches
+        # of a whisper-base micro-batch, 1.2 ms of its 11.6 ms of kernels).  Parameters are therefore captured WITHOUT a .grad — the
+        # node adopts the incoming gradient tensor (graph-private memory, no kernel) — and ONE multi-tensor add at the end of the graph
+        # folds those tensors into the persistent buffers.  Large 2-D weights whose weight-gradient GEMM can accumulate straight into
+        # its gradient home (ops._weight_grad_homes: the persistent buffer itself; served by the 256 x 256 kernels only) keep their
+        # .grad: nothing is added for them either way.  The others lose their home for the capture: a weight without a .grad but with
+        # a home would be OVERWRITTEN in it (the first-micro-batch mode of the eager path), not accumulated.
+        params = [p for p in self.model.parameters() if p.requires_grad and p.grad is not None]
+        kept, homes = [], []
+        for p in params:
+            h = p.__dict__.get("_wft_grad_home")
+            if h is not None and h.data_ptr() == p.grad.data_ptr() and p.dim() == 2 and min(p.shape) >= 1024 \
+                    and p.shape[0] % 256 == 0 and p.shape[1] % 256 == 0:
+                continue
+            if h is not None:
+                homes.append((p, p.__dict__.pop("_wft_grad_home")))
+            kept.append((p, p.grad))
+            p.grad = None
+        try:
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(g, pool=self.pool, stream=side):
+                    with torch.autocast(device_type="cuda", dtype=self.amp_dtype):
+                        loss = self.model(sx, sy_in, targets=sy_out, label_smoothing=self.ls) / self.accum
+                    loss.backward()
+                    sloss = loss.detach()
+                    dst = [pg for p, pg in kept if p.grad is not None]
+                    src = [p.grad for p, pg in kept if p.grad is not None]
+                    if dst:
+                        torch._foreach_add_(dst, src)
+                    del src
+        finally:
+            for p, pg in kept:
+                p.grad = pg
+            for p, h in homes:
+                p.__dict__["_wft_grad_home"] = h
         cur.wait_stream(side)
         if self.pool is None:
             self.pool = g.pool()

@@ -304,6 +304,12 @@ def gemm_nt(a, b, *, M=None, N=None, K=None, lda=None, ldb=None, out=None, out_f
         if need > 0:
             ws = _tn_workspace(a.device, need, slot="nt_colsum")
             args.workspace, args.workspace_bytes = ws.data_ptr(), ws.numel()
+    elif not out_f32 and batch == 1 and epilogue == L.EPI_NONE and K >= 4096 and N * M <= (1 << 21):
+        # few output tiles over a deep K (the tied-embedding backward-data product of a short decoder batch): split-K partials
+        need = L.load().wft_gemm_nt_splitk_workspace_bytes(C.byref(args))
+        if need > 0:
+            ws = _tn_workspace(a.device, need, slot="nt_splitk")
+            args.workspace, args.workspace_bytes = ws.data_ptr(), ws.numel()
     if _args_only:  # (paired launches: gemm_nt_rank_pair)
         return args, out
     if epilogue in (L.EPI_GELU_GRAD8, L.EPI_MUL_AUX8):

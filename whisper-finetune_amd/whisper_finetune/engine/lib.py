@@ -101,6 +101,7 @@ SIGNATURES = {
     "wft_gemm_nt_variant": [C.POINTER(GemmArgs)],
     "wft_gemm_tn_segments_ok": [C.POINTER(GemmArgs)],
     "wft_gemm_nt_colsum_workspace_bytes": [C.POINTER(GemmArgs)],
+    "wft_gemm_nt_splitk_workspace_bytes": [C.POINTER(GemmArgs)],
     "wft_gemm_nt_aux8_bytes": [C.POINTER(GemmArgs)],
     "wft_gemm_tn_bf16": [C.POINTER(GemmArgs), c_vp],
     "wft_gemm_nt_rank_pair_bf16": [C.POINTER(GemmArgs), C.POINTER(GemmArgs), c_vp],
@@ -145,7 +146,7 @@ SIGNATURES = {
     "wft_version": [],
 }
 _RESTYPES = {"wft_last_error": C.c_char_p, "wft_version": C.c_char_p, "wft_layernorm_bwd_workspace": c_i64,
-             "wft_gemm_tn_workspace_bytes": c_i64, "wft_gemm_nt_colsum_workspace_bytes": c_i64, "wft_gemm_nt_aux8_bytes": c_i64, "wft_colsum_workspace_bytes": c_i64,
+             "wft_gemm_tn_workspace_bytes": c_i64, "wft_gemm_nt_colsum_workspace_bytes": c_i64, "wft_gemm_nt_splitk_workspace_bytes": c_i64, "wft_gemm_nt_aux8_bytes": c_i64, "wft_colsum_workspace_bytes": c_i64,
              "wft_attn_bwd_colsum_workspace_bytes": c_i64}
 
 _lib = None

@@ -145,7 +145,10 @@ def train_step(
         lr_scheduler.step()
     # (graph mode: the captured backward adds into persistent gradient buffers — zeroed in place, never dropped; this holds for
     # every later step of a model that has captured graphs, also one that runs eagerly)
-    optimizer.zero_grad(set_to_none=graphed is None and not _has_graphs(model))
+    if graphed is not None:
+        graphed.zero_grads(optimizer)
+    else:
+        optimizer.zero_grad(set_to_none=not _has_graphs(model))
     for slot, ev in pending:  # (in micro-batch order: the reference's order of additions)
         ev.synchronize()
         total_loss += slot.item()
