@@ -103,3 +103,36 @@ def test_nt_split_k_is_for_plain_low_occupancy_products_only():
     ref = a.float().cpu() @ b.float().cpu().t() + bias.cpu()
     got = K.gemm_nt(a, b, bias=bias)   # a bias: the unsplit ring kernel
     assert (got.float().cpu() - ref).abs().max() <= 1e-2 * ref.abs().max()
+
+
+def test_ring_tn_is_bit_identical_to_the_two_buffer_kernel():
+    """Unsplit (short reductions: fewer than eight steps), the same output columns computed alone (6 tiles: ring) and inside a
+    product of 260 tiles (two-buffer kernel): bit for bit, ragged reduction length included."""
+    g = torch.Generator().manual_seed(11)
+    for R in (437, 64, 130):
+        a = bf(torch.randn(R, 256, generator=g)).to(DEV); b = bf(torch.randn(R, 384, generator=g)).to(DEV)
+        wide = b.repeat(1, 44)[:, :128 * 130].contiguous()
+        small = K.gemm_tn(a, b)
+        big = K.gemm_tn(a, wide)
+        assert torch.equal(small, big[:, :384]), R
+        ref = a.float().cpu().t() @ b.float().cpu()
+        assert (small.cpu() - ref).abs().max() <= 1e-5 * ref.abs().max()
+
+
+@pytest.mark.parametrize("R,P,Q", [(1024, 512, 512), (1000, 512, 2048), (12000, 1536, 512), (12000, 512, 512), (4097, 384, 640), (250, 256, 128),
+                                   (1, 256, 256)])
+def test_ring_tn_split_matches_fp32_and_is_reproducible(R, P, Q):
+    g = torch.Generator().manual_seed(R + P)
+    a = bf(torch.randn(R, P, generator=g)).to(DEV); b = bf(torch.randn(R, Q, generator=g)).to(DEV)
+    ref = a.double().t() @ b.double()
+    out = K.gemm_tn(a, b)
+    assert (out.double() - ref).abs().max() <= 2e-5 * ref.abs().max()
+    assert torch.equal(out, K.gemm_tn(a, b))
+    base = torch.randn(P, Q, generator=g).to(DEV)
+    acc = K.gemm_tn(a, b, out=base.clone(), accumulate=True, alpha=0.5)
+    assert (acc.double() - (base.double() + 0.5 * ref)).abs().max() <= 2e-5 * ref.abs().max()
+    # batched reduction (conv-style: several [R, *] items summed into one product)
+    if R >= 64 and R % 2 == 0:
+        h = R // 2
+        both = K.gemm_tn(a, b, R=h, batch=2, strideA=h * P, strideB=h * Q)
+        assert (both.double() - ref).abs().max() <= 2e-5 * ref.abs().max()

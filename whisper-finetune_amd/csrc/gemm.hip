@@ -688,9 +688,14 @@ __device__ __forceinline__ int tn_f(int r) { return (r & 3) | (((r >> 3) & 1) <<
 
 // PB > 0: only the first 16*PB (<= 64) columns of A are non-zero (a rank-r LoRA operand in its 128-wide padded buffer): the
 // wave column wp = 1 and the p-blocks >= PB of wp = 0 skip their fragment reads and MFMAs (their part of C is written as zero).
-template <bool C_F32, int PB = 0>
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmP p) {
-  __shared__ __attribute__((aligned(16))) char smem[65536];  // [buf 2][A 16K | B 16K]
+// NST = 2: two reduction-step buffers in 64 KiB of static LDS, two workgroups per CU (grids of more than one workgroup per CU).
+// NST = 4 (round 6, PB = 0): a ring of four buffers in 128 KiB of dynamic LDS for grids of at most one workgroup per CU — a decoder
+//   block's weight gradients at R = B*S = 1 024 rows are 16-64 tiles of 16 reduction steps, and the two-buffer form pays an exposed
+//   load latency per step there (26 us for 512 x 512 x 1 024, whatever the tile count).  Loads run three steps ahead behind counted
+//   s_waitcnt vmcnt, plain s_barrier, inline-asm transposed reads.  Same products in the same order: bit-identical per split.
+template <bool C_F32, int PB = 0, int NST = 2>
+__global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm_tn_kernel(GemmP p) {
+  static_assert(NST == 2 || PB == 0, "the ring form is the general kernel only");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wq = wave >> 1, wp = wave & 1;
   const int P = p.M, Q = p.N, R = p.K;
@@ -711,104 +716,216 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmP p) {
   const int nsteps = s_end - s_begin;
   if (nsteps <= 0) return;
 
-  // staging: instruction i (0..15) covers r rows 4i..4i+3; lane -> (rr = lane>>4, c' = lane&15)
-  const int rr = lane >> 4, cp = lane & 15;
-  auto stage = [&](int buf, int step) {
-    const int b = step / tpb, t = step - b * tpb;
-    const unsigned short* Ab = p.A + (long)b * p.sA;
-    const unsigned short* Bb = p.B + (long)b * p.sB;
-    char* sa = smem + buf * 32768 + wave * 4096;
-    char* sb = sa + 16384;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int i = wave * 4 + j;
-      const int r = i * 4 + rr;
-      int gr = t * 64 + r;
-      gr = gr < R ? gr : R - 1;
-      const int c = cp ^ (tn_f(r) << 1);
-      // rank-r operand: only its first 2*PB 16-byte chunks per row are ever read back (the other LDS slots keep stale bytes)
-      if (PB == 0 || c < 2 * PB) glds16(Ab + (long)gr * p.lda + p0 + (c << 3), sa + j * 1024);
-      glds16(Bb + (long)gr * p.ldb + q0 + (c << 3), sb + j * 1024);
-    }
-  };
-  auto zero_tail = [&](int buf, int step) {
-    const int t = step % tpb;
-    const int rem = R - t * 64;  // valid rows in this tile
-    if (rem >= 64) return false;
-    // rows [rem, 64) of both tiles -> 0 ; 16 chunks of 16 B per row per operand
-    char* base = smem + buf * 32768;
-    const int nchunk = (64 - rem) * 16;
-    for (int c = tid; c < nchunk; c += 256) {
-      const int off = (rem * 16 + c) * 16;
-      *(u32x4*)(base + off) = u32x4{0, 0, 0, 0};
-      *(u32x4*)(base + 16384 + off) = u32x4{0, 0, 0, 0};
-    }
-    return true;
-  };
-
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  stage(0, s_begin);
-  __syncthreads();
-  if (zero_tail(0, s_begin)) __syncthreads();
+  char* ep_lds;
+  if constexpr (NST == 2) {
+    __shared__ __attribute__((aligned(16))) char smem[65536];  // [buf 2][A 16K | B 16K]
+    ep_lds = smem;
+    // staging: instruction i (0..15) covers r rows 4i..4i+3; lane -> (rr = lane>>4, c' = lane&15)
+    const int rr = lane >> 4, cp = lane & 15;
+    auto stage = [&](int buf, int step) {
+      const int b = step / tpb, t = step - b * tpb;
+      const unsigned short* Ab = p.A + (long)b * p.sA;
+      const unsigned short* Bb = p.B + (long)b * p.sB;
+      char* sa = smem + buf * 32768 + wave * 4096;
+      char* sb = sa + 16384;
+  #pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = wave * 4 + j;
+        const int r = i * 4 + rr;
+        int gr = t * 64 + r;
+        gr = gr < R ? gr : R - 1;
+        const int c = cp ^ (tn_f(r) << 1);
+        // rank-r operand: only its first 2*PB 16-byte chunks per row are ever read back (the other LDS slots keep stale bytes)
+        if (PB == 0 || c < 2 * PB) glds16(Ab + (long)gr * p.lda + p0 + (c << 3), sa + j * 1024);
+        glds16(Bb + (long)gr * p.ldb + q0 + (c << 3), sb + j * 1024);
+      }
+    };
+    auto zero_tail = [&](int buf, int step) {
+      const int t = step % tpb;
+      const int rem = R - t * 64;  // valid rows in this tile
+      if (rem >= 64) return false;
+      // rows [rem, 64) of both tiles -> 0 ; 16 chunks of 16 B per row per operand
+      char* base = smem + buf * 32768;
+      const int nchunk = (64 - rem) * 16;
+      for (int c = tid; c < nchunk; c += 256) {
+        const int off = (rem * 16 + c) * 16;
+        *(u32x4*)(base + off) = u32x4{0, 0, 0, 0};
+        *(u32x4*)(base + 16384 + off) = u32x4{0, 0, 0, 0};
+      }
+      return true;
+    };
 
-  const int g = lane >> 4, li = lane & 15;
-  const int r_in = (li >> 2);               // row within the 4-row block
-  const int fsw = (r_in | ((g & 1) << 2)) << 1;  // tn_f(r) << 1 for r = 32s + 8g + 4t + r_in
-  const int colq = wq * 64 + 4 * (li & 3);  // + iq*16
-  const int colp = wp * 64 + 4 * (li & 3);  // + jp*16
-  constexpr int NPB = PB > 0 ? PB : 4;      // p-blocks this wave multiplies
-  const bool idle = PB > 0 && wp == 1;      // wave-uniform
-  for (int step = 0; step < nsteps; ++step) {
-    const int cur = step & 1;
-    if (step + 1 < nsteps) stage(cur ^ 1, s_begin + step + 1);
-    const char* sa = smem + cur * 32768;
-    const char* sb = sa + 16384;
-    if (!idle) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      s16x8 qf[4], pf[NPB];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int r = 32 * s + 8 * g + 4 * t + r_in;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int cq = colq + i * 16;
-          const int aq = r * 256 + (((cq >> 3) ^ fsw) << 4) + ((cq & 7) << 1);
-          const s16x4 x = lds_read_tr16(sb + aq);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) qf[i][4 * t + e] = x[e];
-          if (i < NPB) {
-            const int cpp = colp + i * 16;
-            const int ap = r * 256 + (((cpp >> 3) ^ fsw) << 4) + ((cpp & 7) << 1);
-            const s16x4 y = lds_read_tr16(sa + ap);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) pf[i][4 * t + e] = y[e];
+    stage(0, s_begin);
+    __syncthreads();
+    if (zero_tail(0, s_begin)) __syncthreads();
+
+    const int g = lane >> 4, li = lane & 15;
+    const int r_in = (li >> 2);               // row within the 4-row block
+    const int fsw = (r_in | ((g & 1) << 2)) << 1;  // tn_f(r) << 1 for r = 32s + 8g + 4t + r_in
+    const int colq = wq * 64 + 4 * (li & 3);  // + iq*16
+    const int colp = wp * 64 + 4 * (li & 3);  // + jp*16
+    constexpr int NPB = PB > 0 ? PB : 4;      // p-blocks this wave multiplies
+    const bool idle = PB > 0 && wp == 1;      // wave-uniform
+    for (int step = 0; step < nsteps; ++step) {
+      const int cur = step & 1;
+      if (step + 1 < nsteps) stage(cur ^ 1, s_begin + step + 1);
+      const char* sa = smem + cur * 32768;
+      const char* sb = sa + 16384;
+      if (!idle) {
+  #pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        s16x8 qf[4], pf[NPB];
+  #pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int r = 32 * s + 8 * g + 4 * t + r_in;
+  #pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int cq = colq + i * 16;
+            const int aq = r * 256 + (((cq >> 3) ^ fsw) << 4) + ((cq & 7) << 1);
+            const s16x4 x = lds_read_tr16(sb + aq);
+  #pragma unroll
+            for (int e = 0; e < 4; ++e) qf[i][4 * t + e] = x[e];
+            if (i < NPB) {
+              const int cpp = colp + i * 16;
+              const int ap = r * 256 + (((cpp >> 3) ^ fsw) << 4) + ((cpp & 7) << 1);
+              const s16x4 y = lds_read_tr16(sa + ap);
+  #pragma unroll
+              for (int e = 0; e < 4; ++e) pf[i][4 * t + e] = y[e];
+            }
           }
         }
+  #pragma unroll
+        for (int i = 0; i < 4; ++i)
+  #pragma unroll
+          for (int j = 0; j < NPB; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(bf16x8, qf[i]), __builtin_bit_cast(bf16x8, pf[j]), acc[i][j], 0, 0, 0);
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NPB; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-              __builtin_bit_cast(bf16x8, qf[i]), __builtin_bit_cast(bf16x8, pf[j]), acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+      if (step + 1 < nsteps) {
+        if (zero_tail(cur ^ 1, s_begin + step + 1)) __syncthreads();
+      }
     }
-    }
-    __syncthreads();
-    if (step + 1 < nsteps) {
-      if (zero_tail(cur ^ 1, s_begin + step + 1)) __syncthreads();
-    }
-  }
 
+  } else {
+    extern __shared__ __attribute__((aligned(16))) char dsmem[];  // [slot NST][A 16K | B 16K]
+    ep_lds = dsmem;
+    const int rr = lane >> 4, cp = lane & 15;
+    int ld_slot = 0, ld_step = s_begin;
+    auto stage = [&]() {
+      const int b = ld_step / tpb, t = ld_step - b * tpb;
+      const unsigned short* Ab = p.A + (long)b * p.sA;
+      const unsigned short* Bb = p.B + (long)b * p.sB;
+      char* sa = dsmem + ld_slot * 32768 + wave * 4096;
+      char* sb = sa + 16384;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = (wave * 4 + j) * 4 + rr;
+        int gr = t * 64 + r;
+        gr = gr < R ? gr : R - 1;
+        const int c = cp ^ (tn_f(r) << 1);
+        glds16(Ab + (long)gr * p.lda + p0 + (c << 3), sa + j * 1024);
+        glds16(Bb + (long)gr * p.ldb + q0 + (c << 3), sb + j * 1024);
+      }
+      ++ld_step;
+      if (++ld_slot == NST) ld_slot = 0;
+    };
+    // fragment read offsets inside a slot for (s, t) = (0, 0); (s, t) adds the immediate 8192 s + 1024 t.  The 16-byte chunk of
+    // fragment i is (i ^ r_in) in bits 1-2: lane-dependent, one address register per fragment and operand
+    const int g = lane >> 4, li = lane & 15;
+    const int r_in = li >> 2;
+    const int fsw = (r_in | ((g & 1) << 2)) << 1;
+    unsigned qoff[4], poff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int cq = wq * 64 + 4 * (li & 3) + i * 16, cpp = wp * 64 + 4 * (li & 3) + i * 16;
+      const unsigned rowb = (unsigned)(8 * g + r_in) * 256u;
+      qoff[i] = 16384u + rowb + (unsigned)((((cq >> 3) ^ fsw) << 4) + ((cq & 7) << 1));
+      poff[i] = rowb + (unsigned)((((cpp >> 3) ^ fsw) << 4) + ((cpp & 7) << 1));
+    }
+    const unsigned lds0 = lds_addr_of(dsmem);
+#pragma unroll
+    for (int u = 0; u < NST - 1; ++u)
+      if (u < nsteps) stage();
+    int rd_slot = 0;
+    for (int step = 0; step < nsteps; ++step) {
+      const int ahead = nsteps - 1 - step;
+      if (ahead >= NST - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * 8) : "memory");
+      else if (NST == 4 && ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      {  // rows past R of a batch item's last step: zeros (the loads clamped them to row R - 1)
+        const int t = (s_begin + step) % tpb;
+        const int rem = R - t * 64;
+        if (rem < 64) {  // workgroup-uniform
+          char* base = dsmem + rd_slot * 32768;
+          const int nchunk = (64 - rem) * 16;
+          for (int c = tid; c < nchunk; c += 256) {
+            const int off = (rem * 16 + c) * 16;
+            *(u32x4*)(base + off) = u32x4{0, 0, 0, 0};
+            *(u32x4*)(base + 16384 + off) = u32x4{0, 0, 0, 0};
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+        }
+      }
+      if (step + NST - 1 < nsteps) stage();
+      const unsigned sb = lds0 + rd_slot * 32768;
+      unsigned qa[4], pa[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { qa[i] = sb + qoff[i]; pa[i] = sb + poff[i]; }
+      s16x4 qf[2][2][4], pf[2][2][4];  // [s][t][fragment]
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { qf[0][0][i] = tn_tr_asm<0>(qa[i]); qf[0][1][i] = tn_tr_asm<1024>(qa[i]); }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { pf[0][0][i] = tn_tr_asm<0>(pa[i]); pf[0][1][i] = tn_tr_asm<1024>(pa[i]); }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { qf[1][0][i] = tn_tr_asm<8192>(qa[i]); qf[1][1][i] = tn_tr_asm<8192 + 1024>(qa[i]); }
+      // LDS reads return in order (the counter holds 15 at most): the first half's 16 fragments are there when 8 are outstanding
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { pf[1][0][i] = tn_tr_asm<8192>(pa[i]); pf[1][1][i] = tn_tr_asm<8192 + 1024>(pa[i]); }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        if (s2 == 1) {
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        s16x8 q8[4], p8[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            q8[i][e] = qf[s2][0][i][e]; q8[i][4 + e] = qf[s2][1][i][e];
+            p8[i][e] = pf[s2][0][i][e]; p8[i][4 + e] = pf[s2][1][i][e];
+          }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, q8[i]), __builtin_bit_cast(bf16x8, p8[j]), acc[i][j], 0, 0, 0);
+      }
+      if (++rd_slot == NST) rd_slot = 0;
+    }
+    __syncthreads();  // (the epilogue stages through LDS other waves may still be reading)
+  }
+  const int g = lane >> 4, li = lane & 15;
+  constexpr int NPB = PB > 0 ? PB : 4;  // p-blocks this wave multiplied
   if (nsplit > 1) {
     // stage the wave's 64(p) x 64(q) fp32 tile through LDS (two halves of 32 p-rows, row pitch 68
     // floats) so that every atomic wave-instruction adds one contiguous 256-byte row of C
-    float* lds = (float*)(smem + wave * 16384);
+    float* lds = (float*)(ep_lds + wave * 16384);
     if (PB > 0 && p.ws) {
       // rank-r operand: the workspace holds only the 16*PB valid rows of every split, ws[split][16 PB][Q] (P == 128, p0 == 0)
       if (wp == 0) {
@@ -1826,10 +1943,27 @@ static int tn256_nsplit(const wft_gemm_args* a) {
   return (int)((nslabs + per - 1) / per);
 }
 // 128x128 path: split-K factor that fills the 512 resident-block slots (256 CUs x 2) in whole waves
+// the ring form of gemm_tn_kernel (one workgroup per CU): the general fp32 product on a grid that fits the chip once
+static bool tn128_ring(const wft_gemm_args* a) {
+  // (P = 128 is the rank-r operand's buffer width: that product stays bit-identical to its p_valid form, gemm_tn_rank_kernel)
+  // measured (tools/dev/small_gemm_time.py, two-buffer -> ring): R = 1 024: 16 tiles 19.2 -> 12.8 us, 48-64 tiles 19.1 -> 16.9-19.0;
+  // R = 12 000: 16 tiles 28.4 -> 23.8, 32 tiles 34.3 -> 32.1, but 48 / 64 tiles 41.6 -> 43.2 / 50.4 -> 52.0 (two workgroups per CU win)
+  const long tiles = (a->M / 128) * (a->N / 128), nsteps = ((a->K + 63) / 64) * a->batch;
+  return a->c_is_f32 && a->M != 128 && a->tn_col_scale == nullptr && a->tn_block_n == 0 && tiles <= wft_num_cus() &&
+         (tiles <= 32 || nsteps <= 32) && g_diag != 13;
+}
 static int tn128_nsplit(const wft_gemm_args* a) {
   if (!a->c_is_f32) return 1;
   const long tiles = (a->M / 128) * (a->N / 128);
   const long nsteps = ((a->K + 63) / 64) * a->batch;
+  if (tn128_ring(a)) {
+    // as many splits as fill the chip once, four reduction steps each at least (the ring's depth)
+    long sp = wft_num_cus() / tiles;
+    if (sp > nsteps / 4) sp = nsteps / 4;
+    if (sp < 1) sp = 1;
+    const long per = (nsteps + sp - 1) / sp;
+    return (int)((nsteps + per - 1) / per);
+  }
   int nsplit = 1;
   double best = 0.0;
   // up to 64 splits: rank-r LoRA gradients are ONE 128-wide tile row (10-40 tiles) over a 48 000+ row reduction
@@ -2006,7 +2140,12 @@ extern "C" int wft_gemm_tn_bf16(const wft_gemm_args* a, void* stream) {
   else if (pb == 2) hipLaunchKernelGGL((gemm_tn_kernel<true, 2>), grid, block, 0, s, p);
   else if (pb == 3) hipLaunchKernelGGL((gemm_tn_kernel<true, 3>), grid, block, 0, s, p);
   else if (pb == 4) hipLaunchKernelGGL((gemm_tn_kernel<true, 4>), grid, block, 0, s, p);
-  else hipLaunchKernelGGL((gemm_tn_kernel<true>), grid, block, 0, s, p);
+  else if (tn128_ring(a)) {
+    static DynLdsOnce once;
+    auto kfn = gemm_tn_kernel<true, 0, 4>;
+    if (!once.set(kfn, 131072)) return WFT_ERR_LAUNCH;
+    hipLaunchKernelGGL(kfn, grid, block, 131072, s, p);
+  } else hipLaunchKernelGGL((gemm_tn_kernel<true>), grid, block, 0, s, p);
   if (use_ws) {
     const long total = a->M * (a->N / 4);
     long g = (total + 255) / 256;
