@@ -111,7 +111,7 @@ int wft_dgelu_mul_bf16(const wft_bf16* dy, const wft_bf16* pre, wft_bf16* out, i
 /* out[c] (+)= sum_r x[r, c] — bias gradients.  x bf16 [rows, ld], out f32[cols] */
 int wft_colsum_bf16(const wft_bf16* x, int64_t rows, int64_t cols, int64_t ld,
                     float* out, int accumulate, void* stream);
-/* The same sums for LARGE inputs (rows >= 65 536) through a caller workspace of wft_colsum_workspace_bytes(rows, cols): the
+/* The same sums for LARGE inputs (rows >= 8 192; round 6, was 65 536) through a caller workspace of wft_colsum_workspace_bytes(rows, cols): the
  * rows are cut into 64 chunks summed by (column group, chunk) workgroups and folded in chunk order (fixed order, HBM rate;
  * the one-pass kernel above occupies cols / 32 workgroups only).  Falls back to wft_colsum_bf16 when the workspace is
  * missing or the input small.  Replaces: the bias gradient torch.autograd forms for nn.Conv1d in

@@ -550,7 +550,9 @@ __global__ __launch_bounds__(256) void colsum_fold_kernel(const float* part, int
 }
 #define WFT_COLSUM_CHUNKS 64
 extern "C" int64_t wft_colsum_workspace_bytes(int64_t rows, int64_t cols) {
-  return rows >= 65536 ? (int64_t)WFT_COLSUM_CHUNKS * cols * (int64_t)sizeof(float) : 0;
+  // (round 6: from 8 192 rows on, was 65 536 — the conv stem's bias gradients of a whisper-base step, 24 000 x 512, took 94 us on the
+  // 16 workgroups of the one-pass kernel)
+  return rows >= 8192 ? (int64_t)WFT_COLSUM_CHUNKS * cols * (int64_t)sizeof(float) : 0;
 }
 extern "C" int wft_colsum_bf16_ws(const wft_bf16* x, int64_t rows, int64_t cols, int64_t ld, float* out, int accumulate,
                                   void* workspace, int64_t workspace_bytes, void* stream) {
@@ -559,7 +561,8 @@ extern "C" int wft_colsum_bf16_ws(const wft_bf16* x, int64_t rows, int64_t cols,
   WFT_CHECK_ARG((((uintptr_t)x) & 15) == 0, "16-byte alignment");
   const int64_t need = wft_colsum_workspace_bytes(rows, cols);
   if (need == 0 || !workspace || workspace_bytes < need) return wft_colsum_bf16(x, rows, cols, ld, out, accumulate, stream);
-  const long per = (rows + WFT_COLSUM_CHUNKS - 1) / WFT_COLSUM_CHUNKS;
+  long per = (rows + WFT_COLSUM_CHUNKS - 1) / WFT_COLSUM_CHUNKS;
+  if (per < 256) per = 256;  // (four passes of a workgroup's 64 row lanes at least)
   const int nchunk = (int)((rows + per - 1) / per);
   hipLaunchKernelGGL(colsum_chunk_kernel, dim3((unsigned)((cols + 31) / 32), (unsigned)nchunk), dim3(256), 0, (hipStream_t)stream, x,
                      (long)rows, (long)cols, (long)ld, per, (float*)workspace);

@@ -267,13 +267,31 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* partial
   const int per = (nblocks + gridDim.y - 1) / gridDim.y;
   const int b0 = blockIdx.y * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
   float acc[3] = {0.f, 0.f, 0.f};
-  if (col < cols)
-    for (int b = b0 + wv; b < b1; b += 4) {
+  if (col < cols) {
+    int b = b0 + wv;
+    // eight partial rows' loads in flight per wave (the single-level call of small problems walks up to 128 rows per wave: one
+    // exposed load latency per row otherwise); same order of additions as the plain loop
+    for (; b + 28 < b1; b += 32) {
+      float v[8][3];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float* pp = partial + (long)(b + 4 * u) * nset * cols + col;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[u][k] = k < nset ? pp[(long)k * cols] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          if (k < nset) acc[k] += v[u][k];
+    }
+    for (; b < b1; b += 4) {
       const float* pp = partial + (long)b * nset * cols + col;
 #pragma unroll
       for (int k = 0; k < 3; ++k)
         if (k < nset) acc[k] += pp[(long)k * cols];
     }
+  }
 #pragma unroll
   for (int k = 0; k < 3; ++k) red[k][wv][cx] = acc[k];
   __syncthreads();
@@ -380,6 +398,15 @@ extern "C" int wft_layernorm_bwd(const wft_bf16* dy, const wft_bf16* x, const fl
     return WFT_OK;
   }
   const int nset = dx_colsum ? 3 : 2;
+  if (grid <= 256) {
+    // small calls (a decoder block at B*S = 1 024 rows: 38 of the 64 LayerNorm backward calls of a whisper-base step) are launch-bound:
+    // one reduce launch over the <= 256 partial rows instead of two levels (16.2 -> 13.9 us per call; from 512 partial rows on the
+    // two-level form wins: 21.6 against 26.1 us at 12 000 x 512; tools/dev/ln_time.py)
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((cols + 63) / 64, 1), dim3(256), 0, (hipStream_t)stream, (const float*)partial, grid,
+                       cols, nset, (float*)nullptr, dgamma, dbeta, dx_colsum);
+    WFT_CHECK_LAUNCH();
+    return WFT_OK;
+  }
   float* mid = (float*)partial + (long)grid * nset * cols;
   hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((cols + 63) / 64, LN_RED_CHUNKS), dim3(256), 0, (hipStream_t)stream,
                      (const float*)partial, grid, cols, nset, mid, (float*)nullptr, (float*)nullptr, (float*)nullptr);
