@@ -1,12 +1,13 @@
 #!/bin/bash
 # Run ON THE GPU BOX from the repo root:  bash profiles/collect_r06.sh <tag> [what]
-#   what = all (default) | bench | stats | pmc | lora | mfma
+#   what = all (default) | bench | stats | pmc | lora | mfma | base
 # Round 6 (headline batch 96).  Produces under gpurun_out/<tag>/ :
 #   bench.json.log            the default bench.py invocation (headline + extras: reference-YAML shapes, configs[1] / [2] / [4],
 #                             entrypoint loop)
 #   stats/                    rocprofv3 --kernel-trace --stats of the headline configuration (--no-extras)
 #   pmc_summary.json          FETCH_SIZE / WRITE_SIZE per kernel of the headline (separate --pmc passes)  -> roofline.traffic
 #   lora_stats/, lora_pmc_summary.json   the same two for BASELINE configs[2] (LoRA r16 + Muon + SD + deep SpecAugment, B = 32)
+#   base_stats/               rocprofv3 --kernel-trace --stats of BASELINE configs[1] (whisper-base, 8 clips, training.wft_hip_graph)
 #   mfma_busy.json            SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CU_CYCLES, GRBM_GUI_ACTIVE, SQ_WAVE_CYCLES, SQ_WAIT_ANY,
 #                             SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY, SQ_LDS_BANK_CONFLICT per kernel (headline), for the MFMA-pipe
 #                             utilisation of the GEMM and attention kernels (north_star: "rocprof MFMA-utilisation counters")
@@ -43,6 +44,10 @@ if want lora; then
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lora_stats -- python3 bench.py $LORA --no-roofline --steps 5 --warmup 2 > $OUT/lora_stats.log 2>&1
   pmc_pass $OUT/lora_pmc_fetch FETCH_SIZE $LORA
   pmc_pass $OUT/lora_pmc_write WRITE_SIZE $LORA
+fi
+if want base; then
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/base_stats -- python3 bench.py --model base --batch 8 --hip-graph --no-extras --no-cpu-baseline --no-roofline --steps 50 --warmup 10 > $OUT/base_stats.log 2>&1
+  tail -1 $OUT/base_stats.log | cut -c1-300
 fi
 if want mfma; then
   pmc_pass $OUT/pmc_sq1 "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY" $HEAD
