@@ -17,7 +17,7 @@ from whisper_finetune.model.optimizer import WftAdamW  # noqa: E402
 DEV = torch.device("cuda:0")
 
 
-def _run(graph: bool, accum: int, steps: int, name="tiny", save_to=None):
+def _run(graph: bool, accum: int, steps: int, name="tiny", save_to=None, drop_grads_after=None):
     dims = O.DIMS[name]
     params = O.init_params(dims, seed=4)
     m = Whisper(ModelDimensions(**vars(dims)))
@@ -43,7 +43,11 @@ def _run(graph: bool, accum: int, steps: int, name="tiny", save_to=None):
             i += 1
 
     it = batches()
-    losses = [model_utils.train_step(m, it, opt, sched, t_cfg) for _ in range(steps)]
+    losses = []
+    for i in range(steps):
+        losses.append(model_utils.train_step(m, it, opt, sched, t_cfg))
+        if drop_grads_after is not None and i == drop_grads_after:
+            opt.zero_grad(set_to_none=True)  # (what an evaluation pass between training steps may do)
     gm = G.graphed_for(m)
     if graph and save_to is not None:
         # the reference saves checkpoints from inside the loop (scripts/finetune.py:205-226 -> model_utils.save_model: deepcopy of the
@@ -118,3 +122,13 @@ def test_configurations_with_host_drawn_kernel_arguments_are_refused(capsys):
         assert model_utils.train_step(m2, gen, opt, sched, t_cfg) > 0
     out = capsys.readouterr().out
     assert out.count("stays on the eager path") == 1 and not G.has_graphs(m2)
+
+
+def test_gradients_dropped_between_steps_come_back_as_their_persistent_slices():
+    """Round 6: the graph's gradients are slices of one flat buffer, zeroed with one fill.  `zero_grad(set_to_none=True)` from outside
+    (an evaluation loop) must not detach the optimizer from them."""
+    l0, p0, _ = _run(False, 2, 7, drop_grads_after=4)
+    l1, p1, n1 = _run(True, 2, 7, drop_grads_after=4)
+    assert n1 == 2 and l0 == l1, (l0, l1)
+    for n in p0:
+        assert torch.equal(p0[n], p1[n]), n

@@ -132,6 +132,12 @@ class GraphedMicroBatch:
         from whisper_finetune.engine import ops
 
         key = (tuple(x.shape), x.dtype, tuple(y_in.shape), tuple(y_out.shape))
+        # a replay adds into the persistent slices whatever .grad says: gradients dropped meanwhile (an evaluation loop's
+        # zero_grad(set_to_none=True), a checkpoint reload) get their zeroed slice back — the optimizer reads .grad
+        for p, v in self._views:
+            if p.grad is None:
+                v.zero_()
+                p.grad = v
         ent = self.graphs.get(key)
         if ent is None:
             if len(self.graphs) >= MAX_SHAPES and self.disabled is None:
