@@ -172,6 +172,31 @@ def test_lora_low_rank_path_matches_oracle_parametrization():
     assert all(p.grad is None for n, p in m.named_parameters() if "lora" not in n)  # base stays frozen
 
 
+def test_adapted_forward_and_backward_launch_no_torch_matmul():
+    """An adapted Linear's `.weight` PROPERTY materialises W + s B A with torch ops (model/lora.py forward: merge / inspection only).
+    The training path must never touch it: round 6 found `fc2.weight.shape[0]` in the MLP doing exactly that once per block and
+    forward (57 hipBLASLt GEMMs per configs[2] step in `profiles/r06_a_lora_muon_kernel_stats.csv`)."""
+    from torch.overrides import TorchFunctionMode
+
+    dims, params, audio, y_in, y_out = _tiny_case()
+    m = Whisper(MODEL_DIMS["tiny"]); m.load_state_dict(params)
+    lora_mod.apply_lora(m, {"rank": 8, "lora_alpha": 16, "lora_dropout": 0.1})
+    m.to(DEV).train()
+    mel = O.log_mel_spectrogram(audio, dims.n_mels).to(DEV)
+    seen = []
+
+    class Spy(TorchFunctionMode):
+        def __torch_function__(self, func, types, args=(), kwargs=None):
+            if getattr(func, "__name__", "") in ("matmul", "__matmul__", "__rmatmul__", "mm", "bmm", "addmm", "baddbmm", "linear", "einsum"):
+                seen.append(func.__name__)
+            return func(*args, **(kwargs or {}))
+
+    with Spy():
+        loss = m(mel, y_in.to(DEV), targets=y_out.to(DEV), label_smoothing=0.1)
+        loss.backward()
+    assert not seen, seen
+
+
 def test_lora_dropout_mask_is_per_input_column():
     """minLoRA drops whole input columns of A (mask [1, in] shared by the batch): with a fixed mask the engine
     equals the oracle's W + s*B@(A*mask)."""

@@ -213,7 +213,7 @@ class MLP(nn.Sequential):
             return fc2(ops32.GeluFn.apply(fc1(x)), residual=residual)
         x2 = _as2d(_to_bf16(x))
         pre, act, codes = ops.linear(x2, fc1._group(), [fc1.base_weight()], [fc1.bias], [fc1.lora_spec()], gelu_out=True,
-                                     gelu_next_n=fc2.weight.shape[0])
+                                     gelu_next_n=fc2.base_weight().shape[0])  # (not fc2.weight: on an adapted Linear that property MATERIALISES W + s B A)
         y = ops.linear(act, fc2._group(), [fc2.base_weight()], [fc2.bias], [fc2.lora_spec()],
                        residual=None if residual is None else _as2d(residual), gelu_pre=pre, gelu_codes=codes)
         return y.view(shape)
