@@ -30,6 +30,9 @@ def t(fn, n=50):
     return e0.elapsed_time(e1) / n * 1e3
 
 
+if len(sys.argv) > 1 and sys.argv[1] == "dec32":  # decoder-sized products of large-v3 at B = 32
+    NT = [(4096, 1280, 1280), (4096, 1280, 5120), (4096, 1280, 3840), (4096, 1280, 2560), (4096, 2560, 1280)]
+    TN = [(4096, 1280, 1280), (4096, 1280, 5120), (4096, 3840, 1280)]
 for M, N, Kd in NT:
     a = torch.randn(M, Kd, device=dev).bfloat16(); b = torch.randn(N, Kd, device=dev).bfloat16()
     us = t(lambda: K.gemm_nt(a, b))
