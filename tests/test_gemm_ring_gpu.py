@@ -71,7 +71,7 @@ def _splitk_bytes(M, N, Kd):
     return L.load().wft_gemm_nt_splitk_workspace_bytes(C.byref(args))
 
 
-@pytest.mark.parametrize("M,N,Kd", [(1024, 512, 51968), (128, 256, 4096), (300, 384, 51968 + 64)])
+@pytest.mark.parametrize("M,N,Kd", [(1024, 512, 51968), (128, 256, 4096), (300, 384, 51968 + 64), (1024, 1280, 51968)])
 def test_nt_split_k_matches_fp32_and_is_reproducible(M, N, Kd):
     assert _splitk_bytes(M, N, Kd) > 0
     g = torch.Generator().manual_seed(M + Kd)

@@ -12,7 +12,7 @@ from whisper_finetune.engine import kernels as K  # noqa: E402
 
 dev = torch.device("cuda:0")
 NT = [(1024, 512, 512), (1024, 512, 2048), (1024, 2048, 512), (1024, 1536, 512), (1024, 512, 1536), (1024, 512, 51968), (12000, 512, 512),
-      (12000, 512, 2048), (12000, 1536, 512), (1024, 51968, 512)]
+      (12000, 512, 2048), (12000, 1536, 512), (1024, 51968, 512), (1024, 1280, 51968)]
 TN = [(1024, 512, 512), (1024, 512, 2048), (1024, 1536, 512), (1024, 2048, 512), (12000, 512, 512), (12000, 512, 2048), (12000, 1536, 512),
       (12000, 1024, 512), (1024, 51968, 512)]
 

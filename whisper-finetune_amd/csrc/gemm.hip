@@ -1719,7 +1719,7 @@ static int nt_splitk_plan(const wft_gemm_args* a, int* per_out) {
     return 1;
   const long tiles = ((a->M + 127) / 128) * (a->N / 128), nk = a->K / 64;
   const int ncu = wft_num_cus();
-  if (tiles * 4 > ncu || nk < 64) return 1;
+  if (tiles * 2 > ncu || nk < 64) return 1;  // (at least two splits' worth of idle CUs)
   long nsplit = ncu / tiles;
   if (nsplit > nk / 16) nsplit = nk / 16;
   const long per = (nk + nsplit - 1) / nsplit;
