@@ -8,10 +8,13 @@ dev = torch.device("cuda:0")
 lib = L.load()
 so = ctypes.CDLL(os.environ["WFT_LIB"])
 B, H, T = 32, 20, 1500
+TQ = int(sys.argv[1]) if len(sys.argv) > 1 else T  # (128: the cross-attention call, Tq = 128 queries over 1 500 keys)
+if len(sys.argv) > 2:
+    B = int(sys.argv[2])
 d = H * 64
 qkv = torch.randn(B, T, 3 * d, device=dev).bfloat16()
-q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
-do = torch.randn(B, T, d, device=dev).bfloat16()
+q, k, v = qkv[:, :TQ, :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+do = torch.randn(B, TQ, d, device=dev).bfloat16()
 o, lse = K.attn_fwd(q, k, v, H, False, 0.125)
 cs = (torch.empty(d, device=dev), torch.empty(d, device=dev))
 for _ in range(3): K.attn_bwd(q, k, v, o, lse, do, H, False, 0.125, colsums=cs)

@@ -66,7 +66,17 @@
 #define NT4W_T3 66
 #define NT4W_T4 84
 #endif
-#define NT4W_ASM_MACROS ".set NT4W_T1, " NT4W_STR(NT4W_T1) "\n.set NT4W_T2, " NT4W_STR(NT4W_T2) "\n.set NT4W_T3, " NT4W_STR(NT4W_T3) "\n.set NT4W_T4, " NT4W_STR(NT4W_T4) "\n" R"ASM(
+// LDS-DMA pieces of k-step t+2: W piece j in slot T1+2 + SPW j, X piece j in slot T2+2 + SPX j (round 6).  Rounds 4-5 issued them in every
+// second slot (19-33, 39-53): a piece costs the wave 100-185 issue cycles inside a phase that already carries 8 pieces and 16
+// ds_reads and 25-60 in a quiet phase (MI355X_MICROARCH.md), and sixteen of them bunched into 36 slots were a third of the k-step's
+// idle matrix-pipe time.  Spread over the k-step: +3 % (NT) / +7 % (TN) at kernel level, -3 % of the headline step.
+#ifndef NT4W_SPX
+#define NT4W_SPX 8   // X pieces in slots 39, 47, ..., 95 (measured: 6-11 within 1 %; 2 = rounds 4-5)
+#endif
+#ifndef NT4W_SPW
+#define NT4W_SPW 3   // W pieces in slots 19, 22, ..., 40 (2-4 equal; 6-12 measured 2-3 % slower than 2-4)
+#endif
+#define NT4W_ASM_MACROS ".set NT4W_T1, " NT4W_STR(NT4W_T1) "\n.set NT4W_T2, " NT4W_STR(NT4W_T2) "\n.set NT4W_T3, " NT4W_STR(NT4W_T3) "\n.set NT4W_T4, " NT4W_STR(NT4W_T4) "\n.set NT4W_SPX, " NT4W_STR(NT4W_SPX) "\n.set NT4W_SPW, " NT4W_STR(NT4W_SPW) "\n" R"ASM(
 .macro NT4W_MFMA s, z
   .if \z
     v_mfma_f32_16x16x32_bf16 a[4*((\s)%%64):4*((\s)%%64)+3], v[128+64*((\s)/64)+4*((\s)%%8):128+64*((\s)/64)+4*((\s)%%8)+3], v[160+64*((\s)/64)+4*(((\s)%%64)/8):160+64*((\s)/64)+4*(((\s)%%64)/8)+3], 0
@@ -79,7 +89,7 @@
   .if \j == 0
     s_mov_b32 m0, \m0base
   .else
-    s_add_u32 m0, m0, 1056
+    s_add_u32 m0, \m0base, 1056*\j   ; (absolute: the two operands' pieces interleave in the k-step body)
   .endif
   s_nop 0
   buffer_load_dwordx4 v[\vb+\j], s[\srd:\srd+3], 0 offen lds
@@ -101,6 +111,21 @@
 ; this wave's LDS-DMA destination in this buffer
 .macro NT4W_KSTEP z, ld, nx, vmA, vmB, rdXc, rdWc, rdXn, rdWn, mX, mW
   .set nt4w_s, 0
+  .set nt4w_iss, 0
+  ; pieces of ONE k-step issued after its last W piece (X pieces) / after its last X piece (W pieces): what is younger than "all of
+  ; k-step t+1's W" / "all of its X" besides the pieces of k-step t+2 issued so far
+  .set nt4w_xaw, 0
+  .set nt4w_wax, 0
+  .set nt4w_j, 0
+  .rept 8
+    .if (NT4W_T2+2+NT4W_SPX*nt4w_j) >= (NT4W_T1+2+NT4W_SPW*7)   ; (inside a slot the W piece is issued first)
+      .set nt4w_xaw, nt4w_xaw+1
+    .endif
+    .if (NT4W_T1+2+NT4W_SPW*nt4w_j) > (NT4W_T2+2+NT4W_SPX*7)
+      .set nt4w_wax, nt4w_wax+1
+    .endif
+    .set nt4w_j, nt4w_j+1
+  .endr
   .rept 128
     .if nt4w_s < 64
       NT4W_MFMA nt4w_s, \z
@@ -116,14 +141,14 @@
     .if nt4w_s == NT4W_T1+1
       s_barrier
     .endif
-    .if (nt4w_s >= NT4W_T1+2) && (nt4w_s < NT4W_T1+18)
-      .if ((nt4w_s-NT4W_T1) %% 2) == 0
-        .if \ld
-          NT4W_DMA (nt4w_s-NT4W_T1-2)/2, 120, 44, \mW
-        .endif
-      .else
-        ds_read_b128 v[224+4*((nt4w_s-NT4W_T1-3)/2):224+4*((nt4w_s-NT4W_T1-3)/2)+3], \rdXc offset:128*((nt4w_s-NT4W_T1-3)/2)+64
+    .if (nt4w_s >= NT4W_T1+2) && (nt4w_s < NT4W_T1+2+8*NT4W_SPW) && (((nt4w_s-NT4W_T1-2) %% NT4W_SPW) == 0)
+      .if \ld
+        NT4W_DMA (nt4w_s-NT4W_T1-2)/NT4W_SPW, 120, 44, \mW
+        .set nt4w_iss, nt4w_iss+1
       .endif
+    .endif
+    .if (nt4w_s >= NT4W_T1+3) && (nt4w_s < NT4W_T1+18) && (((nt4w_s-NT4W_T1) %% 2) == 1)
+      ds_read_b128 v[224+4*((nt4w_s-NT4W_T1-3)/2):224+4*((nt4w_s-NT4W_T1-3)/2)+3], \rdXc offset:128*((nt4w_s-NT4W_T1-3)/2)+64
     .endif
     .if nt4w_s == NT4W_T2
       s_waitcnt lgkmcnt(0)
@@ -131,12 +156,13 @@
     .if nt4w_s == NT4W_T2+1
       s_barrier
     .endif
-    .if (nt4w_s >= NT4W_T2+2) && (nt4w_s < NT4W_T2+18) && (((nt4w_s-NT4W_T2) %% 2) == 0)
+    .if (nt4w_s >= NT4W_T2+2) && (nt4w_s < NT4W_T2+2+8*NT4W_SPX) && (((nt4w_s-NT4W_T2-2) %% NT4W_SPX) == 0)
       .if \ld
-        NT4W_DMA (nt4w_s-NT4W_T2-2)/2, 112, 40, \mX
+        NT4W_DMA (nt4w_s-NT4W_T2-2)/NT4W_SPX, 112, 40, \mX
+        .set nt4w_iss, nt4w_iss+1
       .endif
     .endif
-    .if nt4w_s == NT4W_T2+18
+    .if ((NT4W_T2+2+7*NT4W_SPX >= NT4W_T1+2+7*NT4W_SPW) && (nt4w_s == NT4W_T2+4+7*NT4W_SPX)) || ((NT4W_T2+2+7*NT4W_SPX < NT4W_T1+2+7*NT4W_SPW) && (nt4w_s == NT4W_T1+4+7*NT4W_SPW))
       .if \ld
         s_add_u32 s40, s40, 128
         s_addc_u32 s41, s41, 0
@@ -146,7 +172,11 @@
     .endif
     .if \nx
       .if nt4w_s == NT4W_T3
-        s_waitcnt vmcnt(\vmA)
+        .if \ld
+          s_waitcnt vmcnt(nt4w_xaw+nt4w_iss)   ; (k-step t+1's X pieces behind its last W piece + the pieces of k-step t+2 issued so far are younger)
+        .else
+          s_waitcnt vmcnt(nt4w_xaw)   ; (nothing issued in this k-step: only k-step t+1's own later pieces are younger)
+        .endif
       .endif
       .if nt4w_s == NT4W_T3+1
         s_barrier
@@ -155,7 +185,11 @@
         ds_read_b128 v[128+4*((nt4w_s-NT4W_T3-2)/2):128+4*((nt4w_s-NT4W_T3-2)/2)+3], \rdWn offset:128*((nt4w_s-NT4W_T3-2)/2)
       .endif
       .if nt4w_s == NT4W_T4
-        s_waitcnt vmcnt(\vmB)
+        .if \ld
+          s_waitcnt vmcnt(nt4w_wax+nt4w_iss)
+        .else
+          s_waitcnt vmcnt(nt4w_wax)
+        .endif
       .endif
       .if nt4w_s == NT4W_T4+1
         s_barrier

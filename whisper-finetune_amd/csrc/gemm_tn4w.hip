@@ -38,7 +38,15 @@
 //   slots 68-83       : tr-read Q set 0 of step t+1
 //   slot  85 / 86     : vmcnt(16) / barrier                  -> step t+1's P has landed
 //   slots 87-102      : tr-read P set 0 of step t+1
-#define TN4W_ASM_MACROS R"ASM(
+// LDS-DMA pieces of step t+2: Q piece j in slot 20 + SPQ j, P piece j in slot 38 + SPP j (round 6; rounds 4-5: every second slot — see
+// the note at NT4W_SPX in gemm_nt4w.hip: the pieces' issue cost depends on how crowded their phase is)
+#ifndef TN4W_SPP
+#define TN4W_SPP 12  // P pieces in slots 38, 50, ..., 122
+#endif
+#ifndef TN4W_SPQ
+#define TN4W_SPQ 12  // Q pieces in slots 20, 32, ..., 104: one piece per six slots over the whole step (1 530 -> 1 310 us at 144 000 x 1 280 x 5 120)
+#endif
+#define TN4W_ASM_MACROS ".set TN4W_SPP, " TN4W_STR(TN4W_SPP) "\n.set TN4W_SPQ, " TN4W_STR(TN4W_SPQ) "\n" R"ASM(
 .macro TN4W_MFMA s, z
   .if \z
     v_mfma_f32_16x16x32_bf16 a[4*((\s)%%64):4*((\s)%%64)+3], v[128+64*((\s)/64)+4*((\s)%%8):128+64*((\s)/64)+4*((\s)%%8)+3], v[160+64*((\s)/64)+4*(((\s)%%64)/8):160+64*((\s)/64)+4*(((\s)%%64)/8)+3], 0
@@ -51,7 +59,7 @@
   .if \j == 0
     s_mov_b32 m0, \m0base
   .else
-    s_add_u32 m0, m0, 1056
+    s_add_u32 m0, \m0base, 1056*\j   ; (absolute: the two operands' pieces interleave in the step body)
   .endif
   s_nop 0
   buffer_load_dwordx4 v[\vb+\j], s[\srd:\srd+3], 0 offen lds
@@ -74,6 +82,20 @@
 ; one reduction step.  z: first step (accumulators start from 0); ld: issue the loads of step t+2; nx: read step t+1's fragments
 .macro TN4W_KSTEP z, ld, nx, vmA, vmB, rdPc, rdQc, rdPn, rdQn, mP, mQ
   .set tn4w_s, 0
+  .set tn4w_iss, 0
+  ; pieces of ONE step issued after its last Q piece (P pieces) / after its last P piece (Q pieces); inside a slot Q goes first
+  .set tn4w_paq, 0
+  .set tn4w_qap, 0
+  .set tn4w_j, 0
+  .rept 8
+    .if (38+TN4W_SPP*tn4w_j) >= (20+TN4W_SPQ*7)
+      .set tn4w_paq, tn4w_paq+1
+    .endif
+    .if (20+TN4W_SPQ*tn4w_j) > (38+TN4W_SPP*7)
+      .set tn4w_qap, tn4w_qap+1
+    .endif
+    .set tn4w_j, tn4w_j+1
+  .endr
   .rept 128
     .if tn4w_s < 64
       TN4W_MFMA tn4w_s, \z
@@ -92,9 +114,10 @@
     .if (tn4w_s >= 19) && (tn4w_s < 35)
       TN4W_RD tn4w_s-19, 224, \rdPc, 1
     .endif
-    .if (tn4w_s >= 20) && (tn4w_s < 36) && ((tn4w_s %% 2) == 0)
+    .if (tn4w_s >= 20) && (tn4w_s < 20+8*TN4W_SPQ) && (((tn4w_s-20) %% TN4W_SPQ) == 0)
       .if \ld
-        TN4W_DMA (tn4w_s-20)/2, 120, 44, \mQ
+        TN4W_DMA (tn4w_s-20)/TN4W_SPQ, 120, 44, \mQ
+        .set tn4w_iss, tn4w_iss+1
       .endif
     .endif
     .if tn4w_s == 36
@@ -103,19 +126,24 @@
     .if tn4w_s == 37
       s_barrier
     .endif
-    .if (tn4w_s >= 38) && (tn4w_s < 54) && ((tn4w_s %% 2) == 0)
+    .if (tn4w_s >= 38) && (tn4w_s < 38+8*TN4W_SPP) && (((tn4w_s-38) %% TN4W_SPP) == 0)
       .if \ld
-        TN4W_DMA (tn4w_s-38)/2, 112, 40, \mP
+        TN4W_DMA (tn4w_s-38)/TN4W_SPP, 112, 40, \mP
+        .set tn4w_iss, tn4w_iss+1
       .endif
     .endif
-    .if tn4w_s == 56
+    .if ((38+7*TN4W_SPP >= 20+7*TN4W_SPQ) && (tn4w_s == 40+7*TN4W_SPP+2)) || ((38+7*TN4W_SPP < 20+7*TN4W_SPQ) && (tn4w_s == 22+7*TN4W_SPQ+2))
       .if \ld
         TN4W_ADVANCE
       .endif
     .endif
     .if \nx
       .if tn4w_s == 66
-        s_waitcnt vmcnt(\vmA)
+        .if \ld
+          s_waitcnt vmcnt(tn4w_paq+tn4w_iss)   ; (step t+1's P pieces behind its last Q piece + the pieces of step t+2 issued so far are younger)
+        .else
+          s_waitcnt vmcnt(tn4w_paq)
+        .endif
       .endif
       .if tn4w_s == 67
         s_barrier
@@ -124,7 +152,11 @@
         TN4W_RD tn4w_s-68, 128, \rdQn, 0
       .endif
       .if tn4w_s == 85
-        s_waitcnt vmcnt(\vmB)
+        .if \ld
+          s_waitcnt vmcnt(tn4w_qap+tn4w_iss)
+        .else
+          s_waitcnt vmcnt(tn4w_qap)
+        .endif
       .endif
       .if tn4w_s == 86
         s_barrier
