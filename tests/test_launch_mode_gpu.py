@@ -95,5 +95,5 @@ def test_backward_beside_an_exchange_runs_per_tile_while_another_thread_stays_pe
     assert loss.item() == ref_loss.item()
     for n, p in train.named_parameters():
         if p.grad is not None:
-            assert torch.equal(p.grad, ref_grads[n]), n
+            assert torch.equal(p.grad, ref_grads[n]), (n, float((p.grad - ref_grads[n]).abs().max()), float(ref_grads[n].abs().max()))
     assert torch.equal(got["logits"], want)

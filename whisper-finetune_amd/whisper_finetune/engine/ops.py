@@ -10,6 +10,7 @@ from __future__ import annotations
 from typing import List, Optional, Sequence, Tuple
 
 import itertools
+import threading
 import weakref
 
 import os
@@ -832,7 +833,20 @@ def _stacked_masks(specs):
     return torch.cat([s.mask.detach().view(1, kk) for s in specs], 0)
 
 
-_COLSUMS = {}  # data_ptr -> (producing tensor, colsum)
+# data_ptr -> (producing tensor, colsum), PER THREAD (round 6): producer and consumer are nodes of one backward pass, i.e. run on one
+# autograd device thread; a forward on ANOTHER thread (an evaluator beside a training backward) used to clear the shared table
+# mid-pass — the consumers then fell back to wft_colsum_bf16, whose sums differ from the fused ones in the last bit
+# (tests/test_launch_mode_gpu.py failed one run in three on encoder.blocks.0.*.bias)
+_COLSUMS_TLS = threading.local()
+
+
+def _colsums() -> dict:
+    d = getattr(_COLSUMS_TLS, "d", None)
+    if d is None:
+        d = _COLSUMS_TLS.d = {}
+    return d
+
+
 # Does any bias of the running model take a gradient?  Set by the model at the start of every forward (Whisper.forward /
 # forward_loss).  False in a LoRA run (frozen base): the producer kernels then skip the fused bias-gradient column sums and
 # their reduce launches (LayerNorm backward, attention backward, the DGELU / MUL_AUX GEMM epilogue).
@@ -843,8 +857,8 @@ _K_HAS_BIAS = [False]
 
 
 def reset_colsums() -> None:
-    """Drop unconsumed entries (called at the start of every forward and of every backward pass)."""
-    _COLSUMS.clear()
+    """Drop this thread's unconsumed entries (called at the start of every forward and of every backward pass)."""
+    _colsums().clear()
 
 
 def _publish_colsum(t: torch.Tensor, cs: torch.Tensor) -> None:
@@ -852,14 +866,14 @@ def _publish_colsum(t: torch.Tensor, cs: torch.Tensor) -> None:
     the consumer a VIEW of t (reshape nodes between modules), so the link is by address.  The entry keeps `t` itself
     alive until it is consumed or the next pass starts: its storage therefore cannot be recycled for other data, and a
     consumer tensor with the same address, storage and element count IS this data."""
-    _COLSUMS[t.data_ptr()] = (t, cs)
+    _colsums()[t.data_ptr()] = (t, cs)
 
 
 def _fused_colsum(grad, dy):
     """Column sums a producer kernel already formed for exactly this gradient (LayerNorm backward for the residual
     stream, the DGELU GEMM epilogue for d(pre-activation)); None if autograd handed over different data (accumulated /
     cast / re-laid-out), in which case the caller falls back to wft_colsum_bf16."""
-    ent = _COLSUMS.pop(dy.data_ptr(), None)
+    ent = _colsums().pop(dy.data_ptr(), None)
     if ent is None:
         return None
     t, cs = ent
