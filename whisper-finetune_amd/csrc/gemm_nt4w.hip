@@ -73,10 +73,13 @@
 #ifndef NT4W_SPX
 #define NT4W_SPX 8   // X pieces in slots 39, 47, ..., 95 (measured: 6-11 within 1 %; 2 = rounds 4-5)
 #endif
+#ifndef NT4W_W0
+#define NT4W_W0 (NT4W_T1+2)   // slot of W piece 0 (>= T1+2: behind the barrier that frees the W half; 36 / 42 — behind the X set-1 reads — measured 6-12 % SLOWER: the W pieces are the first thing the next k-step waits for)
+#endif
 #ifndef NT4W_SPW
 #define NT4W_SPW 3   // W pieces in slots 19, 22, ..., 40 (2-4 equal; 6-12 measured 2-3 % slower than 2-4)
 #endif
-#define NT4W_ASM_MACROS ".set NT4W_T1, " NT4W_STR(NT4W_T1) "\n.set NT4W_T2, " NT4W_STR(NT4W_T2) "\n.set NT4W_T3, " NT4W_STR(NT4W_T3) "\n.set NT4W_T4, " NT4W_STR(NT4W_T4) "\n.set NT4W_SPX, " NT4W_STR(NT4W_SPX) "\n.set NT4W_SPW, " NT4W_STR(NT4W_SPW) "\n" R"ASM(
+#define NT4W_ASM_MACROS ".set NT4W_T1, " NT4W_STR(NT4W_T1) "\n.set NT4W_T2, " NT4W_STR(NT4W_T2) "\n.set NT4W_T3, " NT4W_STR(NT4W_T3) "\n.set NT4W_T4, " NT4W_STR(NT4W_T4) "\n.set NT4W_SPX, " NT4W_STR(NT4W_SPX) "\n.set NT4W_SPW, " NT4W_STR(NT4W_SPW) "\n.set NT4W_W0, " NT4W_STR(NT4W_W0) "\n" R"ASM(
 .macro NT4W_MFMA s, z
   .if \z
     v_mfma_f32_16x16x32_bf16 a[4*((\s)%%64):4*((\s)%%64)+3], v[128+64*((\s)/64)+4*((\s)%%8):128+64*((\s)/64)+4*((\s)%%8)+3], v[160+64*((\s)/64)+4*(((\s)%%64)/8):160+64*((\s)/64)+4*(((\s)%%64)/8)+3], 0
@@ -118,10 +121,10 @@
   .set nt4w_wax, 0
   .set nt4w_j, 0
   .rept 8
-    .if (NT4W_T2+2+NT4W_SPX*nt4w_j) >= (NT4W_T1+2+NT4W_SPW*7)   ; (inside a slot the W piece is issued first)
+    .if (NT4W_T2+2+NT4W_SPX*nt4w_j) >= (NT4W_W0+NT4W_SPW*7)   ; (inside a slot the W piece is issued first)
       .set nt4w_xaw, nt4w_xaw+1
     .endif
-    .if (NT4W_T1+2+NT4W_SPW*nt4w_j) > (NT4W_T2+2+NT4W_SPX*7)
+    .if (NT4W_W0+NT4W_SPW*nt4w_j) > (NT4W_T2+2+NT4W_SPX*7)
       .set nt4w_wax, nt4w_wax+1
     .endif
     .set nt4w_j, nt4w_j+1
@@ -141,9 +144,9 @@
     .if nt4w_s == NT4W_T1+1
       s_barrier
     .endif
-    .if (nt4w_s >= NT4W_T1+2) && (nt4w_s < NT4W_T1+2+8*NT4W_SPW) && (((nt4w_s-NT4W_T1-2) %% NT4W_SPW) == 0)
+    .if (nt4w_s >= NT4W_W0) && (nt4w_s < NT4W_W0+8*NT4W_SPW) && (((nt4w_s-NT4W_W0) %% NT4W_SPW) == 0)
       .if \ld
-        NT4W_DMA (nt4w_s-NT4W_T1-2)/NT4W_SPW, 120, 44, \mW
+        NT4W_DMA (nt4w_s-NT4W_W0)/NT4W_SPW, 120, 44, \mW
         .set nt4w_iss, nt4w_iss+1
       .endif
     .endif
@@ -162,7 +165,7 @@
         .set nt4w_iss, nt4w_iss+1
       .endif
     .endif
-    .if ((NT4W_T2+2+7*NT4W_SPX >= NT4W_T1+2+7*NT4W_SPW) && (nt4w_s == NT4W_T2+4+7*NT4W_SPX)) || ((NT4W_T2+2+7*NT4W_SPX < NT4W_T1+2+7*NT4W_SPW) && (nt4w_s == NT4W_T1+4+7*NT4W_SPW))
+    .if ((NT4W_T2+2+7*NT4W_SPX >= NT4W_W0+7*NT4W_SPW) && (nt4w_s == NT4W_T2+4+7*NT4W_SPX)) || ((NT4W_T2+2+7*NT4W_SPX < NT4W_W0+7*NT4W_SPW) && (nt4w_s == NT4W_W0+2+7*NT4W_SPW))
       .if \ld
         s_add_u32 s40, s40, 128
         s_addc_u32 s41, s41, 0
